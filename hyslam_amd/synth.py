@@ -1,0 +1,84 @@
+"""Deterministic synthetic grey images for tests and bench.
+
+Pure-noise images saturate FAST, so frames are *structured*: a smooth gradient background,
+a few thousand filled rectangles / discs with random grey levels (each with its own stereo
+disparity, painted far-to-near) and sigma~2 pixel noise.  Everything is integer arithmetic on a
+counter-based SplitMix64 stream, so the same seed gives the same bytes on every machine
+(no dependence on numpy's own generators).
+"""
+import numpy as np
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed, n, stream=0):
+    """n 64-bit words of the SplitMix64 sequence started at `seed` (+ an independent stream id)."""
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed) * np.uint64(0xD1342543DE82EF95) + np.uint64(stream) * np.uint64(0xDA942042E4DD58B5)
+        z = base + (np.arange(1, n + 1, dtype=np.uint64) * _GAMMA)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _noise(seed, stream, h, w):
+    """integer noise ~ N(0, 2): centred sum of 8 uniform bytes, scaled."""
+    r = splitmix64(seed, h * w, stream).view(np.uint8).reshape(h * w, 8).astype(np.int32).sum(axis=1)
+    return np.floor_divide((r - 1020) * 2 + 104, 209).reshape(h, w)
+
+
+def _scene(seed, w, h, n_shapes):
+    r = splitmix64(seed, n_shapes * 8, stream=1).reshape(n_shapes, 8)
+    x0 = (r[:, 0] % np.uint64(w + 64)).astype(np.int64) - 32
+    y0 = (r[:, 1] % np.uint64(h + 64)).astype(np.int64) - 32
+    sw = 8 + (r[:, 2] % np.uint64(112)).astype(np.int64)
+    sh = 8 + (r[:, 3] % np.uint64(112)).astype(np.int64)
+    grey = (r[:, 4] % np.uint64(256)).astype(np.int64)
+    disc = (r[:, 5] % np.uint64(4)) == 0
+    disp = 4 + (r[:, 6] % np.uint64(117)).astype(np.int64)      # stereo disparity in [4,120]
+    order = np.argsort(disp, kind="stable")                     # far first, near painted last
+    return [(int(x0[i]), int(y0[i]), int(sw[i]), int(sh[i]), int(grey[i]), bool(disc[i]), int(disp[i])) for i in order]
+
+
+def _render(scene, w, h, shift_sign, bg_disp):
+    xs = np.arange(w, dtype=np.int64)[None, :] + (bg_disp if shift_sign else 0)
+    ys = np.arange(h, dtype=np.int64)[:, None]
+    img = 56 + (xs * 96) // max(w, 1) + (ys * 48) // max(h, 1) + (((xs // 97) + (ys // 61)) % 2) * 6
+    img = img.astype(np.int32)
+    for (x0, y0, sw, sh, grey, disc, disp) in scene:
+        xa = x0 - (disp if shift_sign else 0)
+        xb, ya, yb = xa + sw, y0, y0 + sh
+        cxa, cxb, cya, cyb = max(xa, 0), min(xb, w), max(ya, 0), min(yb, h)
+        if cxa >= cxb or cya >= cyb:
+            continue
+        if not disc:
+            img[cya:cyb, cxa:cxb] = grey
+        else:
+            yy = np.arange(cya, cyb, dtype=np.int64)[:, None] * 2 - (ya + yb - 1)
+            xx = np.arange(cxa, cxb, dtype=np.int64)[None, :] * 2 - (xa + xb - 1)
+            m = (xx * xx) * (sh * sh) + (yy * yy) * (sw * sw) <= (sw * sw) * (sh * sh)
+            sub = img[cya:cyb, cxa:cxb]
+            sub[m] = grey
+    return img
+
+
+def synth_image(seed, w, h, n_shapes=None):
+    """One structured grey frame (uint8, h x w)."""
+    if n_shapes is None:
+        n_shapes = max(40, (w * h) // 800)
+    img = _render(_scene(seed, w, h, n_shapes), w, h, False, 0) + _noise(seed, 2, h, w)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_stereo_pair(seed, w, h, n_shapes=None):
+    """Rectified stereo pair: the right frame renders the same scene with every shape moved left by
+    its own disparity (background: 4 px) and independent noise."""
+    if n_shapes is None:
+        n_shapes = max(40, (w * h) // 800)
+    scene = _scene(seed, w, h, n_shapes)
+    left = _render(scene, w, h, False, 4) + _noise(seed, 2, h, w)
+    right = _render(scene, w, h, True, 4) + _noise(seed, 3, h, w)
+    return np.clip(left, 0, 255).astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8)

@@ -1,0 +1,126 @@
+/* hs_oracle.h — CPU ORACLE for the hySLAM ORB extract + Hamming match hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load this library.  The shipped path (hyslam_amd/) never links,
+ * imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference (bmhopkinson/hyslam) has no test, golden
+ * vector or fixture for this path and cannot be compiled here: every
+ * hot-path translation unit needs OpenCV 3.4 (cv::FAST, cv::resize, cv::GaussianBlur,
+ * cv::fastAtan2, cvRound), which is neither vendored in /root/reference nor installed.
+ * This file is therefore a dependency-free *restatement*:
+ *   - hySLAM's own logic follows the reference line by line (citations below, all relative
+ *     to /root/reference/);
+ *   - the OpenCV 3.4 primitives follow OpenCV 3.4's published algorithms (modules/features2d/
+ *     src/fast.cpp, fast_score.cpp; modules/imgproc/src/resize.cpp, smooth.cpp; modules/core/
+ *     src/mathfuncs_core.simd.hpp), x86-64 baseline build (SSE2, no FMA, no IPP), see
+ *     SURVEY.md Appendix A.
+ * What pins it instead: the source-derived known-answer tables T1–T5 of SURVEY.md §8d
+ * (tests/test_oracle_kat.py), an independent numpy restatement of every primitive
+ * (tests/pyref.py) and committed golden vectors produced by this oracle (tests/golden/).
+ *
+ * Documented deviations from the (non-deterministic / UB) reference behaviour:
+ *   D1  DistributeOctTree sorts pair<int,ExtractorNode*> (src/features/ORBExtractor.cpp:321-324),
+ *       i.e. ties between equally populated nodes are broken by heap address.  The oracle
+ *       replaces the pointer with the node's creation sequence number (what a monotone
+ *       allocator yields).
+ *   D2  Stereomatcher indexes vRowIndices[yi] without bounds checks (Stereomatcher.cpp:53-63)
+ *       and reads vDistIdx[size/2] of an empty vector (:143).  The oracle drops rows outside
+ *       [0,nRows) and skips the median filter when there is no match.
+ *   D3  GaussianBlur fixed-point taps are OpenCV-version dependent; default {18,34,49,55,49,34,18}
+ *       (OpenCV 3.4.1..3.4.8 ufixedpoint16 rounding), overridable per call.
+ */
+#ifndef HS_ORACLE_H
+#define HS_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hso_keypoint {      /* the cv::KeyPoint fields the reference sets */
+    float x, y, size, angle, response;
+    int32_t octave;
+} hso_keypoint;
+
+typedef struct hso_orb_params {    /* HYSLAM::FeatureExtractorSettings (src/core/FeatureExtractorSettings.h:19-32) */
+    int32_t nfeatures;             /* nFeatures      */
+    float   scale_factor;          /* fScaleFactor   */
+    int32_t nlevels;               /* nLevels        */
+    int32_t cell_px;               /* N_CELLS — used as cell edge in pixels (ORBExtractor.cpp:409,425) */
+    int32_t ini_th_fast;           /* init_threshold — ignored by the reference (ORBFinder.cpp:58-60) */
+    int32_t min_th_fast;           /* min_threshold  — ignored likewise                             */
+    int32_t fast_threshold;        /* effective FAST threshold; reference: always 20 (ORBFinder.h:92) */
+    uint16_t blur_taps[7];         /* 8.8 fixed-point 7-tap Gaussian; all-zero => default           */
+    uint16_t _pad;
+} hso_orb_params;
+
+typedef struct hso_stereo_params { /* what Stereomatcher reads from Camera / settings (Stereomatcher.cpp:7-24) */
+    float   fx;                    /* camera.fx()                 */
+    float   mbf;                   /* camera.mbf                  */
+    int32_t n_rows;                /* (int)camera.mnMaxY          */
+    float   th_high, th_low;       /* FeatureMatcherSettings      */
+    float   size_ref;              /* orb_params.size_ref (31)    */
+} hso_stereo_params;
+
+/* ---- scalar helpers / tables (E0) ---- */
+int   hso_cv_round_f(float v);
+int   hso_cv_round_d(double v);
+float hso_fast_atan2(float y, float x);
+void  hso_default_params(hso_orb_params* p);
+int   hso_scale_tables(const hso_orb_params* p, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* quotas);
+void  hso_pyramid_size(const hso_orb_params* p, int w, int h, int level, int32_t* lw, int32_t* lh);
+void  hso_cell_grid(const hso_orb_params* p, int lw, int lh, int32_t* ncols, int32_t* nrows, int32_t* wcell, int32_t* hcell);
+void  hso_umax(int32_t* umax16);
+const int32_t* hso_pattern(void);
+
+/* ---- OpenCV primitives (Appendix A) ---- */
+void hso_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+/* out: triplets (x, y, score) int32; returns number found (may exceed cap; only cap written) */
+int  hso_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, int32_t* out_xys, int cap);
+void hso_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const uint16_t* taps7);
+
+/* ---- ORBFinder pieces ---- */
+float hso_ic_angle(const uint8_t* img, int stride, float x, float y);
+void  hso_orb_descriptor(const uint8_t* img, int stride, float x, float y, float angle, uint8_t* desc32);
+int   hso_hamming256(const uint8_t* a, const uint8_t* b);
+
+/* ---- ORBExtractor pieces ---- */
+/* candidates: (x,y,response) float triplets in vToDistributeKeys order; out_idx: index of the kept
+ * candidate per surviving node in final list order.  Returns count. */
+int hso_distribute_octtree(const float* cand_xyr, int n, int minX, int maxX, int minY, int maxY, int N,
+                           int32_t* out_idx, int cap);
+/* per-level candidate list as produced by ComputeKeyPointsOctTree before distribution:
+ * (x,y,response) relative to (minBorderX,minBorderY)=(16,16).  Returns count (may exceed cap). */
+int hso_level_candidates(const hso_orb_params* p, const uint8_t* level_img, int lw, int lh, int stride,
+                         float* out_xyr, int cap);
+
+typedef struct hso_extract_debug {  /* optional taps into the stages, caller-allocated, may be NULL */
+    uint8_t** pyramid;              /* [nlevels] buffers of lw*lh (tight stride) or NULL */
+    uint8_t** blurred;              /* [nlevels] idem */
+    int32_t*  n_candidates;         /* [nlevels] */
+    int32_t*  n_selected;           /* [nlevels] */
+    float**   candidates;           /* [nlevels] (x,y,resp) triplets, cap cand_cap each, or NULL */
+    int32_t   cand_cap;
+} hso_extract_debug;
+
+/* ORBExtractor::operator() (ORBExtractor.cpp:496-562).  Returns number of keypoints (<= cap), or <0 on error. */
+int hso_orb_extract(const hso_orb_params* p, const uint8_t* img, int w, int h, int stride,
+                    hso_keypoint* kps, uint8_t* desc, int cap, hso_extract_debug* dbg);
+
+/* ---- Stereomatcher::computeStereoMatches (Stereomatcher.cpp:36-156) ---- */
+int hso_stereo_match(const hso_keypoint* kpsL, const uint8_t* descL, int nL,
+                     const hso_keypoint* kpsR, const uint8_t* descR, int nR,
+                     const hso_stereo_params* sp, float* uRight, float* depth, int32_t* best_idx, int32_t* best_dist);
+
+/* ---- CPU baseline harness: ImageProcessing::ProcessStereoImage structure (ImageProcessing.cpp:69-116):
+ * left image on a spawned std::thread, right on the caller, then the stereo matcher.  Returns nL. */
+int hso_stereo_frontend(const hso_orb_params* p, const hso_stereo_params* sp,
+                        const uint8_t* imgL, const uint8_t* imgR, int w, int h, int stride,
+                        hso_keypoint* kpsL, uint8_t* descL, int32_t* nL,
+                        hso_keypoint* kpsR, uint8_t* descR, int32_t* nR, int cap,
+                        float* uRight, float* depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,233 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libhs_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by hyslam_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "_build", "libhs_oracle.so")
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("cell_px", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("fast_threshold", C.c_int32),
+                ("blur_taps", C.c_uint16 * 7), ("_pad", C.c_uint16)]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("mbf", C.c_float), ("n_rows", C.c_int32), ("th_high", C.c_float),
+                ("th_low", C.c_float), ("size_ref", C.c_float)]
+
+
+class ExtractDebug(C.Structure):
+    _fields_ = [("pyramid", C.POINTER(C.c_void_p)), ("blurred", C.POINTER(C.c_void_p)),
+                ("n_candidates", C.POINTER(C.c_int32)), ("n_selected", C.POINTER(C.c_int32)),
+                ("candidates", C.POINTER(C.c_void_p)), ("cand_cap", C.c_int32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.hso_fast_atan2.restype = C.c_float
+        L.hso_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.hso_cv_round_f.argtypes = [C.c_float]
+        L.hso_cv_round_d.argtypes = [C.c_double]
+        L.hso_ic_angle.restype = C.c_float
+        L.hso_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.hso_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.hso_pattern.restype = C.POINTER(C.c_int32)
+        _lib = L
+    return _lib
+
+
+def default_params(nfeatures=1000, scale=1.2, nlevels=8):
+    p = OrbParams()
+    lib().hso_default_params(C.byref(p))
+    p.nfeatures, p.scale_factor, p.nlevels = nfeatures, scale, nlevels
+    return p
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def scale_tables(p):
+    n = p.nlevels
+    sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+    q = np.zeros(n, np.int32)
+    lib().hso_scale_tables(C.byref(p), *(a.ctypes.data_as(C.c_void_p) for a in (sc, isc, s2, is2, q)))
+    return sc, isc, s2, is2, q
+
+
+def pyramid_size(p, w, h, level):
+    lw, lh = C.c_int32(), C.c_int32()
+    lib().hso_pyramid_size(C.byref(p), w, h, level, C.byref(lw), C.byref(lh))
+    return lw.value, lh.value
+
+
+def cell_grid(p, lw, lh):
+    v = [C.c_int32() for _ in range(4)]
+    lib().hso_cell_grid(C.byref(p), lw, lh, *(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
+
+
+def umax():
+    u = np.zeros(16, np.int32)
+    lib().hso_umax(u.ctypes.data_as(C.c_void_p))
+    return u
+
+
+def pattern():
+    return np.ctypeslib.as_array(lib().hso_pattern(), shape=(1024,)).copy()
+
+
+def resize_linear(src, dw, dh):
+    src, ps = _u8(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().hso_resize_linear_u8(ps, src.shape[1], src.shape[0], src.strides[0], dst.ctypes.data_as(C.c_void_p), dw, dh, dw)
+    return dst
+
+
+def fast(img, threshold=20, nonmax=True, cap=1 << 20):
+    img, pi = _u8(img)
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().hso_fast9_16(pi, img.shape[1], img.shape[0], img.strides[0], threshold, int(nonmax), out.ctypes.data_as(C.c_void_p), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def gaussian_blur7(img, taps=None):
+    img, pi = _u8(img)
+    dst = np.zeros_like(img)
+    t = None if taps is None else np.ascontiguousarray(taps, np.uint16)
+    lib().hso_gaussian_blur7(pi, img.shape[1], img.shape[0], img.strides[0], dst.ctypes.data_as(C.c_void_p), dst.strides[0],
+                             None if t is None else t.ctypes.data_as(C.c_void_p))
+    return dst
+
+
+def ic_angle(img, x, y):
+    img, pi = _u8(img)
+    return float(lib().hso_ic_angle(pi, img.strides[0], float(x), float(y)))
+
+
+def orb_descriptor(img, x, y, angle):
+    img, pi = _u8(img)
+    d = np.zeros(32, np.uint8)
+    lib().hso_orb_descriptor(pi, img.strides[0], float(x), float(y), float(angle), d.ctypes.data_as(C.c_void_p))
+    return d
+
+
+def hamming(a, b):
+    a, pa = _u8(a)
+    b, pb = _u8(b)
+    return lib().hso_hamming256(pa, pb)
+
+
+def distribute_octtree(cands_xyr, minX, maxX, minY, maxY, N):
+    c = np.ascontiguousarray(cands_xyr, np.float32).reshape(-1, 3)
+    cap = N + 64 + 4 * 16
+    out = np.zeros(cap, np.int32)
+    n = lib().hso_distribute_octtree(c.ctypes.data_as(C.c_void_p), len(c), minX, maxX, minY, maxY, N, out.ctypes.data_as(C.c_void_p), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def level_candidates(p, level_img, cap=1 << 20):
+    img, pi = _u8(level_img)
+    out = np.zeros((cap, 3), np.float32)
+    n = lib().hso_level_candidates(C.byref(p), pi, img.shape[1], img.shape[0], img.strides[0], out.ctypes.data_as(C.c_void_p), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def extract(p, img, cap=None, debug=False, cand_cap=1 << 18):
+    """Returns (kps structured array, desc (n,32) u8[, dbg dict])."""
+    img, pi = _u8(img)
+    h, w = img.shape
+    if cap is None:
+        cap = p.nfeatures + 4 * p.nlevels + 64
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    dbg = None
+    keep = []
+    if debug:
+        L = p.nlevels
+        sizes = [pyramid_size(p, w, h, l) for l in range(L)]
+        pyr = [np.zeros((lh, lw), np.uint8) for (lw, lh) in sizes]
+        blur = [np.zeros((lh, lw), np.uint8) for (lw, lh) in sizes]
+        cands = [np.zeros((cand_cap, 3), np.float32) for _ in range(L)]
+        ncand = np.zeros(L, np.int32)
+        nsel = np.zeros(L, np.int32)
+        arr = lambda lst: (C.c_void_p * L)(*[a.ctypes.data for a in lst])
+        a1, a2, a3 = arr(pyr), arr(blur), arr(cands)
+        keep = [a1, a2, a3]
+        dbg = ExtractDebug(C.cast(a1, C.POINTER(C.c_void_p)), C.cast(a2, C.POINTER(C.c_void_p)),
+                           ncand.ctypes.data_as(C.POINTER(C.c_int32)), nsel.ctypes.data_as(C.POINTER(C.c_int32)),
+                           C.cast(a3, C.POINTER(C.c_void_p)), cand_cap)
+    n = lib().hso_orb_extract(C.byref(p), pi, w, h, img.strides[0], kps.ctypes.data_as(C.c_void_p),
+                              desc.ctypes.data_as(C.c_void_p), cap, C.byref(dbg) if dbg is not None else None)
+    assert 0 <= n <= cap, n
+    if debug:
+        assert (ncand <= cand_cap).all()
+        return kps[:n].copy(), desc[:n].copy(), dict(pyramid=pyr, blurred=blur, n_candidates=ncand, n_selected=nsel,
+                                                     candidates=[c[:k].copy() for c, k in zip(cands, ncand)])
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=1080, th_high=100.0, th_low=50.0, size_ref=31.0):
+    return StereoParams(fx, mbf, n_rows, th_high, th_low, size_ref)
+
+
+def stereo_match(kpsL, descL, kpsR, descR, sp):
+    kpsL = np.ascontiguousarray(kpsL, KP_DTYPE)
+    kpsR = np.ascontiguousarray(kpsR, KP_DTYPE)
+    descL = np.ascontiguousarray(descL, np.uint8)
+    descR = np.ascontiguousarray(descR, np.uint8)
+    nL, nR = len(kpsL), len(kpsR)
+    uR = np.zeros(nL, np.float32)
+    depth = np.zeros(nL, np.float32)
+    bidx = np.zeros(nL, np.int32)
+    bdist = np.zeros(nL, np.int32)
+    lib().hso_stereo_match(kpsL.ctypes.data_as(C.c_void_p), descL.ctypes.data_as(C.c_void_p), nL,
+                           kpsR.ctypes.data_as(C.c_void_p), descR.ctypes.data_as(C.c_void_p), nR, C.byref(sp),
+                           uR.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                           bidx.ctypes.data_as(C.c_void_p), bdist.ctypes.data_as(C.c_void_p))
+    return uR, depth, bidx, bdist
+
+
+def stereo_frontend(p, sp, imgL, imgR, cap=None):
+    imgL, pl = _u8(imgL)
+    imgR, pr = _u8(imgR)
+    h, w = imgL.shape
+    if cap is None:
+        cap = p.nfeatures + 4 * p.nlevels + 64
+    kL, kR = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+    dL, dR = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    nL, nR = C.c_int32(), C.c_int32()
+    uR, depth = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    lib().hso_stereo_frontend(C.byref(p), C.byref(sp), pl, pr, w, h, imgL.strides[0],
+                              kL.ctypes.data_as(C.c_void_p), dL.ctypes.data_as(C.c_void_p), C.byref(nL),
+                              kR.ctypes.data_as(C.c_void_p), dR.ctypes.data_as(C.c_void_p), C.byref(nR), cap,
+                              uR.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p))
+    return kL[:nL.value], dL[:nL.value], kR[:nR.value], dR[:nR.value], uR[:nL.value], depth[:nL.value]
