@@ -1,0 +1,97 @@
+"""ctypes binding of libhyslam_amd.so (the C ABI in include/hyslam_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhyslam_amd.so")
+
+HS_OK, HS_ERR_INVALID, HS_ERR_HIP, HS_ERR_CAPACITY, HS_ERR_NO_DEVICE = 0, 1, 2, 3, 4
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("cell_px", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("fast_threshold", C.c_int32),
+                ("blur_taps", C.c_uint16 * 7), ("_pad", C.c_uint16)]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("mbf", C.c_float), ("n_rows", C.c_int32), ("th_high", C.c_float),
+                ("th_low", C.c_float), ("size_ref", C.c_float)]
+
+
+class HsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("hyslam_amd: %s (status %d)" % (msg, status))
+        self.status = status
+
+
+# every symbol include/hyslam_amd.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
+    "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
+    "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
+    "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
+    "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is absent — build it with `python -c 'import __graft_entry__ as g; g.build()'`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("hyslam_amd: %s not found; the HIP extension must be built (make -C hyslam_amd/csrc). "
+                          "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    L.hs_version.restype = C.c_char_p
+    L.hs_status_string.restype = C.c_char_p
+    L.hs_status_string.argtypes = [C.c_int]
+    L.hs_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.hs_orb_default_params.argtypes = [C.POINTER(OrbParams)]
+    L.hs_orb_default_params.restype = None
+    L.hs_orb_create.argtypes = [C.POINTER(OrbParams), C.c_int, C.POINTER(vp)]
+    L.hs_orb_destroy.argtypes = [vp]
+    L.hs_orb_destroy.restype = None
+    L.hs_orb_last_error.argtypes = [vp]
+    L.hs_orb_last_error.restype = C.c_char_p
+    L.hs_orb_get_levels.argtypes = [vp]
+    L.hs_orb_get_scale_factor.argtypes = [vp]
+    L.hs_orb_get_scale_factor.restype = f32
+    L.hs_orb_get_scale_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.hs_orb_max_keypoints.argtypes = [vp]
+    L.hs_orb_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.hs_orb_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+    L.hs_orb_extract_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+    L.hs_orb_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, sz, sz, vp, vp, vp, C.c_int, vp]
+    L.hs_stereo_match.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp]
+    L.hs_stereo_match_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
+    L.hs_stereo_frontend_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, sz, sz,
+                                                  vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
+    L.hs_orb_synchronize.argtypes = [vp, vp]
+    L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
+    L.hs_orb_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.hs_orb_debug_selected.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def check(handle, status):
+    if status != HS_OK:
+        L = lib()
+        msg = L.hs_status_string(status).decode()
+        if handle:
+            detail = L.hs_orb_last_error(handle).decode()
+            if detail:
+                msg += ": " + detail
+        raise HsError(status, msg)

@@ -1,0 +1,545 @@
+// hs_api.hip — host side of the C ABI declared in include/hyslam_amd.h.
+// Owns the per-handle device workspace (sized for 288 GB HBM: worst-case candidate storage, no overflow
+// paths), the host-computed tables (scale factors, per-level quotas, resize coefficients) and the launch
+// sequence.  The whole extraction of a batch is GPU-resident: pyramid -> FAST/NMS cells -> quadtree
+// distribution -> blur+orientation+rBRIEF, 10 kernel launches for an 8-level pyramid regardless of batch size.
+#include "hs_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define HS_VERSION "hyslam_amd 0.1 (gfx950)"
+
+struct hs_orb {
+    hs_orb_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint16_t taps[7];
+    // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota;
+    // geometry currently configured
+    int w = 0, h = 0, batch_cap = 0;
+    std::vector<HsLevel> lv;
+    int total_cells = 0;
+    uint64_t cand_img_stride = 0;      // candidate entries per image
+    int sel_img_stride = 0;            // selection entries per image
+    int max_kp = 0;
+    // device memory
+    HsLevel* d_lv = nullptr;
+    uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
+    int16_t* d_tables = nullptr;
+    uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr; uint16_t* d_pt_node = nullptr;
+    int32_t *d_cand_count = nullptr, *d_sel_count = nullptr;
+    uint32_t* d_sel = nullptr;
+    uint16_t* d_taps = nullptr;
+    // staging for the host-pointer entry points
+    uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
+    hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
+    float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
+    int last_batch = 0; HsImg0 last_img0{};
+};
+
+namespace {
+
+inline int cv_round_f(float v) { return (int)nearbyintf(v); }           // cvRound: round half to even
+inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+inline short sat_short(float v) { int i = cv_round_f(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); }
+
+int fail(hs_orb* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+
+#define HIP_TRY(h, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
+    return fail(h, HS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+
+void free_geometry(hs_orb* h)
+{
+    hipFree(h->d_pyr); h->d_pyr = nullptr;
+    hipFree(h->d_tables); h->d_tables = nullptr;
+    hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pt_node);
+    h->d_cand_xy = h->d_cand_sk = nullptr; h->d_pt_node = nullptr;
+    hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
+    hipFree(h->d_sel); h->d_sel = nullptr;
+}
+
+// (Re)build per-level geometry, tables and workspace for batches of `batch` frames of w x h.
+int configure(hs_orb* h, int w, int hh, int batch)
+{
+    if (w == h->w && hh == h->h && batch <= h->batch_cap) return HS_OK;
+    if (w < 1 || hh < 1 || w > 16384 || hh > 16384 || batch < 1 || batch > 65535)
+        return fail(h, HS_ERR_INVALID, "image size / batch out of range");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_geometry(h);
+    const int L = h->p.nlevels;
+    h->lv.assign(L, HsLevel{});
+    std::vector<int16_t> tables;
+    std::vector<size_t> tab_off(L * 4, 0);
+    size_t pyr_per_img = 0; uint64_t cand = 0; int sel = 0, cells = 0;
+    std::vector<size_t> pyr_off(L, 0);
+    for (int l = 0; l < L; l++) {
+        HsLevel& V = h->lv[l];
+        V.w = cv_round_f((float)w * h->inv_scale[l]);          // ORBExtractor.cpp:568-569
+        V.h = cv_round_f((float)hh * h->inv_scale[l]);
+        if (V.w < 1 || V.h < 1) return fail(h, HS_ERR_INVALID, "pyramid level collapses to zero size");
+        V.pitch = (V.w + 63) & ~63;
+        if (l > 0) { pyr_off[l] = pyr_per_img; pyr_per_img += (size_t)V.pitch * V.h; }
+        // cell grid, ORBExtractor.cpp:413-428
+        const int minB = HS_BORDER, maxBX = V.w - HS_BORDER, maxBY = V.h - HS_BORDER;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        const float W = (float)h->p.cell_px;
+        V.ncols = width > 0 ? (int)(width / W) : 0;
+        V.nrows = height > 0 ? (int)(height / W) : 0;
+        if (V.ncols < 1 || V.nrows < 1) { V.ncols = V.nrows = 0; V.wcell = V.hcell = 0; }   // reference: division by zero (UB); no keypoints here
+        else { V.wcell = (int)ceilf(width / V.ncols); V.hcell = (int)ceilf(height / V.nrows); }
+        if (V.wcell > HS_MAX_CELL || V.hcell > HS_MAX_CELL) return fail(h, HS_ERR_INVALID, "FAST cell larger than 64 px is not supported");
+        V.cell_begin = cells; cells += V.ncols * V.nrows;
+        // quadtree, ORBExtractor.cpp:183-185
+        V.qt_w = maxBX - minB; V.qt_h = maxBY - minB;
+        V.n_ini = (V.qt_w > 0 && V.qt_h > 0) ? (int)roundf((float)V.qt_w / (float)V.qt_h) : 0;
+        if (V.ncols > 0 && V.n_ini < 1) return fail(h, HS_ERR_INVALID, "aspect ratio w/h < 0.5 is undefined behaviour in the reference (nIni == 0)");
+        if (V.n_ini > HS_QT_MAX_NODES / 4) return fail(h, HS_ERR_INVALID, "aspect ratio too wide");
+        V.hx = V.n_ini > 0 ? (float)V.qt_w / V.n_ini : 1.f;
+        V.quota = h->quota[l];
+        V.cand_cap = V.ncols * V.nrows * ((V.wcell + 1) / 2) * ((V.hcell + 1) / 2);
+        V.cand_off = cand; cand += (uint64_t)((V.cand_cap + 3) & ~3);
+        V.sel_cap = std::max(V.quota + 4, 4 * V.n_ini + 4);
+        V.sel_off = sel; sel += V.sel_cap;
+        V.scale = h->scale[l];
+        V.kp_size = (float)(int)(31 * h->scale[l]);              // ORBExtractor.cpp:478
+        // cv::resize tables (OpenCV 3.4 resize.cpp, INTER_LINEAR, 8U fixed point) from level l-1
+        if (l > 0) {
+            const int sw = h->lv[l - 1].w, sh = h->lv[l - 1].h;
+            const double scale_x = 1. / ((double)V.w / sw), scale_y = 1. / ((double)V.h / sh);
+            int xmax = V.w;
+            size_t o0 = tables.size(); tables.resize(o0 + V.w);            // xofs
+            size_t o1 = tables.size(); tables.resize(o1 + 2 * (size_t)V.w); // ialpha
+            size_t o2 = tables.size(); tables.resize(o2 + V.h);            // yofs
+            size_t o3 = tables.size(); tables.resize(o3 + 2 * (size_t)V.h); // ibeta
+            for (int dx = 0; dx < V.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_f(fx); fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx + 1 >= sw) { xmax = std::min(xmax, dx); if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+                tables[o0 + dx] = (int16_t)sx;
+                tables[o1 + 2 * dx] = sat_short((1.f - fx) * 2048);
+                tables[o1 + 2 * dx + 1] = sat_short(fx * 2048);
+            }
+            for (int dy = 0; dy < V.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_f(fy); fy -= sy;
+                tables[o2 + dy] = (int16_t)std::max(-32768, std::min(32767, sy));
+                tables[o3 + 2 * dy] = sat_short((1.f - fy) * 2048);
+                tables[o3 + 2 * dy + 1] = sat_short(fy * 2048);
+            }
+            V.xmax = xmax;
+            tab_off[4 * l] = o0; tab_off[4 * l + 1] = o1; tab_off[4 * l + 2] = o2; tab_off[4 * l + 3] = o3;
+        }
+    }
+    pyr_per_img = (pyr_per_img + 255) & ~(size_t)255;
+    h->total_cells = cells; h->cand_img_stride = cand; h->sel_img_stride = sel; h->max_kp = sel;
+
+    HIP_TRY(h, hipMalloc(&h->d_pyr, std::max<size_t>(pyr_per_img * batch, 256)));
+    HIP_TRY(h, hipMalloc(&h->d_tables, std::max<size_t>(tables.size() * sizeof(int16_t), 256)));
+    if (!tables.empty()) HIP_TRY(h, hipMemcpy(h->d_tables, tables.data(), tables.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    const size_t ce = std::max<uint64_t>(cand * batch, 64);
+    HIP_TRY(h, hipMalloc(&h->d_cand_xy, ce * 4));
+    HIP_TRY(h, hipMalloc(&h->d_cand_sk, ce * 4));
+    HIP_TRY(h, hipMalloc(&h->d_pt_node, ce * 2));
+    HIP_TRY(h, hipMalloc(&h->d_cand_count, (size_t)batch * L * 4));
+    HIP_TRY(h, hipMalloc(&h->d_sel_count, (size_t)batch * L * 4));
+    HIP_TRY(h, hipMalloc(&h->d_sel, std::max<size_t>((size_t)sel * batch * 12, 64)));
+    for (int l = 0; l < L; l++) {
+        HsLevel& V = h->lv[l];
+        V.img_stride = pyr_per_img;
+        V.base = l > 0 ? h->d_pyr + pyr_off[l] : nullptr;
+        if (l > 0) {
+            V.xofs = h->d_tables + tab_off[4 * l]; V.ialpha = h->d_tables + tab_off[4 * l + 1];
+            V.yofs = h->d_tables + tab_off[4 * l + 2]; V.ibeta = h->d_tables + tab_off[4 * l + 3];
+        }
+    }
+    HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
+    h->w = w; h->h = hh; h->batch_cap = batch;
+    return HS_OK;
+}
+
+int ensure_outputs(hs_orb* h, int batch, int cap)
+{
+    if (batch <= h->out_batch && cap == h->out_cap) return HS_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
+    h->d_kps = nullptr; h->d_desc = nullptr; h->d_n = nullptr;
+    batch = std::max(batch, h->out_batch);
+    HIP_TRY(h, hipMalloc(&h->d_kps, (size_t)batch * cap * sizeof(hs_keypoint)));
+    HIP_TRY(h, hipMalloc(&h->d_desc, (size_t)batch * cap * HS_DESC_BYTES));
+    HIP_TRY(h, hipMalloc(&h->d_n, (size_t)batch * 4));
+    h->out_batch = batch; h->out_cap = cap;
+    return HS_OK;
+}
+
+int ensure_stereo_scratch(hs_orb* h, size_t entries)
+{
+    if (entries <= h->st_entries) return HS_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd);
+    h->d_ur = h->d_depth = nullptr; h->d_bd = nullptr;
+    HIP_TRY(h, hipMalloc(&h->d_ur, entries * 4));
+    HIP_TRY(h, hipMalloc(&h->d_depth, entries * 4));
+    HIP_TRY(h, hipMalloc(&h->d_bd, entries * 4));
+    h->st_entries = entries;
+    return HS_OK;
+}
+
+int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
+{
+    const int L = h->p.nlevels;
+    HIP_TRY(h, hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * L * 4, s));
+    hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+    hs_launch_fast(h->d_lv, L, img0, batch, h->total_cells, h->p.fast_threshold,
+                   h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride, s);
+    hs_launch_quadtree(h->d_lv, L, batch, h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride,
+                       h->d_pt_node, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
+    hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->sel_img_stride, h->max_kp,
+                       h->d_taps, out, s);
+    HIP_TRY(h, hipGetLastError());
+    h->last_batch = batch; h->last_img0 = img0;
+    return HS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* hs_version(void) { return HS_VERSION; }
+
+const char* hs_status_string(int s)
+{
+    switch (s) {
+    case HS_OK: return "ok";
+    case HS_ERR_INVALID: return "invalid argument";
+    case HS_ERR_HIP: return "HIP runtime error";
+    case HS_ERR_CAPACITY: return "output capacity too small";
+    case HS_ERR_NO_DEVICE: return "no usable device";
+    default: return "unknown status";
+    }
+}
+
+int hs_device_count(int* count)
+{
+    if (!count) return HS_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return HS_ERR_NO_DEVICE; }
+    *count = n;
+    return HS_OK;
+}
+
+void hs_orb_default_params(hs_orb_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->cell_px = 30;
+    p->ini_th_fast = 20; p->min_th_fast = 4;
+    p->fast_threshold = 20;      // ORBFinder's in-class default; setThreshold() never changes it (ORBFinder.cpp:58-60)
+    static const uint16_t t[7] = { 18, 34, 49, 55, 49, 34, 18 };
+    memcpy(p->blur_taps, t, sizeof(t));
+}
+
+int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
+{
+    if (!p || !out) return HS_ERR_INVALID;
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > HS_MAX_LEVELS || p->nfeatures < 1 || !(p->scale_factor > 1.0f) || p->cell_px < 8 ||
+        p->fast_threshold < 0 || p->fast_threshold > 255)
+        return HS_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return HS_ERR_NO_DEVICE;
+    hs_orb* h = new hs_orb();
+    h->p = *p; h->device = device;
+    bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
+    static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
+    for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];
+
+    // ORBExtractor::ORBExtractor (ORBExtractor.cpp:86-118); scaleFactor is a double member fed from a float setting
+    const int L = p->nlevels;
+    const double scaleFactor = p->scale_factor;
+    h->scale.resize(L); h->inv_scale.resize(L); h->sigma2.resize(L); h->inv_sigma2.resize(L); h->quota.resize(L);
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) { h->scale[i] = (float)(h->scale[i - 1] * scaleFactor); h->sigma2[i] = h->scale[i] * h->scale[i]; }
+    for (int i = 0; i < L; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+    float factor = (float)(1.0f / scaleFactor);
+    float nDesired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) { h->quota[l] = cv_round_f(nDesired); sum += h->quota[l]; nDesired *= factor; }
+    h->quota[L - 1] = std::max(p->nfeatures - sum, 0);
+    for (int l = 0; l < L; l++)
+        if (h->quota[l] + 8 > HS_QT_MAX_NODES) { delete h; return HS_ERR_INVALID; }
+
+    if (hipSetDevice(device) != hipSuccess) { delete h; return HS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&h->d_lv, sizeof(HsLevel) * HS_MAX_LEVELS) != hipSuccess ||
+        hipMalloc(&h->d_taps, 16) != hipSuccess ||
+        hipMemcpy(h->d_taps, h->taps, 14, hipMemcpyHostToDevice) != hipSuccess) {
+        hs_orb_destroy(h);
+        return HS_ERR_HIP;
+    }
+    *out = h;
+    return HS_OK;
+}
+
+void hs_orb_destroy(hs_orb* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    free_geometry(h);
+    hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
+    hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
+    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* hs_orb_last_error(const hs_orb* h) { return h ? h->err.c_str() : "null handle"; }
+int hs_orb_get_levels(const hs_orb* h) { return h ? h->p.nlevels : 0; }
+float hs_orb_get_scale_factor(const hs_orb* h) { return h ? (float)(double)h->p.scale_factor : 0.f; }
+
+int hs_orb_get_scale_tables(const hs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl)
+{
+    if (!h) return HS_ERR_INVALID;
+    for (int i = 0; i < h->p.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+        if (fpl) fpl[i] = h->quota[i];
+    }
+    return HS_OK;
+}
+
+int hs_orb_max_keypoints(const hs_orb* h)
+{
+    if (!h) return 0;
+    // DistributeOctTree stops at the first split that reaches N nodes: at most N+2 per level, or the
+    // 4*nIni nodes of the unconditional first pass.  nIni depends on the frame; assume the widest supported.
+    int n = 0;
+    for (int l = 0; l < h->p.nlevels; l++) n += std::max(h->quota[l] + 4, 4 * 8 + 4);
+    return n;
+}
+
+int hs_orb_reserve(hs_orb* h, int w, int h_px, int batch)
+{
+    if (!h) return HS_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return configure(h, w, h_px, batch);
+}
+
+int hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, int w, int h_px,
+                                size_t row_stride, size_t image_stride,
+                                hs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!d_imgs || !d_kps || !d_desc || !d_n || batch < 1 || row_stride < (size_t)w || cap < 1 || cap > 65535)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = configure(h, w, h_px, batch);
+    if (rc != HS_OK) return rc;
+    if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HsImg0 img0{ d_imgs, d_imgs, batch, (uint64_t)row_stride, (uint64_t)image_stride };
+    HsOut out{ d_kps, d_desc, d_n, d_kps, d_desc, d_n, batch, cap };
+    return run_extract(h, img0, batch, out, s);
+}
+
+int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride,
+                         hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!n || batch < 1) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (w == 0 || h_px == 0 || !imgs) { for (int i = 0; i < batch; i++) n[i] = 0; return HS_OK; }   // ORBExtractor.cpp:499-500
+    if (!kps || !desc || stride < w || cap < 1 || cap > 65535) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = configure(h, w, h_px, batch);
+    if (rc != HS_OK) return rc;
+    if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
+    const size_t pitch = ((size_t)w + 63) & ~(size_t)63, per_img = pitch * h_px;
+    if (per_img * batch > h->in_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        hipFree(h->d_in); h->d_in = nullptr;
+        HIP_TRY(h, hipMalloc(&h->d_in, per_img * batch));
+        h->in_bytes = per_img * batch;
+    }
+    rc = ensure_outputs(h, batch, cap);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    for (int i = 0; i < batch; i++) {
+        if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
+        HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
+    }
+    HsImg0 img0{ h->d_in, h->d_in, batch, (uint64_t)pitch, (uint64_t)per_img };
+    HsOut out{ h->d_kps, h->d_desc, h->d_n, h->d_kps, h->d_desc, h->d_n, batch, cap };
+    rc = run_extract(h, img0, batch, out, s);
+    if (rc != HS_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(n, h->d_n, (size_t)batch * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(kps, h->d_kps, (size_t)batch * cap * sizeof(hs_keypoint), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(desc, h->d_desc, (size_t)batch * cap * HS_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
+int hs_orb_extract(hs_orb* h, const uint8_t* img, int w, int h_px, int stride,
+                   hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!n) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (!img || w == 0 || h_px == 0) { *n = 0; return HS_OK; }
+    const uint8_t* one[1] = { img };
+    return hs_orb_extract_batch(h, one, 1, w, h_px, stride, kps, desc, cap, n);
+}
+
+int hs_stereo_match_batch_device(hs_orb* h, const hs_keypoint* d_kpsL, const uint8_t* d_descL, const int32_t* d_nL,
+                                 const hs_keypoint* d_kpsR, const uint8_t* d_descR, const int32_t* d_nR,
+                                 int pairs, int cap, const hs_stereo_params* sp,
+                                 float* d_uRight, float* d_depth, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!d_kpsL || !d_descL || !d_nL || !d_kpsR || !d_descR || !d_nR || !sp || !d_uRight || !d_depth ||
+        pairs < 1 || pairs > 65535 || cap < 1 || cap > 65535)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hs_launch_stereo(d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, h->d_bd, s);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_stereo_match(hs_orb* h, const hs_keypoint* kpsL, const uint8_t* descL, int nL,
+                    const hs_keypoint* kpsR, const uint8_t* descR, int nR,
+                    const hs_stereo_params* sp, float* uRight, float* depth)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!sp || nL < 0 || nR < 0 || nL > 65535 || nR > 65535) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (nL == 0) return HS_OK;
+    if (!kpsL || !descL || !uRight || !depth || (nR > 0 && (!kpsR || !descR))) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int cap = std::max(std::max(nL, nR), 1);
+    hipStream_t s = h->stream;
+    hs_keypoint *dk = nullptr; uint8_t* dd = nullptr; int32_t* dn = nullptr;
+    HIP_TRY(h, hipMalloc(&dk, (size_t)2 * cap * sizeof(hs_keypoint)));
+    HIP_TRY(h, hipMalloc(&dd, (size_t)2 * cap * HS_DESC_BYTES));
+    HIP_TRY(h, hipMalloc(&dn, 8));
+    int rc = ensure_stereo_scratch(h, (size_t)cap);
+    int32_t cnt[2] = { nL, nR };
+    hipError_t e = hipSuccess;
+    if (rc == HS_OK) {
+        e = hipMemcpyAsync(dk, kpsL, (size_t)nL * sizeof(hs_keypoint), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && nR) e = hipMemcpyAsync(dk + cap, kpsR, (size_t)nR * sizeof(hs_keypoint), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dd, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && nR) e = hipMemcpyAsync(dd + (size_t)cap * 32, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dn, cnt, 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hs_launch_stereo(dk, dd, dn, dk + cap, dd + (size_t)cap * 32, dn + 1, 1, cap, *sp, h->d_ur, h->d_depth, h->d_bd, s);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(uRight, h->d_ur, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(depth, h->d_depth, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    hipFree(dk); hipFree(dd); hipFree(dn);
+    if (rc != HS_OK) return rc;
+    if (e != hipSuccess) return fail(h, HS_ERR_HIP, hipGetErrorString(e));
+    return HS_OK;
+}
+
+int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint8_t* d_right, int pairs,
+                                    int w, int h_px, size_t row_stride, size_t image_stride,
+                                    hs_keypoint* d_kpsL, uint8_t* d_descL, int32_t* d_nL,
+                                    hs_keypoint* d_kpsR, uint8_t* d_descR, int32_t* d_nR, int cap,
+                                    const hs_stereo_params* sp, float* d_uRight, float* d_depth, void* stream)
+{
+    // The reference runs two ORBExtractor instances side by side (ImageProcessing.cpp:82-83); here the left and
+    // right frames of all pairs go through ONE launch sequence (images [0,pairs) = left, [pairs,2*pairs) = right).
+    if (!h) return HS_ERR_INVALID;
+    if (!d_left || !d_right || !d_kpsL || !d_descL || !d_nL || !d_kpsR || !d_descR || !d_nR || !sp || !d_uRight || !d_depth ||
+        pairs < 1 || 2 * pairs > 65535 || row_stride < (size_t)w || cap < 1 || cap > 65535)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = configure(h, w, h_px, 2 * pairs);
+    if (rc != HS_OK) return rc;
+    if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
+    rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HsImg0 img0{ d_left, d_right, pairs, (uint64_t)row_stride, (uint64_t)image_stride };
+    HsOut out{ d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap };
+    rc = run_extract(h, img0, 2 * pairs, out, s);
+    if (rc != HS_OK) return rc;
+    hs_launch_stereo(d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, h->d_bd, s);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_orb_synchronize(hs_orb* h, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(stream ? (hipStream_t)stream : h->stream));
+    return HS_OK;
+}
+
+int hs_orb_debug_level(hs_orb* h, int image, int level, uint8_t* out, size_t cap_bytes, int32_t* lw, int32_t* lh)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!out || image < 0 || image >= h->last_batch || level < 0 || level >= h->p.nlevels) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const HsLevel& V = h->lv[level];
+    if ((size_t)V.w * V.h > cap_bytes) return fail(h, HS_ERR_CAPACITY, "level larger than buffer");
+    if (lw) *lw = V.w;
+    if (lh) *lh = V.h;
+    const uint8_t* src; size_t pitch;
+    if (level == 0) { src = hs_img0_ptr(h->last_img0, image); pitch = h->last_img0.row_stride; }
+    else { src = V.base + (size_t)image * V.img_stride; pitch = V.pitch; }
+    HIP_TRY(h, hipMemcpy2D(out, V.w, src, pitch, V.w, V.h, hipMemcpyDeviceToHost));
+    return HS_OK;
+}
+
+int hs_orb_debug_candidates(hs_orb* h, int image, int level, int32_t* xys, int cap, int32_t* n)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!xys || !n || image < 0 || image >= h->last_batch || level < 0 || level >= h->p.nlevels) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const HsLevel& V = h->lv[level];
+    int32_t cnt = 0;
+    HIP_TRY(h, hipMemcpy(&cnt, h->d_cand_count + image * h->p.nlevels + level, 4, hipMemcpyDeviceToHost));
+    cnt = std::min(cnt, V.cand_cap);
+    *n = cnt;
+    if (cnt > cap) return fail(h, HS_ERR_CAPACITY, "more candidates than buffer");
+    std::vector<uint32_t> xy(cnt), sk(cnt);
+    if (cnt) {
+        HIP_TRY(h, hipMemcpy(xy.data(), h->d_cand_xy + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(sk.data(), h->d_cand_sk + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < cnt; i++) { xys[3 * i] = xy[i] & 0xFFFF; xys[3 * i + 1] = xy[i] >> 16; xys[3 * i + 2] = sk[i] >> 24; }
+    return HS_OK;
+}
+
+int hs_orb_debug_selected(hs_orb* h, int image, int level, int32_t* xys, int cap, int32_t* n)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!xys || !n || image < 0 || image >= h->last_batch || level < 0 || level >= h->p.nlevels) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const HsLevel& V = h->lv[level];
+    int32_t cnt = 0;
+    HIP_TRY(h, hipMemcpy(&cnt, h->d_sel_count + image * h->p.nlevels + level, 4, hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) return fail(h, HS_ERR_CAPACITY, "more keypoints than buffer");
+    if (cnt) HIP_TRY(h, hipMemcpy(xys, h->d_sel + ((size_t)image * h->sel_img_stride + V.sel_off) * 3, (size_t)cnt * 12, hipMemcpyDeviceToHost));
+    return HS_OK;
+}
+
+} // extern "C"

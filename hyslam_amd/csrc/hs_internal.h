@@ -1,0 +1,79 @@
+// hs_internal.h — shared declarations of the HIP implementation behind include/hyslam_amd.h.
+// gfx950 (MI355X) only: wave64, 160 KiB LDS/CU.  Compiled with -ffp-contract=off: several results
+// (resize tables, fastAtan2, rBRIEF rotation) are defined by separately rounded fp32 operations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hyslam_amd.h"
+
+#define HS_MAX_LEVELS 16
+#define HS_EDGE 19                 // EDGE_THRESHOLD, ORBExtractor.cpp:74
+#define HS_BORDER 16               // minBorderX = EDGE_THRESHOLD-3, ORBExtractor.cpp:413
+#define HS_MAX_CELL 64             // largest FAST cell interior edge the cell kernel's LDS tile holds
+#define HS_QT_MAX_NODES 2048       // quadtree list capacity in LDS (>= largest per-level quota + 8)
+#define HS_QT_THREADS 1024
+
+// Per-level geometry and buffers; lives in device memory, read through scalar loads.
+struct HsLevel {
+    int32_t w, h;                  // level size (ORBExtractor.cpp:568-569)
+    int32_t pitch;                 // row pitch of the level buffer (levels >= 1)
+    int32_t _r0;
+    uint64_t img_stride;           // bytes between consecutive images of this level's buffer
+    uint8_t* base;                 // level buffer (levels >= 1; level 0 is the caller's image)
+    // FAST cell grid (ORBExtractor.cpp:413-428)
+    int32_t ncols, nrows, wcell, hcell;
+    int32_t cell_begin;            // first block index of this level in the all-levels cell launch
+    // DistributeOctTree inputs (ORBExtractor.cpp:179-203,475-476)
+    int32_t qt_w, qt_h;            // maxBorderX-minBorderX, maxBorderY-minBorderY
+    int32_t n_ini;                 // round(qt_w / qt_h)
+    float   hx;                    // qt_w / n_ini
+    int32_t quota;                 // mnFeaturesPerLevel[level]
+    // candidate / selection storage (entries, per image)
+    int32_t cand_cap;
+    int32_t sel_cap;
+    uint64_t cand_off;             // offset of this level inside one image's candidate arrays
+    int32_t sel_off;               // offset inside one image's selection arrays
+    // resize tables (cv::resize INTER_LINEAR, fixed point), device pointers; level >= 1
+    int32_t xmax;
+    const int16_t* xofs;           // [w]
+    const int16_t* ialpha;         // [w][2]
+    const int16_t* yofs;           // [h]
+    const int16_t* ibeta;          // [h][2]
+    float scale;                   // mvScaleFactor[level]
+    float kp_size;                 // (int)(31*scale)
+};
+
+struct HsImg0 {                    // level 0 = the caller's frames; images [0,split) from base, the rest from base2
+    const uint8_t* base;           // (left / right frames of a stereo batch go through one launch sequence)
+    const uint8_t* base2;
+    int32_t split;
+    uint64_t row_stride;
+    uint64_t img_stride;
+};
+__host__ __device__ inline const uint8_t* hs_img0_ptr(const HsImg0& I, int img)
+{
+    return img < I.split ? I.base + (size_t)img * I.img_stride : I.base2 + (size_t)(img - I.split) * I.img_stride;
+}
+
+struct HsOut {                     // extractor outputs, split the same way
+    hs_keypoint* kps; uint8_t* desc; int32_t* n;
+    hs_keypoint* kps2; uint8_t* desc2; int32_t* n2;
+    int32_t split;
+    int32_t cap;
+};
+
+// kernels_*.hip launchers (all asynchronous on `s`)
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
+                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cand_count, uint64_t cand_img_stride, hipStream_t s);
+void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch,
+                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cand_count, uint64_t cand_img_stride,
+                        uint16_t* pt_node, uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s);
+void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
+                        const uint32_t* sel_xys, const int32_t* sel_count, int sel_img_stride, int max_sel,
+                        const uint16_t* taps7, HsOut out, hipStream_t s);
+void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
+                      const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
+                      int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
+                      int32_t* best_dist /*[pairs][cap] scratch*/, hipStream_t s);

@@ -1,0 +1,191 @@
+// kernels_describe.hip — K5+K6+K7 fused: 7x7 Gaussian blur (patch-local), intensity-centroid orientation,
+// 256-bit rotated BRIEF descriptor, final keypoint record.  One wavefront per keypoint.
+//
+// Replaces, per level (src/features/ORBExtractor.cpp:535-555):
+//     workingMat = level.clone(); GaussianBlur(workingMat, workingMat, Size(7,7), 2, 2, BORDER_REFLECT_101);
+//     feature_finder->compute(workingMat, keypoints, desc);   // ORBFinder.cpp:70-129
+//     keypoint->pt *= scale
+// The reference blurs whole levels (6.4 Mpx read + write per 1080p frame) although only the 37x37
+// neighbourhood of ~2000 keypoints is ever sampled.  The blur is a pure function of the 43x43 raw
+// neighbourhood (reflect-101 at the level border), so it is evaluated per keypoint in LDS: 1849 B read per
+// keypoint instead of 2*P/K = 6419 B, and no blurred image ever goes to HBM.  Results are identical.
+//
+// Arithmetic:
+//   blur   : unsigned 8.8 fixed-point taps, 16-bit saturating row sums, 32-bit column sums, (acc+0x8000)>>16
+//   angle  : integer moments over the 749-px disc (umax table), cv::fastAtan2 polynomial in fp32, no FMA
+//   rBRIEF : a=(float)cos(theta), b=(float)sin(theta) evaluated in double; offsets = round-half-even of
+//            separately rounded fp32 products; bit i of byte j = test 8j+i -> one ballot per 64 tests.
+#include "hs_internal.h"
+#include "../../include/hyslam_orb_pattern.h"
+
+__constant__ int8_t c_pattern[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
+__constant__ int8_t c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBFinder.cpp:131-149
+
+#define RAW_N 43
+#define RAW_P 44
+#define BL_N 37
+#define H_P 38
+#define BL_P 40
+#define KP_PER_BLOCK 4
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p < 0 ? 0 : p;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2 (OpenCV 3.4 mathfuncs_core atan_f32); every operation individually rounded
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)2.2204460492503131e-16));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)2.2204460492503131e-16));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0,
+                                                                 const uint32_t* __restrict__ sel_xys, const int32_t* __restrict__ sel_count,
+                                                                 int sel_img_stride, const uint16_t* __restrict__ taps7,
+                                                                 HsOut O)
+{
+    __shared__ uint8_t s_raw[KP_PER_BLOCK][RAW_N * RAW_P];
+    __shared__ uint16_t s_h[KP_PER_BLOCK][RAW_N * H_P];
+    __shared__ uint8_t s_bl[KP_PER_BLOCK][BL_N * BL_P];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int img = blockIdx.y;
+    const int g = blockIdx.x * KP_PER_BLOCK + wv;          // keypoint index inside the image (levels concatenated)
+
+    // locate the level: prefix over the per-level selection counts (wave-uniform scalar loop)
+    int level = -1, first = 0, total = 0;
+    for (int l = 0; l < nlevels; l++) {
+        int c = sel_count[img * nlevels + l];
+        if (level < 0 && g < total + c) { level = l; first = total; }
+        total += c;
+    }
+    const int cap = O.cap;
+    const bool second = img >= O.split;
+    const int oimg = second ? img - O.split : img;
+    hs_keypoint* kps = second ? O.kps2 : O.kps;
+    uint8_t* desc = second ? O.desc2 : O.desc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) (second ? O.n2 : O.n)[oimg] = min(total, cap);
+    if (level < 0 || g >= cap) return;                      // wave-uniform
+
+    const HsLevel& L = lv[level];
+    const uint32_t* sel = sel_xys + ((size_t)img * sel_img_stride + L.sel_off + (g - first)) * 3;
+    const int cx = (int)sel[0], cy = (int)sel[1];
+    const int score = (int)sel[2];
+
+    const uint8_t* base; size_t pitch;
+    if (level == 0) { base = hs_img0_ptr(img0, img); pitch = img0.row_stride; }
+    else { base = L.base + (size_t)img * L.img_stride; pitch = L.pitch; }
+
+    uint8_t* raw = s_raw[wv]; uint16_t* hb = s_h[wv]; uint8_t* bl = s_bl[wv];
+
+    // ---- raw 43x43 neighbourhood, BORDER_REFLECT_101 at the level border
+    for (int i = lane; i < RAW_N * RAW_N; i += 64) {
+        int r = i / RAW_N, q = i - r * RAW_N;
+        int y = reflect101(cy - 21 + r, L.h), x = reflect101(cx - 21 + q, L.w);
+        raw[r * RAW_P + q] = base[(size_t)y * pitch + x];
+    }
+    uint32_t tp[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) tp[k] = taps7[k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done before the reads below
+    // ---- horizontal pass: ufixedpoint16 saturating sums
+    for (int i = lane; i < RAW_N * BL_N; i += 64) {
+        int r = i / BL_N, c = i - r * BL_N;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            uint32_t t = min(tp[k] * (uint32_t)raw[r * RAW_P + c + k], 0xFFFFu);
+            acc = min(acc + t, 0xFFFFu);
+        }
+        hb[r * H_P + c] = (uint16_t)acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- vertical pass: ufixedpoint32 saturating sums, round, saturate to u8
+    for (int i = lane; i < BL_N * BL_N; i += 64) {
+        int r = i / BL_N, c = i - r * BL_N;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            acc += (unsigned long long)tp[k] * hb[(r + k) * H_P + c];
+            acc = acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc;
+        }
+        unsigned long long v = (acc + 0x8000ull) >> 16;
+        bl[r * BL_P + c] = (uint8_t)(v > 255 ? 255 : v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+
+    // ---- intensity centroid (ORBFinder.cpp:16-43): integer moments over the umax disc
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        int vv = i / 31 - 15, uu = i - (i / 31) * 31 - 15;
+        int av = vv < 0 ? -vv : vv, au = uu < 0 ? -uu : uu;
+        if (au <= c_umax[av]) {
+            int I = bl[(18 + vv) * BL_P + 18 + uu];
+            m10 += uu * I; m01 += vv * I;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- rBRIEF (ORBFinder.cpp:89-129)
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float theta = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)theta), b = (float)sin((double)theta);
+    uint8_t* dout = desc + ((size_t)oimg * cap + g) * HS_DESC_BYTES;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int t = 64 * r + lane;
+        float x0 = (float)c_pattern[4 * t + 0], y0 = (float)c_pattern[4 * t + 1];
+        float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+        int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        int t0 = bl[(18 + dy0) * BL_P + 18 + dx0];
+        int t1 = bl[(18 + dy1) * BL_P + 18 + dx1];
+        unsigned long long m = __ballot(t0 < t1);
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = m;
+    }
+    if (lane == 0) {
+        hs_keypoint k;
+        // keypoint->pt *= scale for level != 0 (ORBExtractor.cpp:546-552)
+        k.x = level ? __fmul_rn((float)cx, L.scale) : (float)cx;
+        k.y = level ? __fmul_rn((float)cy, L.scale) : (float)cy;
+        k.size = L.kp_size; k.angle = angle; k.response = (float)score; k.octave = level;
+        kps[(size_t)oimg * cap + g] = k;
+    }
+}
+
+void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
+                        const uint32_t* sel_xys, const int32_t* sel_count, int sel_img_stride, int max_sel,
+                        const uint16_t* taps7, HsOut out, hipStream_t s)
+{
+    int per_img = max_sel < out.cap ? max_sel : out.cap;
+    dim3 grid((per_img + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch, 1);
+    if (grid.x == 0) grid.x = 1;
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride,
+                       taps7, out);
+}

@@ -1,0 +1,328 @@
+// kernels_quadtree.hip — H4 moved onto the GPU: ORBExtractor::DistributeOctTree (src/features/ORBExtractor.cpp:179-403)
+// with ExtractorNode::DivideNode (:121-177).
+//
+// The reference is a sequential std::list algorithm.  Its observable behaviour is restated here as a
+// level-synchronous, order-preserving parallel algorithm; one 1024-thread workgroup owns one (image, level):
+//
+//   * The std::list is an array in list order.  Every new node is push_front'ed, so after a pass that
+//     creates T children (creation order = processing order of the parent, then n1..n4) the list is
+//     [children in reverse creation order] ++ [untouched nodes in their old order].
+//   * Phase 1 (:246-305) splits every multi-point node, in list order.  Phase 2 (:316-377) sorts the
+//     multi-point nodes created by the previous pass by (size, pointer) and splits from the back until the
+//     list holds >= N nodes.  Documented deviation D1: the pointer is replaced by the creation sequence
+//     number (monotone allocator); because the candidates of a phase-2 pass were all created by the previous
+//     pass, "larger sequence number" == "smaller list index", so the processing order is
+//     (size descending, list index ascending).  The cut "stop once size >= N" is a prefix sum of
+//     (children-1) over that order.
+//   * A point only ever moves from a node to one of its children, decided by the reference's comparisons
+//     `x < n1.UR.x`, `y < n1.BR.y` with halfX = ceil((UR.x-UL.x)/2).  Per pass: one sweep over the points to
+//     count the four children of every splittable node (LDS atomics), a block scan to lay out the new list,
+//     one sweep to relabel.
+//   * The kept keypoint of a node is its maximum response, first in vToDistributeKeys order on ties (:381-400):
+//     a 64-bit LDS atomicMax on score<<56 | ~order, where order = (cell, y, x) reproduces the reference's
+//     candidate order (cells row-major, cv::FAST's row-major scan inside a cell).
+//
+// Inputs are the unordered candidate records written by k_fast_cells.  Outputs per (image, level):
+// selected (x,y,score) in final list order + count.  Bound: LDS atomics / VALU; HBM traffic negligible.
+#include "hs_internal.h"
+
+#define QT_T HS_QT_THREADS
+#define QT_M HS_QT_MAX_NODES
+
+struct QtNodes {
+    int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M];
+    uint32_t cnt[QT_M];
+};
+
+// exclusive scan of one int per thread over the 1024-thread block; returns prefix, writes total
+__device__ __forceinline__ int block_scan_excl(int v, int* s_wave /*[16]*/, int& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+    __syncthreads();                       // protect s_wave reuse
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < QT_T / 64; w++) { int x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
+{
+    // DivideNode: halfX = ceil((UR.x-UL.x)/2); n1.UR.x = UL.x+halfX; n1.BR.y = UL.y+halfY
+    int mx = N.x0[nd] + ((N.x1[nd] - N.x0[nd] + 1) >> 1);
+    int my = N.y0[nd] + ((N.y1[nd] - N.y0[nd] + 1) >> 1);
+    return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4
+}
+
+__global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels,
+                                                   const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
+                                                   const int32_t* __restrict__ cand_count, uint64_t cand_img_stride,
+                                                   uint16_t* __restrict__ pt_node_all,
+                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride)
+{
+    __shared__ QtNodes nodes[2];
+    __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
+    __shared__ int16_t proc_rank[QT_M];            // processing rank of a node in this pass, -1 = not split
+    __shared__ int16_t order_node[QT_M];           // rank -> node
+    __shared__ uint16_t new_index[QT_M];           // surviving node -> index in the next list
+    __shared__ uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
+    __shared__ int s_wave[QT_T / 64];
+    __shared__ int s_misc[8];
+
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, img = blockIdx.y;
+    const HsLevel& L = lv[level];
+    const int N = L.quota;
+    int n = cand_count[img * nlevels + level];
+    if (n > L.cand_cap) n = L.cand_cap;
+    const uint32_t* pxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
+    const uint32_t* psk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
+    uint16_t* pnode = pt_node_all + (size_t)img * cand_img_stride + L.cand_off;
+    uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
+    int32_t* out_n = &sel_count[img * nlevels + level];
+
+    const int nIni = L.n_ini;
+    const float hX = L.hx;
+    if (n == 0 || nIni < 1 || nIni > QT_M / 4) { if (tid == 0) *out_n = 0; return; }
+
+    // ---- roots (:183-225): count, drop empty ones, keep list order = root order
+    for (int i = tid; i < nIni; i += QT_T) ccount[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < n; p += QT_T) {
+        int x = pxy[p] & 0xFFFF;
+        int r = (int)((float)x / hX);               // vpIniNodes[kp.pt.x/hX]
+        r = min(r, nIni - 1);
+        atomicAdd(&ccount[r], 1u);
+    }
+    __syncthreads();
+    int cur = 0;
+    if (tid == 0) {
+        int S = 0;
+        for (int i = 0; i < nIni; i++) {
+            if (ccount[i] > 0) {
+                nodes[0].x0[S] = (int16_t)(int)(hX * (float)i);
+                nodes[0].x1[S] = (int16_t)(int)(hX * (float)(i + 1));
+                nodes[0].y0[S] = 0; nodes[0].y1[S] = (int16_t)L.qt_h;
+                nodes[0].cnt[S] = ccount[i];
+                new_index[i] = (uint16_t)S;
+                S++;
+            }
+        }
+        s_misc[0] = S;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += QT_T) {
+        int x = pxy[p] & 0xFFFF;
+        int r = min((int)((float)x / hX), nIni - 1);
+        pnode[p] = new_index[r];
+    }
+    int S = s_misc[0];
+    __syncthreads();
+
+    // ---- main loop
+    bool phase2 = false;     // uniform across the block
+    int T_prev = 0;          // number of children created by the previous pass (they sit at list indices [0,T_prev))
+    for (int iter = 0; iter < 64; iter++) {
+        QtNodes& C = nodes[cur];
+        QtNodes& X = nodes[cur ^ 1];
+        const int prevSize = S;
+        int E;               // number of nodes considered for splitting this pass
+
+        // -- choose processing order
+        if (!phase2) {
+            // every multi-point node, in list order (:246-305)
+            int flags[(QT_M + QT_T - 1) / QT_T];
+            int local = 0;
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                flags[k] = (i < S && C.cnt[i] > 1) ? 1 : 0;
+                local += flags[k];
+            }
+            int tot; int pre = block_scan_excl(local, s_wave, tot);
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                if (i < S) {
+                    if (flags[k]) { proc_rank[i] = (int16_t)pre; order_node[pre] = (int16_t)i; pre++; }
+                    else proc_rank[i] = -1;
+                }
+            }
+            E = tot;
+        } else {
+            // multi-point nodes created by the previous pass, sorted by (size desc, list index asc) (:321-325, D1)
+            for (int i = tid; i < S; i += QT_T) proc_rank[i] = -1;
+            __syncthreads();
+            int tot_local = 0;
+            for (int i = tid; i < T_prev; i += QT_T) {
+                uint32_t ci = C.cnt[i];
+                if (ci > 1) {
+                    int r = 0;
+                    for (int j = 0; j < T_prev; j++) {
+                        uint32_t cj = C.cnt[j];
+                        r += (cj > 1) && (cj > ci || (cj == ci && j < i));
+                    }
+                    proc_rank[i] = (int16_t)r; order_node[r] = (int16_t)i;
+                    tot_local++;
+                }
+            }
+            int tot; block_scan_excl(tot_local, s_wave, tot);
+            E = tot;
+        }
+        __syncthreads();
+        if (E == 0) break;                          // nothing can be split: size == prevSize (:309,374)
+
+        // -- count the four children of every candidate node
+        for (int i = tid; i < 4 * E; i += QT_T) ccount[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += QT_T) {
+            int nd = pnode[p];
+            int r = proc_rank[nd];
+            if (r >= 0) {
+                uint32_t xy = pxy[p];
+                atomicAdd(&ccount[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)], 1u);
+            }
+        }
+        __syncthreads();
+
+        // -- how many of them are actually split this pass
+        int P = E;
+        if (phase2) {
+            // size after splitting the first k nodes = S + sum_{i<k}(children_i - 1); stop at the first k with size >= N
+            int local = 0; int add[(QT_M + QT_T - 1) / QT_T];
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int r = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                int a = 0;
+                if (r < E) a = (ccount[4 * r] > 0) + (ccount[4 * r + 1] > 0) + (ccount[4 * r + 2] > 0) + (ccount[4 * r + 3] > 0) - 1;
+                add[k] = a; local += a;
+            }
+            int tot; int pre = block_scan_excl(local, s_wave, tot);
+            if (tid == 0) s_misc[1] = E;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int r = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                if (r < E) {
+                    int before = S + pre, after = before + add[k];
+                    if (before < N && after >= N) s_misc[1] = r + 1;      // unique r: size is non-decreasing
+                    pre = after - S;
+                }
+            }
+            __syncthreads();
+            P = s_misc[1];
+        }
+
+        // -- lay out the next list: children of processed nodes in reverse creation order, then survivors
+        int T, nToExpand;
+        {
+            int local = 0, lexp = 0;
+            int fl[4 * ((QT_M + QT_T - 1) / QT_T)];
+#pragma unroll
+            for (int k = 0; k < 4 * ((QT_M + QT_T - 1) / QT_T); k++) {
+                int i = tid * (4 * ((QT_M + QT_T - 1) / QT_T)) + k;
+                uint32_t cc = (i < 4 * P) ? ccount[i] : 0;
+                fl[k] = cc > 0; local += fl[k]; lexp += cc > 1;
+            }
+            int pre = block_scan_excl(local, s_wave, T);
+            block_scan_excl(lexp, s_wave, nToExpand);
+#pragma unroll
+            for (int k = 0; k < 4 * ((QT_M + QT_T - 1) / QT_T); k++) {
+                int i = tid * (4 * ((QT_M + QT_T - 1) / QT_T)) + k;
+                if (i < 4 * P && fl[k]) {
+                    int pos = T - 1 - pre; pre++;
+                    child_index[i] = (uint16_t)pos;
+                    int nd = order_node[i >> 2], c = i & 3;
+                    int x0 = C.x0[nd], x1 = C.x1[nd], y0 = C.y0[nd], y1 = C.y1[nd];
+                    int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                    if (pos < QT_M) {
+                        X.x0[pos] = (int16_t)((c & 1) ? mx : x0); X.x1[pos] = (int16_t)((c & 1) ? x1 : mx);
+                        X.y0[pos] = (int16_t)((c & 2) ? my : y0); X.y1[pos] = (int16_t)((c & 2) ? y1 : my);
+                        X.cnt[pos] = ccount[i];
+                    }
+                }
+            }
+        }
+        int nsurv;
+        {
+            int local = 0; int fl[(QT_M + QT_T - 1) / QT_T];
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                int r = (i < S) ? proc_rank[i] : 0;
+                fl[k] = (i < S) && !(r >= 0 && r < P);
+                local += fl[k];
+            }
+            int pre = block_scan_excl(local, s_wave, nsurv);
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
+                if (fl[k]) {
+                    int pos = T + pre; pre++;
+                    new_index[i] = (uint16_t)pos;
+                    if (pos < QT_M) {
+                        X.x0[pos] = C.x0[i]; X.x1[pos] = C.x1[i]; X.y0[pos] = C.y0[i]; X.y1[pos] = C.y1[i];
+                        X.cnt[pos] = C.cnt[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (T + nsurv > QT_M) { if (tid == 0) *out_n = 0; return; }     // cannot happen for quota+8 <= QT_M (host checks)
+
+        // -- relabel the points
+        for (int p = tid; p < n; p += QT_T) {
+            int nd = pnode[p];
+            int r = proc_rank[nd];
+            if (r >= 0 && r < P) {
+                uint32_t xy = pxy[p];
+                pnode[p] = child_index[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)];
+            } else pnode[p] = new_index[nd];
+        }
+        __syncthreads();
+        S = T + nsurv;
+        cur ^= 1;
+        T_prev = T;
+
+        // -- termination (:307-313, :370-375)
+        if (S >= N || S == prevSize) break;
+        if (!phase2 && (S + nToExpand * 3) > N) phase2 = true;
+    }
+
+    // ---- keep the best point of every node (:381-400), emit in list order
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(ccount);      // QT_M * 8 bytes <= sizeof(ccount)
+    for (int i = tid; i < S; i += QT_T) best[i] = 0ull;
+    __syncthreads();
+    for (int p = tid; p < n; p += QT_T) {
+        uint32_t xy = pxy[p], sk = psk[p];
+        unsigned long long order = ((unsigned long long)(sk & 0xFFFFFFu) << 32) | xy;          // (cell, y, x)
+        unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
+        atomicMax(&best[pnode[p]], key);
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += QT_T) {
+        if (i < L.sel_cap) {
+            unsigned long long key = best[i];
+            unsigned long long order = 0x00FFFFFFFFFFFFFFull - (key & 0x00FFFFFFFFFFFFFFull);
+            uint32_t xy = (uint32_t)order;
+            out[3 * i + 0] = (xy & 0xFFFF) + HS_BORDER;       // keypoints[i].pt.x += minBorderX (:484-485)
+            out[3 * i + 1] = (xy >> 16) + HS_BORDER;
+            out[3 * i + 2] = (uint32_t)(key >> 56);
+        }
+    }
+    if (tid == 0) *out_n = min(S, L.sel_cap);
+}
+
+void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch,
+                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cand_count, uint64_t cand_img_stride,
+                        uint16_t* pt_node, uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s)
+{
+    dim3 grid(nlevels, batch, 1);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, cand_xy, cand_sk, cand_count, cand_img_stride,
+                       pt_node, sel_xys, sel_count, sel_img_stride);
+}

@@ -1,0 +1,135 @@
+// kernels_stereo.hip — K8a: left<->right stereo matching by Hamming distance.
+//
+// Replaces Stereomatcher::computeStereoMatches (src/features/Stereomatcher.cpp:36-156) and the
+// ORBDistance bit-hack it calls per pair (src/features/low_level/DescriptorDistance.cpp:9-25).
+// The reference builds a per-row table of right keypoints (iR listed in rows floor(y-r)..ceil(y+r),
+// r = 2*size/size_ref) and scans vRowIndices[(int)vL] in ascending iR.  Here one wavefront owns one left
+// keypoint and tests *every* right keypoint against the same predicate (row band, |octave diff| <= 1,
+// uL-maxD <= uR <= uL): 2000 x 2000 predicate evaluations per pair are noise for the GPU and no table
+// is materialised.  The running minimum uses the key dist<<16 | iR, which reproduces the reference's
+// strict `dist < bestDist` over ascending iR (first minimum wins).  Descriptors are XORed as 4 x u64 and
+// counted with v_bcnt (__popcll) — equal to the reference's 32-bit parallel bit count.
+//
+// Second kernel: the reference's sort + median + 2.1*median rejection (:142-155) is a histogram of the
+// accepted integer distances, one workgroup per pair.
+// Documented deviation D2 (reference UB): rows outside [0,nRows) are ignored, no match => no filtering.
+#include "hs_internal.h"
+
+__global__ __launch_bounds__(256) void k_stereo_match(const hs_keypoint* __restrict__ kpsL, const uint8_t* __restrict__ descL,
+                                                      const int32_t* __restrict__ nLs,
+                                                      const hs_keypoint* __restrict__ kpsR, const uint8_t* __restrict__ descR,
+                                                      const int32_t* __restrict__ nRs,
+                                                      int cap, hs_stereo_params sp,
+                                                      float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ best_dist)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 4 + wv;
+    const int nL = min(nLs[pair], cap), nR = min(nRs[pair], cap);
+    if (iL >= cap) return;
+    const size_t o = (size_t)pair * cap;
+    if (iL >= nL) { if (lane == 0) { uRight[o + iL] = -1.0f; depth[o + iL] = -1.0f; best_dist[o + iL] = -1; } return; }
+
+    const hs_keypoint kl = kpsL[o + iL];
+    const float vL = kl.y, uL = kl.x;
+    const int levelL = kl.octave;
+    const float mbf = sp.mbf, mb = sp.mbf / sp.fx;
+    const float minD = 0.f, maxD = mbf / mb;                 // :66-68
+    const float minU = uL - maxD, maxU = uL - minD;
+    const int rowL = (int)vL;                                // vRowIndices[vL]
+    bool ok = (vL >= 0.f) && rowL < sp.n_rows && !(maxU < 0.f);
+
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(descL + (o + iL) * 32);
+    const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
+
+    // bestDist starts at TH_HIGH and only strictly smaller distances replace it (:92,114)
+    uint32_t best = 0xFFFFFFFFu;
+    const float th_high = sp.th_high;
+    if (ok) {
+        for (int iR = lane; iR < nR; iR += 64) {
+            const hs_keypoint kr = kpsR[o + iR];
+            const float r = 2.0f * kr.size / sp.size_ref;    // :56
+            const int maxr = (int)ceilf(kr.y + r);
+            const int minr = (int)floorf(kr.y - r);
+            if (rowL < minr || rowL > maxr) continue;
+            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
+            const float uR = kr.x;
+            if (!(uR >= minU && uR <= maxU)) continue;
+            const unsigned long long* dr = reinterpret_cast<const unsigned long long*>(descR + (o + iR) * 32);
+            int d = __popcll(l0 ^ dr[0]) + __popcll(l1 ^ dr[1]) + __popcll(l2 ^ dr[2]) + __popcll(l3 ^ dr[3]);
+            if ((float)d < th_high) {
+                uint32_t key = ((uint32_t)d << 16) | (uint32_t)iR;
+                best = min(best, key);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
+
+    if (lane == 0) {
+        float ur_out = -1.0f, depth_out = -1.0f; int bd = -1;
+        if (best != 0xFFFFFFFFu) {
+            const float bestDist = (float)(best >> 16);
+            const int bestIdxR = best & 0xFFFF;
+            const float dist_threshold = (sp.th_high + sp.th_low) / 2;          // :41
+            if (bestDist < dist_threshold) {
+                float uR0 = kpsR[o + bestIdxR].x;
+                float disparity = uL - uR0;
+                if (disparity >= minD && disparity < maxD) {
+                    if (disparity <= 0) { disparity = 0.01; uR0 = uL - 0.01; }    // double constants, as in the reference (:130-131)
+                    depth_out = mbf / disparity;
+                    ur_out = uR0;
+                    bd = (int)(best >> 16);
+                }
+            }
+        }
+        uRight[o + iL] = ur_out; depth[o + iL] = depth_out; best_dist[o + iL] = bd;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nLs, int cap,
+                                                       float* __restrict__ uRight, float* __restrict__ depth,
+                                                       const int32_t* __restrict__ best_dist)
+{
+    __shared__ int hist[257];
+    __shared__ float s_th;
+    const int pair = blockIdx.x;
+    const int nL = min(nLs[pair], cap);
+    const size_t o = (size_t)pair * cap;
+    for (int i = threadIdx.x; i < 257; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nL; i += 256) {
+        int d = best_dist[o + i];
+        if (d >= 0) atomicAdd(&hist[min(d, 256)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int d = 0; d <= 256; d++) total += hist[d];
+        float th = -1.f;
+        if (total > 0) {
+            // sorted (dist, iL) pairs: element total/2 carries the median distance (:142-144)
+            int target = total / 2, acc = 0, med = 0;
+            for (int d = 0; d <= 256; d++) { acc += hist[d]; if (acc > target) { med = d; break; } }
+            th = 1.5f * 1.4f * (float)med;
+        }
+        s_th = th;
+    }
+    __syncthreads();
+    const float th = s_th;
+    if (th < 0.f) return;
+    for (int i = threadIdx.x; i < nL; i += 256) {
+        int d = best_dist[o + i];
+        if (d >= 0 && !((float)d < th)) { uRight[o + i] = -1.f; depth[o + i] = -1.f; }      // :146-155
+    }
+}
+
+void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
+                      const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
+                      int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth, int32_t* best_dist, hipStream_t s)
+{
+    if (pairs <= 0 || cap <= 0) return;
+    dim3 grid((cap + 3) / 4, pairs, 1);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, s, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, nL, cap, uRight, depth, best_dist);
+}

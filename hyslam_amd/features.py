@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's feature interfaces for the ORB hot path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow bmhopkinson/hyslam:
+  FeatureExtractorSettings  src/core/FeatureExtractorSettings.h:19-32
+  FeatureMatcherSettings    src/features/FeatureMatcher.h:98-103
+  ORBExtractor              src/features/ORBExtractor.h:62-130 (FeatureExtractor ABC: FeatureExtractor.h:25-37)
+  Stereomatcher             src/features/Stereomatcher.h:25-51
+  ORBFactory                src/features/ORBFactory.h / FeatureFactory.h:21-33
+All compute happens in libhyslam_amd.so (HIP, gfx950).  Nothing here falls back to a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from ._native import KP_DTYPE, HsError  # noqa: F401
+
+
+class FeatureExtractorSettings:
+    def __init__(self, nFeatures=1000, fScaleFactor=1.2, nLevels=8, init_threshold=20, min_threshold=4, N_CELLS=30,
+                 size_ref=31.0, sigma_ref=1.0):
+        # defaults of ORBFactory::ORBFactory(), src/features/ORBFactory.cpp:13-25
+        self.nFeatures, self.fScaleFactor, self.nLevels = nFeatures, fScaleFactor, nLevels
+        self.init_threshold, self.min_threshold, self.N_CELLS = init_threshold, min_threshold, N_CELLS
+        self.size_ref, self.sigma_ref = size_ref, sigma_ref
+
+
+class FeatureMatcherSettings:
+    def __init__(self, nnratio=0.6, TH_HIGH=100.0, TH_LOW=50.0, checkOri=True):
+        self.nnratio, self.TH_HIGH, self.TH_LOW, self.checkOri = nnratio, TH_HIGH, TH_LOW, checkOri
+
+
+class Camera:
+    """The fields of HYSLAM::Camera the stereo matcher reads (src/features/Stereomatcher.cpp:7-24,44)."""
+
+    def __init__(self, fx=1050.0, mbf=1050.0 * 0.12, mnMaxY=1080.0):
+        self._fx, self.mbf, self.mnMaxY = fx, mbf, mnMaxY
+
+    def fx(self):
+        return self._fx
+
+
+def _params(settings, blur_taps=None, fast_threshold=20):
+    p = N.OrbParams()
+    N.lib().hs_orb_default_params(C.byref(p))
+    p.nfeatures, p.scale_factor, p.nlevels = settings.nFeatures, settings.fScaleFactor, settings.nLevels
+    p.cell_px, p.ini_th_fast, p.min_th_fast = settings.N_CELLS, settings.init_threshold, settings.min_threshold
+    p.fast_threshold = fast_threshold
+    if blur_taps is not None:
+        for i in range(7):
+            p.blur_taps[i] = int(blur_taps[i])
+    return p
+
+
+class ORBExtractor:
+    """HYSLAM::ORBExtractor.  `extractor(image)` returns (keypoints[KP_DTYPE], descriptors[n,32] uint8)."""
+
+    def __init__(self, settings=None, device=0, blur_taps=None):
+        self.settings = settings or FeatureExtractorSettings()
+        self._lib = N.lib()
+        self._h = C.c_void_p()
+        self._p = _params(self.settings, blur_taps)
+        st = self._lib.hs_orb_create(C.byref(self._p), device, C.byref(self._h))
+        if st != N.HS_OK:
+            self._h = C.c_void_p()
+            raise HsError(st, self._lib.hs_status_string(st).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.hs_orb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- FeatureExtractor interface (FeatureExtractor.h:25-37)
+    def GetLevels(self):
+        return self._lib.hs_orb_get_levels(self._h)
+
+    def GetScaleFactor(self):
+        return self._lib.hs_orb_get_scale_factor(self._h)
+
+    def _tables(self):
+        n = self.GetLevels()
+        arrs = [np.zeros(n, np.float32) for _ in range(4)] + [np.zeros(n, np.int32)]
+        N.check(self._h, self._lib.hs_orb_get_scale_tables(self._h, *(a.ctypes.data_as(C.c_void_p) for a in arrs)))
+        return arrs
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def GetFeaturesPerLevel(self):
+        return self._tables()[4]
+
+    def max_keypoints(self):
+        return self._lib.hs_orb_max_keypoints(self._h)
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors), ORBExtractor.cpp:496-562 (mask ignored, as in the reference)."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)     # silent return, ORBExtractor.cpp:499-500
+        k, d = self.extract_batch([image])
+        return k[0], d[0]
+
+    def extract_batch(self, images):
+        imgs = [np.ascontiguousarray(im) for im in images]
+        for im in imgs:
+            if im.dtype != np.uint8 or im.ndim != 2:
+                raise TypeError("image must be CV_8UC1 (2-D uint8)")          # assert(image.type() == CV_8UC1), :503
+            if im.shape != imgs[0].shape:
+                raise ValueError("batched frames must have equal size")
+        b = len(imgs)
+        h, w = imgs[0].shape
+        cap = self.max_keypoints()
+        kps = np.zeros((b, cap), KP_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        ptrs = (C.c_void_p * b)(*[im.ctypes.data for im in imgs])
+        N.check(self._h, self._lib.hs_orb_extract_batch(self._h, ptrs, b, w, h, imgs[0].strides[0],
+                                                        kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
+                                                        n.ctypes.data_as(C.c_void_p)))
+        return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
+
+    # ---- device-resident entry points (pointers are plain integers, e.g. torch.Tensor.data_ptr())
+    def reserve(self, w, h, batch):
+        N.check(self._h, self._lib.hs_orb_reserve(self._h, w, h, batch))
+
+    def extract_batch_device(self, d_imgs, batch, w, h, row_stride, image_stride, d_kps, d_desc, d_n, cap, stream=0):
+        N.check(self._h, self._lib.hs_orb_extract_batch_device(self._h, d_imgs, batch, w, h, row_stride, image_stride,
+                                                               d_kps, d_desc, d_n, cap, stream or None))
+
+    def stereo_match_batch_device(self, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, sp, d_uRight, d_depth, stream=0):
+        N.check(self._h, self._lib.hs_stereo_match_batch_device(self._h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap,
+                                                                C.byref(sp), d_uRight, d_depth, stream or None))
+
+    def stereo_frontend_batch_device(self, d_left, d_right, pairs, w, h, row_stride, image_stride,
+                                     d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap, sp, d_uRight, d_depth, stream=0):
+        N.check(self._h, self._lib.hs_stereo_frontend_batch_device(self._h, d_left, d_right, pairs, w, h, row_stride, image_stride,
+                                                                   d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
+                                                                   C.byref(sp), d_uRight, d_depth, stream or None))
+
+    def synchronize(self, stream=0):
+        N.check(self._h, self._lib.hs_orb_synchronize(self._h, stream or None))
+
+    # ---- stage taps (parity tests)
+    def debug_level(self, image, level):
+        buf = np.zeros(1 << 26, np.uint8)
+        lw, lh = C.c_int32(), C.c_int32()
+        N.check(self._h, self._lib.hs_orb_debug_level(self._h, image, level, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(lw), C.byref(lh)))
+        return buf[:lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+    def debug_candidates(self, image, level, cap=1 << 20):
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int32()
+        N.check(self._h, self._lib.hs_orb_debug_candidates(self._h, image, level, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def debug_selected(self, image, level, cap=1 << 16):
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int32()
+        N.check(self._h, self._lib.hs_orb_debug_selected(self._h, image, level, out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+
+def stereo_params(camera, settings=None, size_ref=31.0):
+    settings = settings or FeatureMatcherSettings()
+    return N.StereoParams(camera.fx(), camera.mbf, int(camera.mnMaxY), settings.TH_HIGH, settings.TH_LOW, size_ref)
+
+
+class Stereomatcher:
+    """HYSLAM::Stereomatcher (src/features/Stereomatcher.h:25-51): construct from the left/right views, the camera and the
+    matcher settings, call computeStereoMatches(), read uRight/depth with getData()."""
+
+    def __init__(self, keys, keysR, descriptors, descriptorsR, camera, settings=None, extractor=None, size_ref=31.0):
+        self.mvKeys = np.ascontiguousarray(keys, KP_DTYPE)
+        self.mvKeysRight = np.ascontiguousarray(keysR, KP_DTYPE)
+        self.mDescriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        self.mDescriptorsRight = np.ascontiguousarray(descriptorsR, np.uint8).reshape(-1, 32)
+        self.sp = stereo_params(camera, settings, size_ref)
+        self._ex = extractor or ORBExtractor()
+        self.mvuRight = np.full(len(self.mvKeys), -1.0, np.float32)
+        self.mvDepth = np.full(len(self.mvKeys), -1.0, np.float32)
+
+    def computeStereoMatches(self):
+        ex = self._ex
+        nL, nR = len(self.mvKeys), len(self.mvKeysRight)
+        self.mvuRight = np.full(nL, -1.0, np.float32)
+        self.mvDepth = np.full(nL, -1.0, np.float32)
+        N.check(ex._h, ex._lib.hs_stereo_match(ex._h, self.mvKeys.ctypes.data_as(C.c_void_p), self.mDescriptors.ctypes.data_as(C.c_void_p), nL,
+                                               self.mvKeysRight.ctypes.data_as(C.c_void_p), self.mDescriptorsRight.ctypes.data_as(C.c_void_p), nR,
+                                               C.byref(self.sp), self.mvuRight.ctypes.data_as(C.c_void_p),
+                                               self.mvDepth.ctypes.data_as(C.c_void_p)))
+
+    def getData(self):
+        return self.mvuRight, self.mvDepth
+
+
+class ORBFactory:
+    """HYSLAM::ORBFactory: hands out extractors and matcher settings (FeatureFactory.h:21-33, ORBFactory.cpp:13-45)."""
+
+    def __init__(self, extractor_settings=None, matcher_settings=None, device=0):
+        self.extractor_settings = extractor_settings or FeatureExtractorSettings()
+        self.matcher_settings = matcher_settings or FeatureMatcherSettings()
+        self.device = device
+
+    def getExtractor(self, settings=None):
+        return ORBExtractor(settings or self.extractor_settings, self.device)
+
+    def getFeatureExtractorSettings(self):
+        return self.extractor_settings
+
+    def getFeatureMatcherSettings(self):
+        return self.matcher_settings
+
+    def setFeatureMatcherSettings(self, s):
+        self.matcher_settings = s
