@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — stereo frames/s of ORB extract + left<->right match at 1920x1080 / 2000 features (BASELINE.json C2).
+
+A *step* is one pass of the hot path (pyramid -> FAST/NMS cells -> quadtree distribution -> blur+orientation+rBRIEF for
+left and right frames, then the stereo matcher) over one batch of `--pairs` synthetic stereo pairs that are already
+resident in HBM.  One process per GPU; frames shard across ranks with no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0:
+  value     whole-job stereo pairs per second (all ranks)
+  roofline  the dominant kernel of the step: algorithmic bytes per launch / its HIP-event-measured duration vs 8 TB/s
+  cpu_baseline  the oracle ("port" of the reference's CPU path, left||right on 2 threads) timed on this box, N=1 only
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+W, H, NFEAT = 1920, 1080, 2000
+
+
+def pyramid_pixels(ex, w, h):
+    inv = ex.GetInverseScaleFactors()
+    sizes = [(int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))) for s in inv]
+    return [a * b for a, b in sizes]
+
+
+def algorithmic_bytes(px, k):
+    """compulsory HBM bytes per mono frame at the reference's stage granularity."""
+    P, p0, p7 = sum(px), px[0], px[-1]
+    per_stage = {
+        "pyramid": (P - p7) + (P - p0),          # each level read once to make the next + levels 1.. written
+        "fast_cells": P,                         # FAST reads every level once
+        "quadtree": 0,                           # host stage in the reference; candidate lists only
+        "describe": 2 * P + k * 1369 + k * 60,   # blur read+write, 37x37 window per keypoint, record out
+    }
+    return per_stage, sum(per_stage.values())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import hyslam_amd as HS
+    from hyslam_amd import _native as N
+    from hyslam_amd.synth import synth_stereo_pair
+
+    # ---- synthetic input, resident in HBM before the timed region
+    B = args.pairs
+    nd = max(1, min(args.distinct, B))
+    pairs = [synth_stereo_pair(1000 + 97 * rank + i, W, H) for i in range(nd)]
+    left = torch.from_numpy(np.stack([pairs[i % nd][0] for i in range(B)])).to(dev)
+    right = torch.from_numpy(np.stack([pairs[i % nd][1] for i in range(B)])).to(dev)
+
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+    cap = ex.max_keypoints()
+    sp = HS.stereo_params(HS.Camera(fx=1050.0, mbf=1050.0 * 0.12, mnMaxY=float(H)))
+    kp_bytes = N.KP_DTYPE.itemsize
+    kL = torch.empty(B * cap * kp_bytes, dtype=torch.uint8, device=dev)
+    kR = torch.empty_like(kL)
+    dL = torch.empty(B * cap * 32, dtype=torch.uint8, device=dev)
+    dR = torch.empty_like(dL)
+    nL = torch.zeros(B, dtype=torch.int32, device=dev)
+    nR = torch.zeros(B, dtype=torch.int32, device=dev)
+    uR = torch.empty(B * cap, dtype=torch.float32, device=dev)
+    depth = torch.empty_like(uR)
+    ex.reserve(W, H, 2 * B)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ex.stereo_frontend_batch_device(left.data_ptr(), right.data_ptr(), B, W, H, W, W * H,
+                                        kL.data_ptr(), dL.data_ptr(), nL.data_ptr(), kR.data_ptr(), dR.data_ptr(), nR.data_ptr(),
+                                        cap, sp, uR.data_ptr(), depth.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ex.profile_begin()          # warm-up also pre-creates part of the event pool
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ex.profile_end()
+
+    fence()
+    ex.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    prof = ex.profile_end()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    total_pairs = world * B * args.steps
+    value = total_pairs / elapsed
+
+    n_left = nL.cpu().numpy()
+    n_match = int((depth.view(B, cap)[0] > 0).sum().item())
+
+    out = None
+    if rank == 0:
+        px = pyramid_pixels(ex, W, H)
+        per_stage, per_frame = algorithmic_bytes(px, NFEAT)
+        frames_per_launch = 2 * B
+        stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items()}
+        dom = max(("pyramid", "fast_cells", "quadtree", "describe"), key=lambda s: stage_ms[s])
+        dom_bytes = per_stage[dom] * frames_per_launch
+        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        pair_bytes = 2 * per_frame
+        out = {
+            "metric": "stereo frames/sec ORB extract+match, 1920x1080 @2000 feat",
+            "value": round(value, 2), "unit": "stereo_pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C2: 1920x1080 stereo pair, 2000 features/frame, 8 levels @1.2, extract L+R + stereo match",
+                       "pairs_per_step_per_gpu": B, "distinct_pairs": nd, "sharding": "frames round-robin, no collective",
+                       "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(stage_ms[dom], 5),
+                         "frames_per_launch": frames_per_launch},
+            "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
+            "end_to_end": {"algorithmic_bytes_per_pair": int(pair_bytes),
+                           "achieved_GBps": round(value / world * pair_bytes / 1e9, 2),
+                           "frac_of_hbm_peak": round(value / world * pair_bytes / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pairs, budget_s):
+    """The oracle in the reference's structure (ImageProcessing::ProcessStereoImage, src/main/ImageProcessing.cpp:69-116):
+    left frame on a spawned thread, right on the caller, then the stereo matcher — 2 host cores per pair."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    p = oracle.default_params(NFEAT)
+    sp = oracle.stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=H)
+    oracle.stereo_frontend(p, sp, pairs[0][0], pairs[0][1])      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        L, R = pairs[n % len(pairs)]
+        oracle.stereo_frontend(p, sp, L, R)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s and n >= 4:
+            break
+    return {"value": round(n / el, 3), "unit": "stereo_pairs/s", "cores": 2, "kind": "port",
+            "sample": "%d synthetic 1920x1080 pairs in %.1f s; oracle/ C++ restatement (left||right threads + stereo match), "
+                      "omits the reference's cv::Mat/FeatureDescriptor allocation overheads; host has %d logical cores"
+                      % (n, el, os.cpu_count())}
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
+    "hs_orb_profile_begin", "hs_orb_profile_end",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
 
@@ -79,6 +80,8 @@ def lib():
     L.hs_stereo_frontend_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, sz, sz,
                                                   vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
     L.hs_orb_synchronize.argtypes = [vp, vp]
+    L.hs_orb_profile_begin.argtypes = [vp]
+    L.hs_orb_profile_end.argtypes = [vp, vp, vp]
     L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.hs_orb_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.hs_orb_debug_selected.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]

@@ -41,6 +41,10 @@ struct hs_orb {
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
     int last_batch = 0; HsImg0 last_img0{};
+    // stage profiling: events[i] marks the start of stage prof_stage[i]; the event after the last stage has stage -1
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<int> prof_stage;
 };
 
 namespace {
@@ -50,6 +54,15 @@ inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
 inline short sat_short(float v) { int i = cv_round_f(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); }
 
 int fail(hs_orb* h, int code, const std::string& msg) { if (h) h->err = msg; return code; }
+
+// record "stage `stage` starts here" (stage -1 closes the previous one) when profiling is on
+void mark(hs_orb* h, int stage, hipStream_t s)
+{
+    if (!h->prof) return;
+    if (h->ev_used == h->ev_pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->ev_pool.push_back(e); }
+    (void)hipEventRecord(h->ev_pool[h->ev_used++], s);
+    h->prof_stage.push_back(stage);
+}
 
 #define HIP_TRY(h, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
     return fail(h, HS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
@@ -195,16 +208,31 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
 {
     const int L = h->p.nlevels;
     HIP_TRY(h, hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * L * 4, s));
+    mark(h, 0, s);
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+    mark(h, 1, s);
     hs_launch_fast(h->d_lv, L, img0, batch, h->total_cells, h->p.fast_threshold,
                    h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride, s);
+    mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride,
                        h->d_pt_node, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
+    mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->sel_img_stride, h->max_kp,
                        h->d_taps, out, s);
+    mark(h, -1, s);
     HIP_TRY(h, hipGetLastError());
     h->last_batch = batch; h->last_img0 = img0;
     return HS_OK;
+}
+
+void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32_t* nL, const hs_keypoint* kR, const uint8_t* dR,
+                const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
+{
+    mark(h, 4, s);
+    hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, s);
+    mark(h, 5, s);
+    hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, s);
+    mark(h, -1, s);
 }
 
 } // namespace
@@ -296,6 +324,7 @@ void hs_orb_destroy(hs_orb* h)
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
     hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -410,7 +439,7 @@ int hs_stereo_match_batch_device(hs_orb* h, const hs_keypoint* d_kpsL, const uin
     int rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
     if (rc != HS_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    hs_launch_stereo(d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, h->d_bd, s);
+    run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
     HIP_TRY(h, hipGetLastError());
     return HS_OK;
 }
@@ -440,7 +469,7 @@ int hs_stereo_match(hs_orb* h, const hs_keypoint* kpsL, const uint8_t* descL, in
         if (e == hipSuccess && nR) e = hipMemcpyAsync(dd + (size_t)cap * 32, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(dn, cnt, 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
-            hs_launch_stereo(dk, dd, dn, dk + cap, dd + (size_t)cap * 32, dn + 1, 1, cap, *sp, h->d_ur, h->d_depth, h->d_bd, s);
+            run_stereo(h, dk, dd, dn, dk + cap, dd + (size_t)cap * 32, dn + 1, 1, cap, *sp, h->d_ur, h->d_depth, s);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(uRight, h->d_ur, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
@@ -476,8 +505,34 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     HsOut out{ d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap };
     rc = run_extract(h, img0, 2 * pairs, out, s);
     if (rc != HS_OK) return rc;
-    hs_launch_stereo(d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, h->d_bd, s);
+    run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
     HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_orb_profile_begin(hs_orb* h)
+{
+    if (!h) return HS_ERR_INVALID;
+    h->prof = true; h->ev_used = 0; h->prof_stage.clear();
+    return HS_OK;
+}
+
+int hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!ms || !launches) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int i = 0; i < HS_NUM_STAGES; i++) { ms[i] = 0; launches[i] = 0; }
+    h->prof = false;
+    if (h->ev_used) HIP_TRY(h, hipEventSynchronize(h->ev_pool[h->ev_used - 1]));
+    for (size_t i = 0; i + 1 < h->ev_used; i++) {
+        int st = h->prof_stage[i];
+        if (st < 0 || st >= HS_NUM_STAGES) continue;
+        float t = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
+        ms[st] += t; launches[st]++;
+    }
+    h->ev_used = 0; h->prof_stage.clear();
     return HS_OK;
 }
 

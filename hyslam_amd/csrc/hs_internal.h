@@ -77,3 +77,4 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
                       int32_t* best_dist /*[pairs][cap] scratch*/, hipStream_t s);
+void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s);

@@ -131,5 +131,10 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
     if (pairs <= 0 || cap <= 0) return;
     dim3 grid((cap + 3) / 4, pairs, 1);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, s, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+}
+
+void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s)
+{
+    if (pairs <= 0 || cap <= 0) return;
     hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, nL, cap, uRight, depth, best_dist);
 }

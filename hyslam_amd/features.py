@@ -155,6 +155,18 @@ class ORBExtractor:
     def synchronize(self, stream=0):
         N.check(self._h, self._lib.hs_orb_synchronize(self._h, stream or None))
 
+    STAGES = ("pyramid", "fast_cells", "quadtree", "describe", "stereo_match", "stereo_median")
+
+    def profile_begin(self):
+        N.check(self._h, self._lib.hs_orb_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> {stage: (total_ms, launches)} measured with HIP events on the launch stream."""
+        ms = np.zeros(6, np.float64)
+        cnt = np.zeros(6, np.int32)
+        N.check(self._h, self._lib.hs_orb_profile_end(self._h, ms.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        return {s: (float(ms[i]), int(cnt[i])) for i, s in enumerate(self.STAGES)}
+
     # ---- stage taps (parity tests)
     def debug_level(self, image, level):
         buf = np.zeros(1 << 26, np.uint8)

@@ -127,6 +127,15 @@ int  hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uin
 /* block until everything enqueued on the handle's own stream (or `stream`) has finished */
 int  hs_orb_synchronize(hs_orb* h, void* stream);
 
+/* ---- per-stage device timing (HIP events recorded on the stream the kernels run on) ----
+ * Stages: 0 pyramid, 1 FAST+NMS cells, 2 quadtree distribution, 3 blur+orient+rBRIEF, 4 stereo match, 5 stereo median.
+ * begin: start collecting (events are recorded around every stage of every later call on this handle);
+ * end:   synchronise, write the summed milliseconds per stage into ms[6] and the number of launches of each
+ *        stage into launches[6] (pyramid counts one launch per call although it is nlevels-1 kernels), stop collecting. */
+#define HS_NUM_STAGES 6
+int  hs_orb_profile_begin(hs_orb* h);
+int  hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches);
+
 /* ---- stage taps for parity tests (host outputs; synchronous; valid after an extract call) ---- */
 /* pyramid level `level` of image `image` of the last batch: tight w*h bytes; ORBExtractor::ComputePyramid :564-589 */
 int  hs_orb_debug_level(hs_orb* h, int image, int level, uint8_t* out, size_t cap_bytes, int32_t* lw, int32_t* lh);

@@ -1,0 +1,196 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs,
+bit-exact for every stage (pyramid bytes, FAST candidates, quadtree selection, keypoint fields, descriptor bytes,
+uRight/depth), against the committed golden vectors, and through size-independent properties at full size."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import hyslam_amd as HS
+from hyslam_amd import _native as N
+from hyslam_amd.synth import synth_image, synth_stereo_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def settings(n, scale=1.2, levels=8):
+    return HS.FeatureExtractorSettings(nFeatures=n, fScaleFactor=scale, nLevels=levels)
+
+
+def assert_same_features(gk, gd, ok, od):
+    assert len(gk) == len(ok), (len(gk), len(ok))
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(gk[f], ok[f]), f
+    assert gk.tobytes() == ok.tobytes()
+    assert np.array_equal(gd, od)
+
+
+def stage_parity(img, nfeat, scale=1.2):
+    p = oracle.default_params(nfeat, scale)
+    ok, od, dbg = oracle.extract(p, img, debug=True)
+    ex = HS.ORBExtractor(settings(nfeat, scale))
+    gk, gd = ex(img)
+    sc = oracle.scale_tables(p)[0]
+    for l in range(p.nlevels):
+        assert np.array_equal(ex.debug_level(0, l), dbg["pyramid"][l]), "pyramid level %d" % l
+        gc = ex.debug_candidates(0, l)
+        oc = dbg["candidates"][l].astype(np.int32)
+        assert len(gc) == len(oc), "candidate count level %d" % l
+        if len(gc):
+            assert np.array_equal(gc[np.lexsort((gc[:, 0], gc[:, 1]))], oc[np.lexsort((oc[:, 0], oc[:, 1]))]), "candidates level %d" % l
+        gs = ex.debug_selected(0, l)
+        m = ok["octave"] == l
+        assert len(gs) == int(m.sum()) == int(dbg["n_selected"][l]), "selection count level %d" % l
+        mul = np.float32(sc[l]) if l else np.float32(1)
+        assert np.array_equal(gs[:, 0].astype(np.float32) * mul, ok["x"][m]) and np.array_equal(gs[:, 1].astype(np.float32) * mul, ok["y"][m])
+        assert np.array_equal(gs[:, 2].astype(np.float32), ok["response"][m])
+    assert_same_features(gk, gd, ok, od)
+    return ex, gk, gd
+
+
+def test_c1_mono_640x480_stagewise(gpu):
+    stage_parity(synth_image(1, 640, 480), 1000)
+
+
+def test_c1_matches_committed_golden(gpu):
+    for name in ("c1_mono_640x480_1000", "imaging_800x600_1500_s14"):
+        g = np.load(os.path.join(G, name + ".npz"))
+        img = synth_image(int(g["seed"]), int(g["w"]), int(g["h"]))
+        ex = HS.ORBExtractor(settings(int(g["nfeat"]), float(g["scale"])))
+        gk, gd = ex(img)
+        assert gk.tobytes() == g["keypoints"].tobytes() and np.array_equal(gd, g["descriptors"]), name
+        sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+        assert [sha(ex.debug_level(0, l)) for l in range(8)] == g["pyramid_sha256"].tolist()
+
+
+def test_c2_stereo_1080p_extract_and_match(gpu):
+    L, R = synth_stereo_pair(2, 1920, 1080)
+    ex, gkL, gdL = stage_parity(L, 2000)
+    p = oracle.default_params(2000)
+    okR, odR = oracle.extract(p, R)
+    gkR, gdR = ex(R)
+    assert_same_features(gkR, gdR, okR, odR)
+    sp = oracle.stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=1080)
+    ouR, odepth, _, _ = oracle.stereo_match(gkL, gdL, gkR, gdR, sp)
+    sm = HS.Stereomatcher(gkL, gkR, gdL, gdR, HS.Camera(1050.0, 1050.0 * 0.12, 1080.0), extractor=ex)
+    sm.computeStereoMatches()
+    guR, gdepth = sm.getData()
+    assert np.array_equal(guR, ouR) and np.array_equal(gdepth, odepth)
+    assert int((gdepth > 0).sum()) > 200
+
+
+def test_stereo_golden_and_identical_views(gpu):
+    g = np.load(os.path.join(G, "stereo_640x480_1000.npz"))
+    ex = HS.ORBExtractor(settings(1000))
+    cam = HS.Camera(float(g["fx"]), float(g["fx"]) * 0.12, float(g["h"]))
+    sm = HS.Stereomatcher(g["kL"], g["kR"], g["dL"], g["dR"], cam, extractor=ex)
+    sm.computeStereoMatches()
+    assert np.array_equal(sm.getData()[0], g["uRight"]) and np.array_equal(sm.getData()[1], g["depth"])
+    # left == right: every keypoint matches itself at distance 0, disparity 0 -> the reference's 0.01 px clamp (Stereomatcher.cpp:128-132)
+    sm = HS.Stereomatcher(g["kL"], g["kL"], g["dL"], g["dL"], cam, extractor=ex)
+    sm.computeStereoMatches()
+    uR, depth = sm.getData()
+    sp = oracle.stereo_params(fx=float(g["fx"]), mbf=float(g["fx"]) * 0.12, n_rows=int(g["h"]))
+    ouR, odepth, _, _ = oracle.stereo_match(g["kL"], g["dL"], g["kL"], g["dL"], sp)
+    assert np.array_equal(uR, ouR) and np.array_equal(depth, odepth)
+    assert (depth > 0).all() and np.array_equal(uR, (g["kL"]["x"].astype(np.float64) - 0.01).astype(np.float32))
+
+
+@pytest.mark.parametrize("w,h,nfeat,scale", [(643, 481, 700, 1.2), (320, 200, 500, 1.2), (800, 600, 1500, 1.4), (1024, 400, 6000, 1.2),
+                                              (97, 83, 300, 1.2)])
+def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
+    """odd widths (byte-wise tile loads at level 0), levels too small for a FAST cell, the 1.4 'Imaging' profile,
+    a wide frame with three root nodes and a quota above 1300."""
+    stage_parity(synth_image(40 + w, w, h), nfeat, scale)
+
+
+def test_empty_flat_and_noise_frames(gpu):
+    ex = HS.ORBExtractor(settings(500))
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)                                   # silent return, ORBExtractor.cpp:499-500
+    k, d = ex(np.full((240, 320), 77, np.uint8))
+    assert len(k) == 0                                                          # no corners anywhere
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)                    # FAST saturates: thousands of candidates per level
+    ok, od = oracle.extract(oracle.default_params(500), noise)
+    gk, gd = ex(noise)
+    assert_same_features(gk, gd, ok, od)
+
+
+def test_batch_equals_singles_and_is_deterministic(gpu):
+    imgs = [synth_image(60 + i, 640, 480) for i in range(5)]
+    ex = HS.ORBExtractor(settings(1000))
+    ks, ds = ex.extract_batch(imgs)
+    ks2, ds2 = ex.extract_batch(imgs)
+    for i, im in enumerate(imgs):
+        k1, d1 = ex(im)
+        assert k1.tobytes() == ks[i].tobytes() == ks2[i].tobytes() and np.array_equal(d1, ds[i]) and np.array_equal(ds[i], ds2[i])
+    ok, od = oracle.extract(oracle.default_params(1000), imgs[3])
+    assert_same_features(ks[3], ds[3], ok, od)
+
+
+def test_strided_input_and_capacity_error(gpu):
+    big = synth_image(70, 700, 500)
+    view = big[10:490, 20:660]                                                  # non-contiguous rows are re-packed by the binding
+    ex = HS.ORBExtractor(settings(800))
+    ok, od = oracle.extract(oracle.default_params(800), view)
+    gk, gd = ex(view)
+    assert_same_features(gk, gd, ok, od)
+    img = np.ascontiguousarray(view)
+    kps = np.zeros(10, N.KP_DTYPE)
+    desc = np.zeros((10, 32), np.uint8)
+    n = C.c_int32(-5)
+    st = ex._lib.hs_orb_extract(ex._h, img.ctypes.data_as(C.c_void_p), 640, 480, 640, kps.ctypes.data_as(C.c_void_p),
+                                desc.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert st == N.HS_ERR_CAPACITY and b"cap" in ex._lib.hs_orb_last_error(ex._h)
+    assert not kps["x"].any()                                                   # nothing partial written
+
+
+def test_properties_at_full_size(gpu):
+    """BASELINE sizes, checked through size-independent properties (no oracle run): level quotas, bounds, response ordering
+    inside the quadtree guarantee, scale bookkeeping, determinism, stereo consistency."""
+    L, R = synth_stereo_pair(5, 1920, 1080)
+    ex = HS.ORBExtractor(settings(2000))
+    (kL, kR), (dL, dR) = ex.extract_batch([L, R])
+    (kL2, _), _ = ex.extract_batch([L, R])
+    assert kL.tobytes() == kL2.tobytes()
+    quota = ex.GetFeaturesPerLevel()
+    sc = ex.GetScaleFactors()
+    for k in (kL, kR):
+        assert (np.diff(k["octave"]) >= 0).all()                                 # levels concatenated in order
+        for l in range(8):
+            m = k["octave"] == l
+            assert quota[l] <= m.sum() <= quota[l] + 2                           # DistributeOctTree overshoots by at most 2
+            lw, lh = np.rint(np.float32(1920) / sc[l]), np.rint(np.float32(1080) / sc[l])
+            x, y = k["x"][m] / sc[l], k["y"][m] / sc[l]
+            assert (np.abs(x - np.rint(x)) < 1e-3).all() and (x > 18.5).all() and (x < lw - 19.5).all() and (y > 18.5).all() and (y < lh - 19.5).all()
+            assert (k["size"][m] == np.float32(int(np.float32(31) * sc[l]))).all()
+        assert (k["response"] >= 19).all() and (k["angle"] >= 0).all() and (k["angle"] < 360).all()
+        assert len(np.unique(np.stack([k["x"], k["y"], k["octave"]], 1), axis=0)) == len(k)
+    sm = HS.Stereomatcher(kL, kR, dL, dR, HS.Camera(), extractor=ex)
+    sm.computeStereoMatches()
+    uR, depth = sm.getData()
+    m = depth > 0
+    assert m.sum() > 200 and (uR[~m] == -1).all() and (depth[~m] == -1).all()
+    disp = kL["x"][m] - uR[m]
+    assert (disp > 0).all() and (disp < 1050).all() and np.array_equal(depth[m], np.float32(1050.0 * 0.12) / disp)
+
+
+def test_device_api_bench_and_torch_interop_in_subprocess(gpu):
+    """Device-resident batch entry points with torch-owned HBM buffers and torch's stream (separate process: torch brings its
+    own HIP runtime and must be imported before the library)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_device_api_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "2", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and line["unit"] == "stereo_pairs/s" and line["roofline"]["frac"] > 0 and line["n_gpus"] == 1
