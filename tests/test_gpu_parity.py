@@ -94,14 +94,26 @@ def test_stereo_golden_and_identical_views(gpu):
     sm = HS.Stereomatcher(g["kL"], g["kR"], g["dL"], g["dR"], cam, extractor=ex)
     sm.computeStereoMatches()
     assert np.array_equal(sm.getData()[0], g["uRight"]) and np.array_equal(sm.getData()[1], g["depth"])
-    # left == right: every keypoint matches itself at distance 0, disparity 0 -> the reference's 0.01 px clamp (Stereomatcher.cpp:128-132)
+    # left == right: every keypoint matches itself at distance 0 with disparity 0 (the 0.01 px clamp, Stereomatcher.cpp:128-132);
+    # the median distance is then 0, thDist = 0, and the reference's `dist < thDist` filter (:146-155) rejects every match.
     sm = HS.Stereomatcher(g["kL"], g["kL"], g["dL"], g["dL"], cam, extractor=ex)
     sm.computeStereoMatches()
     uR, depth = sm.getData()
     sp = oracle.stereo_params(fx=float(g["fx"]), mbf=float(g["fx"]) * 0.12, n_rows=int(g["h"]))
     ouR, odepth, _, _ = oracle.stereo_match(g["kL"], g["dL"], g["kL"], g["dL"], sp)
     assert np.array_equal(uR, ouR) and np.array_equal(depth, odepth)
-    assert (depth > 0).all() and np.array_equal(uR, (g["kL"]["x"].astype(np.float64) - 0.01).astype(np.float32))
+    assert (depth == -1).all() and (uR == -1).all()
+    # one differing right descriptor lifts the median above 0 only if it is the median element; flip bits in most of them instead
+    dR = g["dL"].copy()
+    dR[: len(dR) * 3 // 4, 0] ^= 0x0F                                           # distance 4 for 3/4 of the keypoints
+    sm = HS.Stereomatcher(g["kL"], g["kL"], g["dL"], dR, cam, extractor=ex)
+    sm.computeStereoMatches()
+    uR, depth = sm.getData()
+    ouR, odepth, _, _ = oracle.stereo_match(g["kL"], g["dL"], g["kL"], dR, sp)
+    assert np.array_equal(uR, ouR) and np.array_equal(depth, odepth) and (depth > 0).sum() > len(dR) // 2
+    m = depth > 0
+    assert np.array_equal(uR[m], (g["kL"]["x"][m].astype(np.float64) - 0.01).astype(np.float32))
+    assert np.array_equal(depth[m], np.full(int(m.sum()), np.float32(float(g["fx"]) * 0.12) / np.float32(0.01), np.float32))
 
 
 @pytest.mark.parametrize("w,h,nfeat,scale", [(643, 481, 700, 1.2), (320, 200, 500, 1.2), (800, 600, 1500, 1.4), (1024, 400, 6000, 1.2),
