@@ -32,8 +32,8 @@ struct hs_orb {
     HsLevel* d_lv = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
-    uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr; uint16_t* d_pt_node = nullptr;
-    int32_t *d_cand_count = nullptr, *d_sel_count = nullptr;
+    uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr, *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
+    int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
     uint32_t* d_sel = nullptr;
     uint16_t* d_taps = nullptr;
     // staging for the host-pointer entry points
@@ -71,8 +71,8 @@ void free_geometry(hs_orb* h)
 {
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
-    hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pt_node);
-    h->d_cand_xy = h->d_cand_sk = nullptr; h->d_pt_node = nullptr;
+    hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
+    h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
     hipFree(h->d_sel); h->d_sel = nullptr;
 }
@@ -126,18 +126,20 @@ int configure(hs_orb* h, int w, int hh, int batch)
             const int sw = h->lv[l - 1].w, sh = h->lv[l - 1].h;
             const double scale_x = 1. / ((double)V.w / sw), scale_y = 1. / ((double)V.h / sh);
             int xmax = V.w;
-            size_t o0 = tables.size(); tables.resize(o0 + V.w);            // xofs
-            size_t o1 = tables.size(); tables.resize(o1 + 2 * (size_t)V.w); // ialpha
-            size_t o2 = tables.size(); tables.resize(o2 + V.h);            // yofs
-            size_t o3 = tables.size(); tables.resize(o3 + 2 * (size_t)V.h); // ibeta
+            auto grow = [&](size_t n) { size_t o = (tables.size() + 3) & ~(size_t)3; tables.resize(o + n); return o; };   // 8-byte aligned
+            size_t o0 = grow(4 * (size_t)V.w);   // x table: {sx, a0, a1, 0} per output column
+            size_t o1 = o0;
+            size_t o2 = grow(V.h);               // yofs
+            size_t o3 = grow(2 * (size_t)V.h);   // ibeta
             for (int dx = 0; dx < V.w; dx++) {
                 float fx = (float)((dx + 0.5) * scale_x - 0.5);
                 int sx = cv_floor_f(fx); fx -= sx;
                 if (sx < 0) { fx = 0; sx = 0; }
                 if (sx + 1 >= sw) { xmax = std::min(xmax, dx); if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
-                tables[o0 + dx] = (int16_t)sx;
-                tables[o1 + 2 * dx] = sat_short((1.f - fx) * 2048);
-                tables[o1 + 2 * dx + 1] = sat_short(fx * 2048);
+                tables[o0 + 4 * dx] = (int16_t)sx;
+                tables[o0 + 4 * dx + 1] = sat_short((1.f - fx) * 2048);
+                tables[o0 + 4 * dx + 2] = sat_short(fx * 2048);
+                tables[o0 + 4 * dx + 3] = 0;
             }
             for (int dy = 0; dy < V.h; dy++) {
                 float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -159,7 +161,10 @@ int configure(hs_orb* h, int w, int hh, int batch)
     const size_t ce = std::max<uint64_t>(cand * batch, 64);
     HIP_TRY(h, hipMalloc(&h->d_cand_xy, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_cand_sk, ce * 4));
+    HIP_TRY(h, hipMalloc(&h->d_pts_xy, ce * 4));
+    HIP_TRY(h, hipMalloc(&h->d_pts_sk, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_pt_node, ce * 2));
+    HIP_TRY(h, hipMalloc(&h->d_cell_count, std::max<size_t>((size_t)cells * batch * 4, 64)));
     HIP_TRY(h, hipMalloc(&h->d_cand_count, (size_t)batch * L * 4));
     HIP_TRY(h, hipMalloc(&h->d_sel_count, (size_t)batch * L * 4));
     HIP_TRY(h, hipMalloc(&h->d_sel, std::max<size_t>((size_t)sel * batch * 12, 64)));
@@ -207,15 +212,14 @@ int ensure_stereo_scratch(hs_orb* h, size_t entries)
 int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
 {
     const int L = h->p.nlevels;
-    HIP_TRY(h, hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * L * 4, s));
     mark(h, 0, s);
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
     hs_launch_fast(h->d_lv, L, img0, batch, h->total_cells, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride, s);
+                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, s);
     mark(h, 2, s);
-    hs_launch_quadtree(h->d_lv, L, batch, h->d_cand_xy, h->d_cand_sk, h->d_cand_count, h->cand_img_stride,
-                       h->d_pt_node, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
+    hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
+                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->sel_img_stride, h->max_kp,
                        h->d_taps, out, s);
@@ -575,8 +579,8 @@ int hs_orb_debug_candidates(hs_orb* h, int image, int level, int32_t* xys, int c
     if (cnt > cap) return fail(h, HS_ERR_CAPACITY, "more candidates than buffer");
     std::vector<uint32_t> xy(cnt), sk(cnt);
     if (cnt) {
-        HIP_TRY(h, hipMemcpy(xy.data(), h->d_cand_xy + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(h, hipMemcpy(sk.data(), h->d_cand_sk + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(xy.data(), h->d_pts_xy + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(sk.data(), h->d_pts_sk + (size_t)image * h->cand_img_stride + V.cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     }
     for (int i = 0; i < cnt; i++) { xys[3 * i] = xy[i] & 0xFFFF; xys[3 * i + 1] = xy[i] >> 16; xys[3 * i + 2] = sk[i] >> 24; }
     return HS_OK;

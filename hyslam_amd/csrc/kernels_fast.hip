@@ -7,14 +7,22 @@
 //   * NMS is 3x3, strict, and *per cell*: a neighbour outside the cell interior counts as score 0
 //     (cv::FAST zero-fills its score rows and never scores the 3 px frame of the Mat it is given);
 //   * score = max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1 over the 16 arcs of length 9.
-// The reference's cell == one workgroup here: the tile (interior + apron) is staged in LDS with coalesced
-// dword row loads, the score map lives only in LDS, so the only HBM traffic is one read of the level.
-// One launch covers every level of every image of the batch (blockIdx.x enumerates cells of all levels).
 //
-// Output: unordered candidate records per (image, level), appended with one global atomic per cell:
-//   cand_xy = y<<16 | x          (coordinates relative to (16,16), as in vToDistributeKeys)
-//   cand_sk = score<<24 | cell   (cell = row-major cell index; with (y,x) it restores the reference's
-//                                 vToDistributeKeys order, which only matters for response ties)
+// MI355X mapping.  The reference's cell is the unit of work: its tile (interior + apron) is staged in LDS with
+// coalesced dword row loads and the score map lives only in LDS, so the only HBM traffic is one read of each level.
+// The launch is PERSISTENT: 4 workgroups per CU each walk a contiguous range of the (image, level, cell) list;
+// the dwords of the NEXT cell's tile are fetched into registers before the current cell is processed, which takes
+// the ~2 us global-load latency off the per-cell critical path (a one-cell-per-workgroup launch was latency bound:
+// 7.5 us per cell at 5 workgroups/CU).  Ranges are dealt so that workgroups that share an XCD (blockIdx % 8) own
+// neighbouring cells and reuse each other's apron lines in that XCD's L2.  Per cell:
+//   pass 1  every pixel: compass-point quick reject -> "maybe" list in LDS (dense lanes for what follows)
+//   pass 2  maybe pixels: 16-bit darker/brighter ring masks, 9 contiguous cyclic bits -> corner list
+//   pass 3  corners: score into the LDS score tile;  pass 4: strict 3x3 NMS inside the cell
+// Output: each cell owns a fixed slot range (no global atomics, deterministic placement):
+//   cand_xy[cell slot] = y<<16 | x         (coordinates relative to (16,16), as in vToDistributeKeys)
+//   cand_sk[cell slot] = score<<24 | cell  (cell = row-major cell index; with (y,x) it restores the reference's
+//                                           vToDistributeKeys order, which only matters for response ties)
+//   cell_count[image][global cell] = number of slots used.
 // Bound: integer VALU + LDS byte reads; HBM bytes = P per frame.
 #include "hs_internal.h"
 
@@ -23,6 +31,11 @@
 #define SCORE_PITCH (HS_MAX_CELL + 4)        // interior + 1 px zero frame, padded
 #define SCORE_ROWS (HS_MAX_CELL + 2)
 #define MAX_OUT (HS_MAX_CELL * HS_MAX_CELL / 4)
+#define NPRE 6                               // prefetched dwords per thread: 1536 >= 70 rows x 19 dwords
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would expose the latency of
+// the next cell's prefetch at the first barrier after it is issued; the tile/list hand-offs inside a cell are LDS-only.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t)
 {
@@ -42,79 +55,155 @@ __device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t)
     return -b0 - 1;
 }
 
+struct CellGeom {           // wave-uniform description of one work item
+    int img, level, c, gcell;
+    int xoff, yoff;         // j*wCell, i*hCell: what the reference adds to cv::FAST's local coordinates (:463-464)
+    int iniX, iniY, tw, th; // sub-image handed to cv::FAST
+    int off, ndw;           // dword staging: tile x = off + (x - iniX); ndw dwords per row
+    int ccap;               // slots this cell owns
+    const uint8_t* rows;    // address of (a0, iniY) in the level
+    size_t pitch;
+    bool valid, aligned;
+};
+
+__device__ __forceinline__ CellGeom cell_geom(const HsLevel* __restrict__ lv, int nlevels, const HsImg0& img0, int total_cells, int w)
+{
+    CellGeom g;
+    g.img = w / total_cells;
+    g.gcell = w - g.img * total_cells;
+    int level = 0;
+    while (level + 1 < nlevels && g.gcell >= lv[level + 1].cell_begin) level++;
+    const HsLevel& L = lv[level];
+    g.level = level;
+    g.c = g.gcell - L.cell_begin;
+    const int ci = g.c / L.ncols, cj = g.c - ci * L.ncols;
+    g.xoff = cj * L.wcell; g.yoff = ci * L.hcell;
+    g.iniX = HS_BORDER + g.xoff; g.iniY = HS_BORDER + g.yoff;
+    const int maxX = min(g.iniX + L.wcell + 6, L.w - HS_BORDER), maxY = min(g.iniY + L.hcell + 6, L.h - HS_BORDER);
+    g.tw = maxX - g.iniX; g.th = maxY - g.iniY;
+    g.valid = g.tw >= 7 && g.th >= 7;                 // reference skip rules (:435,444) / cv::FAST on < 7 rows or columns
+    g.ccap = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+    const uint8_t* base;
+    if (level == 0) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
+    else { base = L.base + (size_t)g.img * L.img_stride; g.pitch = L.pitch; }
+    const int a0 = g.iniX & ~3;
+    g.off = g.iniX - a0;
+    g.ndw = (g.off + g.tw + 3) >> 2;
+    g.aligned = (((uintptr_t)base | g.pitch) & 3) == 0;
+    g.rows = base + (size_t)g.iniY * g.pitch + a0;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0, int fast_th,
                                                     uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
-                                                    int32_t* __restrict__ cand_count, uint64_t cand_img_stride)
+                                                    int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
+                                                    int total_cells, int total_work)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_ROWS * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t score[SCORE_ROWS * SCORE_PITCH];
-    __shared__ uint16_t clist[HS_MAX_CELL * HS_MAX_CELL];
+    __shared__ uint16_t mlist[HS_MAX_CELL * HS_MAX_CELL];      // "maybe" pixels (py<<8 | px)
+    __shared__ uint16_t clist[HS_MAX_CELL * HS_MAX_CELL];      // corners
     __shared__ uint32_t out_xy[MAX_OUT];
     __shared__ uint8_t out_s[MAX_OUT];
-    __shared__ int n_corner, n_out, out_base;
+    __shared__ int n_maybe, n_corner, n_out;
 
     const int tid = threadIdx.x;
-    const int img = blockIdx.y;
-    int level = 0;
-    while (level + 1 < nlevels && (int)blockIdx.x >= lv[level + 1].cell_begin) level++;
-    const HsLevel& L = lv[level];
-    const int c = blockIdx.x - L.cell_begin;
-    const int ci = c / L.ncols, cj = c - ci * L.ncols;
-    const int iniX = HS_BORDER + cj * L.wcell, iniY = HS_BORDER + ci * L.hcell;
-    const int maxX = min(iniX + L.wcell + 6, L.w - HS_BORDER), maxY = min(iniY + L.hcell + 6, L.h - HS_BORDER);
-    const int tw = maxX - iniX, th = maxY - iniY;      // sub-image handed to cv::FAST
-    if (tw < 7 || th < 7) return;                       // reference skip rules (:435,444) / FAST on < 7 rows
-    const int iw = tw - 6, ih = th - 6;                 // interior = pixels FAST can report
-
-    const uint8_t* base; size_t pitch;
-    if (level == 0) { base = hs_img0_ptr(img0, img); pitch = img0.row_stride; }
-    else { base = L.base + (size_t)img * L.img_stride; pitch = L.pitch; }
-
-    if (tid == 0) { n_corner = 0; n_out = 0; }
-    // zero the score frame
-    for (int i = tid; i < SCORE_ROWS * SCORE_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
-
-    // ---- stage the tile: coalesced dword loads of each row when alignment allows
-    const int a0 = iniX & ~3;
-    const int off = iniX - a0;                          // tile x = off + (x - iniX)
-    if ((((uintptr_t)base | pitch) & 3) == 0) {
-        const int ndw = (off + tw + 3) >> 2;            // <= 19
-        for (int i = tid; i < th * ndw; i += 256) {
-            int r = i / ndw, q = i - r * ndw;
-            uint32_t v = *reinterpret_cast<const uint32_t*>(base + (size_t)(iniY + r) * pitch + a0 + 4 * q);
-            *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * q]) = v;
-        }
-    } else {
-        for (int i = tid; i < th * tw; i += 256) {
-            int r = i / tw, q = i - r * tw;
-            tile[r * TILE_PITCH + off + q] = base[(size_t)(iniY + r) * pitch + iniX + q];
-        }
-    }
-    __syncthreads();
-
-    // ---- segment test: 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits
-    const int npix = iw * ih;
     const int t = fast_th;
     constexpr int RO[16] = { 3 * TILE_PITCH + 0, 3 * TILE_PITCH + 1, 2 * TILE_PITCH + 2, 1 * TILE_PITCH + 3,
                              0 * TILE_PITCH + 3, -1 * TILE_PITCH + 3, -2 * TILE_PITCH + 2, -3 * TILE_PITCH + 1,
                              -3 * TILE_PITCH + 0, -3 * TILE_PITCH - 1, -2 * TILE_PITCH - 2, -1 * TILE_PITCH - 3,
                              0 * TILE_PITCH - 3, 1 * TILE_PITCH - 3, 2 * TILE_PITCH - 2, 3 * TILE_PITCH - 1 };
-    for (int p0 = 0; p0 < npix; p0 += 256) {
-        int p = p0 + tid;
-        bool valid = p < npix;
-        int pp = valid ? p : 0;
-        int py = pp / iw, px = pp - py * iw;
-        const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
-        int v = ctr[0];
-        int lo = v - t, hi = v + t;
-        // quick reject on the four axis pairs (any 9-arc holds one pixel of every antipodal pair)
-        int r0 = ctr[RO[0]], r8 = ctr[RO[8]], r4 = ctr[RO[4]], r12 = ctr[RO[12]];
-        bool dk = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
-        bool br = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
-        bool maybe = valid && (dk || br);
-        if (__ballot(maybe) == 0ull) continue;
-        uint32_t mdark = 0, mbright = 0;
-        if (maybe) {
+
+    // contiguous range of work items; workgroups with equal blockIdx % 8 (same XCD) get neighbouring ranges
+    const int nblk = gridDim.x, per_xcd = nblk >> 3;
+    const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int per = (total_work + nblk - 1) / nblk;
+    const int w_begin = chunk * per, w_end = min(total_work, w_begin + per);
+    if (w_begin >= w_end) return;
+
+    for (int i = tid; i < SCORE_ROWS * SCORE_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    if (tid == 0) n_out = 0;
+
+    uint32_t pre[NPRE];
+    CellGeom g = cell_geom(lv, nlevels, img0, total_cells, w_begin);
+    auto prefetch = [&](const CellGeom& q) {
+        if (!(q.valid && q.aligned)) return;
+        const float rcp = 1.0f / (float)q.ndw;
+        const int n = q.th * q.ndw;
+#pragma unroll
+        for (int j = 0; j < NPRE; j++) {
+            int i = tid + 256 * j;
+            if (i < n) {
+                int r = (int)(((float)i + 0.5f) * rcp), c = i - r * q.ndw;
+                pre[j] = *reinterpret_cast<const uint32_t*>(q.rows + (size_t)r * q.pitch + 4 * c);
+            }
+        }
+    };
+    prefetch(g);
+
+    for (int w = w_begin; w < w_end; w++) {
+        const HsLevel& L = lv[g.level];
+        int32_t* cnt = &cell_count[(size_t)g.img * total_cells + g.gcell];
+        if (!g.valid) {
+            if (tid == 0) *cnt = 0;
+            if (w + 1 < w_end) { g = cell_geom(lv, nlevels, img0, total_cells, w + 1); prefetch(g); }
+            continue;
+        }
+        const int iw = g.tw - 6, ih = g.th - 6;                 // interior = pixels FAST can report
+        const int off = g.off;
+        // ---- stage the tile
+        if (g.aligned) {
+            const float rcp = 1.0f / (float)g.ndw;
+            const int n = g.th * g.ndw;
+#pragma unroll
+            for (int j = 0; j < NPRE; j++) {
+                int i = tid + 256 * j;
+                if (i < n) {
+                    int r = (int)(((float)i + 0.5f) * rcp), c = i - r * g.ndw;
+                    *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = pre[j];
+                }
+            }
+        } else {
+            const uint8_t* src = g.rows + off;                  // (iniX, iniY)
+            for (int i = tid; i < g.th * g.tw; i += 256) {
+                int r = i / g.tw, c = i - r * g.tw;
+                tile[r * TILE_PITCH + off + c] = src[(size_t)r * g.pitch + c];
+            }
+        }
+        if (tid == 0) { n_maybe = 0; n_corner = 0; }
+        LDS_BARRIER();                                           // S0: tile ready, previous cell fully drained
+        const CellGeom cur = g;
+        if (w + 1 < w_end) { g = cell_geom(lv, nlevels, img0, total_cells, w + 1); prefetch(g); }   // in flight during the passes
+
+        // ---- pass 1 (every pixel): quick reject on the four compass points.  A 9-arc of the 16-ring always holds two
+        //      ADJACENT compass points, i.e. (p0 or p8) and (p4 or p12).
+        const int npix = iw * ih;
+        const float rcp_iw = 1.0f / (float)iw;                  // exact floor(p/iw) for p < 4096, iw <= 64
+        for (int p = tid; p < npix; p += 256) {
+            int py = (int)(((float)p + 0.5f) * rcp_iw), px = p - py * iw;
+            const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
+            int v = ctr[0];
+            int lo = v - t, hi = v + t;
+            int r0 = ctr[RO[0]], r8 = ctr[RO[8]], r4 = ctr[RO[4]], r12 = ctr[RO[12]];
+            bool dk = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
+            bool br = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
+            if (dk || br) {
+                int slot = atomicAdd(&n_maybe, 1);
+                mlist[slot] = (uint16_t)((py << 8) | px);
+            }
+        }
+        LDS_BARRIER();                                           // S1
+        if (tid == 0) n_out = 0;                                 // everyone has left the previous cell's emit
+
+        // ---- pass 2 (maybe pixels): 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits
+        const int nm = n_maybe;
+        for (int i = tid; i < nm; i += 256) {
+            int pos = mlist[i];
+            int py = pos >> 8, px = pos & 255;
+            const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
+            int v = ctr[0];
+            int lo = v - t, hi = v + t;
+            uint32_t mdark = 0, mbright = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 int r = ctr[RO[k]];
@@ -127,64 +216,65 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
             uint32_t y = m2 & (m2 >> 1); y &= y >> 2; y &= y >> 4; y &= m2 >> 8;
             if (((x | y) & 0xFFFFu) != 0) {
                 int slot = atomicAdd(&n_corner, 1);
-                clist[slot] = (uint16_t)p;
+                clist[slot] = (uint16_t)pos;
             }
         }
-    }
-    __syncthreads();
+        LDS_BARRIER();                                           // S2
 
-    // ---- corner score for the (few) corners, dense lanes
-    const int nc = n_corner;
-    for (int i = tid; i < nc; i += 256) {
-        int p = clist[i];
-        int py = p / iw, px = p - py * iw;
-        const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
-        int v = ctr[0];
-        int d[16];
+        // ---- pass 3 (corners): corner score
+        const int nc = n_corner;
+        for (int i = tid; i < nc; i += 256) {
+            int pos = clist[i];
+            int py = pos >> 8, px = pos & 255;
+            const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
+            int v = ctr[0];
+            int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - (int)ctr[RO[k]];
-        score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)fast_corner_score(d, t);
-    }
-    __syncthreads();
-
-    // ---- 3x3 strict NMS inside the cell
-    for (int i = tid; i < nc; i += 256) {
-        int p = clist[i];
-        int py = p / iw, px = p - py * iw;
-        const uint8_t* sc = &score[(py + 1) * SCORE_PITCH + px + 1];
-        int s = sc[0];
-        bool keep = s > sc[1] && s > sc[-1] &&
-                    s > sc[-SCORE_PITCH - 1] && s > sc[-SCORE_PITCH] && s > sc[-SCORE_PITCH + 1] &&
-                    s > sc[SCORE_PITCH - 1] && s > sc[SCORE_PITCH] && s > sc[SCORE_PITCH + 1];
-        if (keep) {
-            int slot = atomicAdd(&n_out, 1);
-            // coordinates relative to (minBorderX, minBorderY): x_local + j*wCell (ORBExtractor.cpp:463-464)
-            int xr = px + 3 + cj * L.wcell, yr = py + 3 + ci * L.hcell;
-            out_xy[slot] = ((uint32_t)yr << 16) | (uint32_t)xr;
-            out_s[slot] = (uint8_t)s;
+            for (int k = 0; k < 16; k++) d[k] = v - (int)ctr[RO[k]];
+            score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)fast_corner_score(d, t);
         }
-    }
-    __syncthreads();
-    const int no = n_out;
-    if (no == 0) return;
-    int32_t* cnt = &cand_count[img * nlevels + level];
-    if (tid == 0) out_base = atomicAdd(cnt, no);
-    __syncthreads();
-    const int ob = out_base;
-    uint32_t* gxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
-    uint32_t* gsk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
-    for (int i = tid; i < no; i += 256) {
-        if (ob + i < L.cand_cap) {
-            gxy[ob + i] = out_xy[i];
-            gsk[ob + i] = ((uint32_t)out_s[i] << 24) | (uint32_t)c;
+        LDS_BARRIER();                                           // S3
+
+        // ---- pass 4: 3x3 strict NMS inside the cell
+        for (int i = tid; i < nc; i += 256) {
+            int pos = clist[i];
+            int py = pos >> 8, px = pos & 255;
+            const uint8_t* sc = &score[(py + 1) * SCORE_PITCH + px + 1];
+            int s = sc[0];
+            bool keep = s > sc[1] && s > sc[-1] &&
+                        s > sc[-SCORE_PITCH - 1] && s > sc[-SCORE_PITCH] && s > sc[-SCORE_PITCH + 1] &&
+                        s > sc[SCORE_PITCH - 1] && s > sc[SCORE_PITCH] && s > sc[SCORE_PITCH + 1];
+            if (keep) {
+                int slot = atomicAdd(&n_out, 1);
+                // coordinates relative to (minBorderX, minBorderY): x_local + j*wCell (ORBExtractor.cpp:463-464)
+                out_xy[slot] = ((uint32_t)(py + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff);
+                out_s[slot] = (uint8_t)s;
+            }
+        }
+        LDS_BARRIER();                                           // S4: tile, lists and score reads are finished
+
+        // ---- emit into this cell's slots; restore the all-zero score tile
+        const int no = n_out;
+        if (tid == 0) *cnt = no;
+        const size_t slot0 = (size_t)cur.img * cand_img_stride + L.cand_off + (size_t)cur.c * cur.ccap;
+        for (int i = tid; i < no; i += 256) {
+            cand_xy[slot0 + i] = out_xy[i];
+            cand_sk[slot0 + i] = ((uint32_t)out_s[i] << 24) | (uint32_t)cur.c;
+        }
+        for (int i = tid; i < nc; i += 256) {
+            int pos = clist[i];
+            score[((pos >> 8) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0;
         }
     }
 }
 
 void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
-                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cand_count, uint64_t cand_img_stride, hipStream_t s)
+                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride, hipStream_t s)
 {
     if (total_cells <= 0) return;
-    dim3 grid(total_cells, batch, 1);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cand_count, cand_img_stride);
+    const int total_work = total_cells * batch;
+    int nblk = 256 * 4;                                   // 4 persistent workgroups per CU
+    while (nblk > 8 && nblk / 2 >= total_work) nblk /= 2;  // tiny jobs: do not launch idle workgroups
+    hipLaunchKernelGGL(k_fast_cells, dim3(nblk), dim3(256), 0, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+                       cand_img_stride, total_cells, total_work);
 }

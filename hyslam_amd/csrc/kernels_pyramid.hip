@@ -8,9 +8,15 @@
 // The coefficient tables are built on the host with the same double/float expressions OpenCV uses.
 //
 // Bound: HBM/L2 bandwidth.  Algorithmic bytes per level = src px read once + dst px written once.
-// Each lane produces 4 consecutive destination pixels and stores one dword (coalesced 256 B per wave row).
+// Each lane produces 4 consecutive destination pixels and stores one dword (256 B per wave row).  The source
+// pixels of those 4 outputs span <= 11 bytes (scale <= 2), so each of the two source rows is fetched as up to
+// four aligned dwords and the taps are picked out with v_alignbyte instead of 16 byte loads; the x table is one
+// 8-byte record {sx, a0, a1, -} per output.
 #include "hs_internal.h"
 
+struct HsXTab { int16_t sx, a0, a1, pad; };
+
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict__ lv, int level, HsImg0 img0)
 {
     const HsLevel& D = lv[level];
@@ -19,34 +25,60 @@ __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict_
     const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (dy >= D.h || dx0 >= D.w) return;
 
-    const uint8_t* sbase; size_t spitch; int sw, sh;
+    const uint8_t* sbase; size_t spitch;
     if (level == 1) { sbase = hs_img0_ptr(img0, img); spitch = img0.row_stride; }
     else { const HsLevel& S = lv[level - 1]; sbase = S.base + (size_t)img * S.img_stride; spitch = S.pitch; }
-    sw = lv[level - 1].w; sh = lv[level - 1].h;
+    const int sw = lv[level - 1].w, sh = lv[level - 1].h;
 
-    int sy = D.yofs[dy];
+    const int sy = D.yofs[dy];
     const int b0 = D.ibeta[2 * dy], b1 = D.ibeta[2 * dy + 1];
-    int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-    int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
+    const int sy0 = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 >= sh ? sh - 1 : sy + 1);
     const uint8_t* S0 = sbase + (size_t)sy0 * spitch;
     const uint8_t* S1 = sbase + (size_t)sy1 * spitch;
 
-    uint32_t packed = 0;
+    // x table records for the 4 outputs (dx beyond the row reuse the last valid one; their bytes land in the row padding)
+    const HsXTab* xt = reinterpret_cast<const HsXTab*>(D.xofs);
+    HsXTab t[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int dx = dx0 + i;
-        if (dx < D.w) {
-            int sx = D.xofs[dx];
-            int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+    for (int i = 0; i < 4; i++) t[i] = xt[min(dx0 + i, D.w - 1)];
+
+    uint32_t packed = 0;
+    const int base = t[0].sx & ~3;
+    const int last = min(t[3].sx + 1, sw - 1);                 // last source byte any of the 4 outputs reads
+    if (ALIGNED && last - base < 12) {
+        uint32_t r0[4], r1[4];
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(S0 + base);
+        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(S1 + base);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bool need = base + 4 * j <= last;
+            r0[j] = need ? p0[j] : 0u;
+            r1[j] = need ? p1[j] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = t[i].sx - base;                       // 0..9
+            const int q = k >> 2;
+            uint32_t lo0 = q == 0 ? r0[0] : (q == 1 ? r0[1] : r0[2]), hi0 = q == 0 ? r0[1] : (q == 1 ? r0[2] : r0[3]);
+            uint32_t lo1 = q == 0 ? r1[0] : (q == 1 ? r1[1] : r1[2]), hi1 = q == 0 ? r1[1] : (q == 1 ? r1[2] : r1[3]);
+            uint32_t w0 = __builtin_amdgcn_alignbyte(hi0, lo0, k & 3);     // bytes k, k+1 in the low half
+            uint32_t w1 = __builtin_amdgcn_alignbyte(hi1, lo1, k & 3);
+            int s00 = w0 & 0xFF, s01 = (w0 >> 8) & 0xFF, s10 = w1 & 0xFF, s11 = (w1 >> 8) & 0xFF;
             int h0, h1;
-            if (dx < D.xmax) {
-                int a0 = D.ialpha[2 * dx], a1 = D.ialpha[2 * dx + 1];
-                h0 = S0[sx] * a0 + S0[sx1] * a1;
-                h1 = S1[sx] * a0 + S1[sx1] * a1;
-            } else {
-                h0 = S0[sx] * 2048;
-                h1 = S1[sx] * 2048;
-            }
+            if (dx0 + i < D.xmax) { h0 = s00 * t[i].a0 + s01 * t[i].a1; h1 = s10 * t[i].a0 + s11 * t[i].a1; }
+            else { h0 = s00 * 2048; h1 = s10 * 2048; }          // S[xofs]*ONE past xmax (right tap not read)
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sx = t[i].sx;
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            int h0, h1;
+            if (dx0 + i < D.xmax) { h0 = S0[sx] * t[i].a0 + S0[sx1] * t[i].a1; h1 = S1[sx] * t[i].a0 + S1[sx1] * t[i].a1; }
+            else { h0 = S0[sx] * 2048; h1 = S1[sx] * 2048; }
             int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
             packed |= (uint32_t)(v & 0xFF) << (8 * i);
         }
@@ -60,6 +92,10 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
     for (int l = 1; l < nlevels; l++) {
         dim3 block(64, 4, 1);
         dim3 grid((h_lv[l].w + 255) / 256, (h_lv[l].h + 3) / 4, batch);
-        hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, d_lv, l, img0);
+        // dword source fetches need 4-byte aligned rows: always true for our own levels, checked for the caller's frames
+        bool aligned = true;
+        if (l == 1) aligned = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 3) == 0;
+        if (aligned) hipLaunchKernelGGL(k_resize_level<true>, grid, block, 0, s, d_lv, l, img0);
+        else hipLaunchKernelGGL(k_resize_level<false>, grid, block, 0, s, d_lv, l, img0);
     }
 }

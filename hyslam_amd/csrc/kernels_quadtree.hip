@@ -22,7 +22,7 @@
 //     a 64-bit LDS atomicMax on score<<56 | ~order, where order = (cell, y, x) reproduces the reference's
 //     candidate order (cells row-major, cv::FAST's row-major scan inside a cell).
 //
-// Inputs are the unordered candidate records written by k_fast_cells.  Outputs per (image, level):
+// Inputs are the per-cell candidate slots written by k_fast_cells (gathered into a dense list first).  Outputs per (image, level):
 // selected (x,y,score) in final list order + count.  Bound: LDS atomics / VALU; HBM traffic negligible.
 #include "hs_internal.h"
 
@@ -59,10 +59,11 @@ __device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
     return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4
 }
 
-__global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels,
+__global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
-                                                   const int32_t* __restrict__ cand_count, uint64_t cand_img_stride,
-                                                   uint16_t* __restrict__ pt_node_all,
+                                                   const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
+                                                   uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
+                                                   uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride)
 {
     __shared__ QtNodes nodes[2];
@@ -78,13 +79,32 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     const int level = blockIdx.x, img = blockIdx.y;
     const HsLevel& L = lv[level];
     const int N = L.quota;
-    int n = cand_count[img * nlevels + level];
-    if (n > L.cand_cap) n = L.cand_cap;
-    const uint32_t* pxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
-    const uint32_t* psk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
+    uint32_t* pxy = pts_xy_all + (size_t)img * cand_img_stride + L.cand_off;
+    uint32_t* psk = pts_sk_all + (size_t)img * cand_img_stride + L.cand_off;
     uint16_t* pnode = pt_node_all + (size_t)img * cand_img_stride + L.cand_off;
     uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
     int32_t* out_n = &sel_count[img * nlevels + level];
+
+    // ---- gather this level's candidates from the per-cell slots k_fast_cells filled into one dense list
+    //      (block-wide prefix sum over the cell counts, one thread copies one cell: a few records each)
+    int n = 0;
+    {
+        const int ncell = L.ncols * L.nrows;
+        const int ccap = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+        const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
+        const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
+        const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
+        for (int c0 = 0; c0 < ncell; c0 += QT_T) {
+            const int c = c0 + tid;
+            const int k = c < ncell ? min(ccnt[c], ccap) : 0;
+            int tot; int pre = n + block_scan_excl(k, s_wave, tot);
+            const size_t src = (size_t)c * ccap;
+            for (int i = 0; i < k; i++) { pxy[pre + i] = sxy[src + i]; psk[pre + i] = ssk[src + i]; }
+            n += tot;
+        }
+        __syncthreads();      // the dense list is complete (written and read by this workgroup only)
+    }
+    if (tid == 0) cand_count[img * nlevels + level] = n;
 
     const int nIni = L.n_ini;
     const float hX = L.hx;
@@ -318,11 +338,12 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     if (tid == 0) *out_n = min(S, L.sel_cap);
 }
 
-void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch,
-                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cand_count, uint64_t cand_img_stride,
-                        uint16_t* pt_node, uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s)
+void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
+                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
+                        uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s)
 {
     dim3 grid(nlevels, batch, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, cand_xy, cand_sk, cand_count, cand_img_stride,
-                       pt_node, sel_xys, sel_count, sel_img_stride);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride);
 }

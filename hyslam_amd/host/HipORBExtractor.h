@@ -1,0 +1,126 @@
+// HipORBExtractor.h — header-only C++ adaptors that put the C ABI (include/hyslam_amd.h) behind hySLAM's own
+// interfaces, so Tracking / Mapping see a drop-in:
+//   HYSLAM::HipORBExtractor : HYSLAM::FeatureExtractor        (src/features/FeatureExtractor.h:25-37; replaces
+//                                                              ORBExtractor, src/features/ORBExtractor.h:62-130)
+//   HYSLAM::HipORBDistance  : HYSLAM::DescriptorDistance      (src/features/low_level/DescriptorDistance.h)
+//   HYSLAM::HipStereomatcher                                   (src/features/Stereomatcher.h:25-51)
+// Build inside hySLAM with -DHYSLAM_AMD_WITH_HYSLAM (real OpenCV + hySLAM headers); in this repository the same
+// code is compiled against host/cv_compat.h so its gather/scatter logic is unit-tested without OpenCV.
+#pragma once
+#ifdef HYSLAM_AMD_WITH_HYSLAM
+#include <FeatureExtractor.h>
+#include <FeatureMatcher.h>
+#include <opencv2/core/core.hpp>
+#else
+#include "cv_compat.h"
+#endif
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/hyslam_amd.h"
+
+namespace HYSLAM {
+
+// ORBDistance (DescriptorDistance.cpp:9-25) kept on the host for the callers that still ask per-pair distances.
+class HipORBDistance : public DescriptorDistance {
+public:
+    float distance(const cv::Mat& D1, const cv::Mat& D2) override {
+        const uint64_t* a = reinterpret_cast<const uint64_t*>(D1.ptr(0));
+        const uint64_t* b = reinterpret_cast<const uint64_t*>(D2.ptr(0));
+        int d = 0;
+        for (int i = 0; i < 4; i++) d += __builtin_popcountll(a[i] ^ b[i]);
+        return static_cast<float>(d);
+    }
+};
+
+class HipORBExtractor : public FeatureExtractor {
+public:
+    HipORBExtractor(std::shared_ptr<DescriptorDistance> dist_func_, FeatureExtractorSettings settings, int device = 0)
+        : dist_func(dist_func_) {
+        hs_orb_params p;
+        hs_orb_default_params(&p);
+        p.nfeatures = settings.nFeatures; p.scale_factor = settings.fScaleFactor; p.nlevels = settings.nLevels;
+        p.cell_px = settings.N_CELLS; p.ini_th_fast = settings.init_threshold; p.min_th_fast = settings.min_threshold;
+        int st = hs_orb_create(&p, device, &h);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st));
+        cap = hs_orb_max_keypoints(h);
+        kps.resize(cap); desc.resize((size_t)cap * HS_DESC_BYTES);
+    }
+    ~HipORBExtractor() override { hs_orb_destroy(h); }
+    HipORBExtractor(const HipORBExtractor&) = delete;
+    HipORBExtractor& operator=(const HipORBExtractor&) = delete;
+
+    // ORBExtractor::operator(), src/features/ORBExtractor.cpp:496-562: keypoints are cleared, descriptors appended.
+    void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                    std::vector<FeatureDescriptor>& descriptors) override {
+        cv::Mat image = _image.getMat();
+        if (image.empty()) return;
+        if (image.type() != 0) throw std::runtime_error("HipORBExtractor: image must be CV_8UC1");
+        int32_t n = 0;
+        int st = hs_orb_extract(h, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(), cap, &n);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        _keypoints.clear();
+        _keypoints.reserve(n);
+        descriptors.reserve(descriptors.size() + n);
+        for (int i = 0; i < n; i++) {
+            cv::KeyPoint k;
+            k.pt.x = kps[i].x; k.pt.y = kps[i].y; k.size = kps[i].size; k.angle = kps[i].angle;
+            k.response = kps[i].response; k.octave = kps[i].octave; k.class_id = -1;
+            _keypoints.push_back(k);
+            descriptors.push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, desc.data() + (size_t)i * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
+        }
+    }
+    int GetLevels() override { return hs_orb_get_levels(h); }
+    float GetScaleFactor() override { return hs_orb_get_scale_factor(h); }
+    std::vector<float> GetScaleFactors() override { return table(0); }
+    std::vector<float> GetInverseScaleFactors() override { return table(1); }
+    std::vector<float> GetScaleSigmaSquares() override { return table(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() override { return table(3); }
+    hs_orb* handle() { return h; }
+
+private:
+    std::vector<float> table(int which) {
+        std::vector<float> t[4];
+        for (auto& v : t) v.resize(GetLevels());
+        hs_orb_get_scale_tables(h, t[0].data(), t[1].data(), t[2].data(), t[3].data(), nullptr);
+        return t[which];
+    }
+    hs_orb* h = nullptr;
+    int cap = 0;
+    std::vector<hs_keypoint> kps;
+    std::vector<uint8_t> desc;
+    std::shared_ptr<DescriptorDistance> dist_func;
+};
+
+// Stereomatcher (src/features/Stereomatcher.h:25-51) over flat arrays: construct, computeStereoMatches(), getData().
+class HipStereomatcher {
+public:
+    HipStereomatcher(hs_orb* handle, const std::vector<cv::KeyPoint>& keys, const std::vector<cv::KeyPoint>& keysR,
+                     const std::vector<FeatureDescriptor>& descs, const std::vector<FeatureDescriptor>& descsR,
+                     float fx, float mbf, float mnMaxY, FeatureMatcherSettings settings, float size_ref = 31.f)
+        : h(handle) {
+        sp.fx = fx; sp.mbf = mbf; sp.n_rows = (int)mnMaxY; sp.th_high = settings.TH_HIGH; sp.th_low = settings.TH_LOW; sp.size_ref = size_ref;
+        gather(keys, descs, kL, dL); gather(keysR, descsR, kR, dR);
+    }
+    void computeStereoMatches() {
+        mvuRight.assign(kL.size(), -1.0f); mvDepth.assign(kL.size(), -1.0f);
+        int st = hs_stereo_match(h, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
+        if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
+    }
+    void getData(std::vector<float>& mvuRight_, std::vector<float>& mvDepth_) { mvuRight_ = mvuRight; mvDepth_ = mvDepth; }
+
+private:
+    static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) {
+        ok.resize(k.size()); od.resize(k.size() * HS_DESC_BYTES);
+        for (size_t i = 0; i < k.size(); i++) {
+            ok[i] = hs_keypoint{ k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave };
+            cv::Mat row = d[i].rawDescriptor();
+            std::memcpy(od.data() + i * HS_DESC_BYTES, row.ptr(0), HS_DESC_BYTES);
+        }
+    }
+    hs_orb* h; hs_stereo_params sp;
+    std::vector<hs_keypoint> kL, kR; std::vector<uint8_t> dL, dR;
+    std::vector<float> mvuRight, mvDepth;
+};
+
+}  // namespace HYSLAM

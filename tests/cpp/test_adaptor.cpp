@@ -1,0 +1,58 @@
+// Exercises hyslam_amd/host/HipORBExtractor.h the way ImageProcessing::ProcessStereoImage uses an extractor and the
+// stereo matcher (src/main/ImageProcessing.cpp:82-103), and compares with the CPU oracle (test infrastructure).
+// usage: test_adaptor W H  < left.raw right.raw on stdin        prints "ADAPTOR OK ..." on success
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../hyslam_amd/host/HipORBExtractor.h"
+#include "../../oracle/hs_oracle.h"
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) return 2;
+    const int W = atoi(argv[1]), H = atoi(argv[2]);
+    cv::Mat L(H, W), R(H, W);
+    if (fread(L.data, 1, (size_t)W * H, stdin) != (size_t)W * H || fread(R.data, 1, (size_t)W * H, stdin) != (size_t)W * H) return 3;
+    using namespace HYSLAM;
+    FeatureExtractorSettings s; s.nFeatures = 1000;
+    int ndev = 0;
+    if (hs_device_count(&ndev) != HS_OK || ndev == 0) {
+        try { HipORBExtractor ex(std::make_shared<HipORBDistance>(), s); } catch (const std::exception& e) { printf("NO DEVICE: %s\n", e.what()); return 0; }
+        return 4;      // must have thrown: there is no CPU fallback
+    }
+    auto dist = std::make_shared<HipORBDistance>();
+    HipORBExtractor exL(dist, s), exR(dist, s);
+    std::vector<cv::KeyPoint> kL, kR; std::vector<FeatureDescriptor> dL, dR;
+    exL(L, cv::Mat(), kL, dL);
+    exR(R, cv::Mat(), kR, dR);
+    std::vector<cv::KeyPoint> none; std::vector<FeatureDescriptor> dnone;
+    exL(cv::Mat(), cv::Mat(), none, dnone);
+    if (!none.empty() || !dnone.empty()) return 5;
+    FeatureMatcherSettings ms;
+    HipStereomatcher sm(exL.handle(), kL, kR, dL, dR, 500.f, 60.f, (float)H, ms);
+    sm.computeStereoMatches();
+    std::vector<float> uR, depth; sm.getData(uR, depth);
+
+    hso_orb_params p; hso_default_params(&p); p.nfeatures = 1000;
+    const int cap = 1200;
+    std::vector<hso_keypoint> okL(cap), okR(cap); std::vector<uint8_t> odL(cap * 32), odR(cap * 32);
+    int nL = hso_orb_extract(&p, L.data, W, H, W, okL.data(), odL.data(), cap, nullptr);
+    int nR = hso_orb_extract(&p, R.data, W, H, W, okR.data(), odR.data(), cap, nullptr);
+    if (nL != (int)kL.size() || nR != (int)kR.size() || dL.size() != kL.size()) { printf("count mismatch %d %zu %d %zu\n", nL, kL.size(), nR, kR.size()); return 6; }
+    for (int i = 0; i < nL; i++) {
+        if (kL[i].pt.x != okL[i].x || kL[i].pt.y != okL[i].y || kL[i].angle != okL[i].angle || kL[i].octave != okL[i].octave ||
+            kL[i].size != okL[i].size || kL[i].response != okL[i].response || kL[i].class_id != -1) { printf("keypoint %d differs\n", i); return 7; }
+        cv::Mat row = dL[i].rawDescriptor();
+        if (memcmp(row.ptr(0), &odL[i * 32], 32)) { printf("descriptor %d differs\n", i); return 8; }
+    }
+    if (dL[0].distance(dL[1]) != (float)hso_hamming256(&odL[0], &odL[32])) return 9;
+    hso_stereo_params sp{ 500.f, 60.f, H, 100.f, 50.f, 31.f };
+    std::vector<float> ouR(nL), odepth(nL);
+    hso_stereo_match(okL.data(), odL.data(), nL, okR.data(), odR.data(), nR, &sp, ouR.data(), odepth.data(), nullptr, nullptr);
+    int matches = 0;
+    for (int i = 0; i < nL; i++) { if (uR[i] != ouR[i] || depth[i] != odepth[i]) { printf("stereo %d differs\n", i); return 10; } matches += depth[i] > 0; }
+    std::vector<float> sf = exL.GetScaleFactors();
+    if (exL.GetLevels() != 8 || sf.size() != 8 || sf[1] != 1.2f) return 11;
+    printf("ADAPTOR OK %d %d keypoints, %d stereo matches\n", nL, nR, matches);
+    return 0;
+}
