@@ -3,5 +3,6 @@
 The compute lives in libhyslam_amd.so (hand-written HIP for gfx950) behind the C ABI of include/hyslam_amd.h;
 this package is the thin host-side mirror of the reference's FeatureExtractor / Stereomatcher interfaces.
 """
-from .features import (Camera, FeatureExtractorSettings, FeatureMatcherSettings, HsError, KP_DTYPE, ORBExtractor,  # noqa: F401
-                       ORBFactory, Stereomatcher, stereo_params)
+from .features import (Camera, FeatureExtractorSettings, FeatureMatcher, FeatureMatcherSettings, HsError, KP_DTYPE,  # noqa: F401
+                       ORBExtractor, ORBFactory, Stereomatcher, stereo_params)
+from ._native import FrameView, LM_DTYPE, ProjParams  # noqa: F401

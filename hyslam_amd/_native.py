@@ -26,6 +26,24 @@ class StereoParams(C.Structure):
                 ("th_low", C.c_float), ("size_ref", C.c_float)]
 
 
+LM_DTYPE = np.dtype([("pos", "<f4", 3), ("size", "<f4"), ("min_dist", "<f4"), ("max_dist", "<f4"), ("normal", "<f4", 3),
+                     ("assoc_kp", "<i4"), ("prev_angle", "<f4"), ("skip", "<i4"), ("desc", "u1", 32)])
+
+
+class FrameView(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("sensor", C.c_int32), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("size_ref", C.c_float), ("n", C.c_int32),
+                ("kps", C.c_void_p), ("desc", C.c_void_p), ("uR", C.c_void_p), ("kp_lm_obs", C.c_void_p)]
+
+
+class ProjParams(C.Structure):
+    _fields_ = [("th", C.c_float), ("score_threshold", C.c_float), ("second_best_ratio", C.c_float),
+                ("frac_smaller", C.c_float), ("frac_larger", C.c_float),
+                ("use_distance", C.c_int32), ("use_stereo", C.c_int32), ("check_rotation", C.c_int32)]
+
+
 class HsError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("hyslam_amd: %s (status %d)" % (msg, status))
@@ -38,6 +56,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
+    "hs_search_by_projection", "hs_search_by_bow", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_orb_profile_begin", "hs_orb_profile_end",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
@@ -80,6 +99,11 @@ def lib():
     L.hs_stereo_frontend_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, sz, sz,
                                                   vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
     L.hs_orb_synchronize.argtypes = [vp, vp]
+    L.hs_search_by_projection.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
+    L.hs_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                   vp, f32, f32, C.c_int, vp, vp]
+    L.hs_hamming_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.hs_hamming_knn2_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     L.hs_orb_profile_begin.argtypes = [vp]
     L.hs_orb_profile_end.argtypes = [vp, vp, vp]
     L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]

@@ -41,6 +41,8 @@ struct hs_orb {
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
     int last_batch = 0; HsImg0 last_img0{};
+    // bump-allocated scratch for the host-pointer matcher entry points
+    uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
     // stage profiling: events[i] marks the start of stage prof_stage[i]; the event after the last stage has stage -1
     bool prof = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -229,6 +231,27 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     return HS_OK;
 }
 
+// grow-only device scratch, carved in 256-byte aligned pieces; scratch_begin() invalidates earlier pieces
+int scratch_begin(hs_orb* h, size_t total)
+{
+    total += 4096;
+    if (total > h->scratch_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        hipFree(h->d_scratch); h->d_scratch = nullptr; h->scratch_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_scratch, total));
+        h->scratch_bytes = total;
+    }
+    h->scratch_used = 0;
+    return HS_OK;
+}
+template <class T> T* carve(hs_orb* h, size_t count)
+{
+    T* p = reinterpret_cast<T*>(h->d_scratch + h->scratch_used);
+    h->scratch_used += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+}
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32_t* nL, const hs_keypoint* kR, const uint8_t* dR,
                 const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
 {
@@ -327,7 +350,7 @@ void hs_orb_destroy(hs_orb* h)
     free_geometry(h);
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
-    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd);
+    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd); hipFree(h->d_scratch);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -511,6 +534,137 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     if (rc != HS_OK) return rc;
     run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
     HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
+                            int32_t* match_idx, float* match_dist, int32_t* n_matches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!F || !pp || L < 0 || !n_matches || (L > 0 && (!lms || !match_idx || !match_dist)) || F->n < 0 || F->n > 65535 ||
+        (F->n > 0 && (!F->kps || !F->desc)) || (pp->use_stereo && F->sensor != 0 && F->n > 0 && !F->uR))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_matches = 0;
+    if (L == 0) return HS_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = F->n;
+    const size_t nn = (size_t)std::max(n, 1);
+    int rc = scratch_begin(h, pad256(nn * sizeof(hs_keypoint)) + pad256(nn * 32) + 2 * pad256(nn * 4) + pad256(nn * 2) + pad256(nn * 4) +
+                              pad256((size_t)L * sizeof(hs_landmark)) + 3 * pad256((size_t)L * 4) + 256);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    hs_keypoint* d_kps = carve<hs_keypoint>(h, nn); uint8_t* d_desc = carve<uint8_t>(h, nn * 32);
+    float* d_uR = carve<float>(h, nn); int32_t* d_obs = carve<int32_t>(h, nn); int8_t* d_cell = carve<int8_t>(h, nn * 2);
+    int32_t* d_winner = carve<int32_t>(h, nn);
+    hs_landmark* d_lms = carve<hs_landmark>(h, L);
+    int32_t* d_midx = carve<int32_t>(h, L); float* d_mdist = carve<float>(h, L); float* d_pangle = carve<float>(h, L);
+    int32_t* d_nm = carve<int32_t>(h, 1);
+    if (n > 0) {
+        HIP_TRY(h, hipMemcpyAsync(d_kps, F->kps, (size_t)n * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(d_desc, F->desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+        if (F->uR) HIP_TRY(h, hipMemcpyAsync(d_uR, F->uR, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        if (F->kp_lm_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, F->kp_lm_obs, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(h, hipMemcpyAsync(d_lms, lms, (size_t)L * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
+    hs_launch_frame_grid(*F, d_kps, d_cell, s);
+    hs_launch_search_projection(*F, d_kps, d_desc, F->uR ? d_uR : nullptr, F->kp_lm_obs ? d_obs : nullptr, d_cell, d_lms, L, *pp,
+                                d_midx, d_mdist, d_winner, d_pangle, d_nm, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(match_idx, d_midx, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(match_dist, d_mdist, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int i = 0; i < L; i++) if (match_idx[i] < 0) match_dist[i] = -1.f;      // entries dropped by the rotation check
+    return HS_OK;
+}
+
+int hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                     const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                     const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                     const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                     const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation,
+                     int32_t* match12, int32_t* n_matches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || !n_matches || (n1 > 0 && (!kps1 || !desc1 || !match12)) || (n2 > 0 && (!kps2 || !desc2)) ||
+        (nn1 > 0 && (!node_id1 || !node_ptr1 || !idx1)) || (nn2 > 0 && (!node_id2 || !node_ptr2 || !idx2)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_matches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || nn1 == 0 || nn2 == 0) return HS_OK;
+    // merge-walk of the two DBoW2::FeatureVector maps (FeatureMatcher.cc:230-265): nodes present on both sides
+    std::vector<int32_t> pa, pb;
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (node_id1[a] == node_id2[b]) { pa.push_back(a++); pb.push_back(b++); }
+        else if (node_id1[a] < node_id2[b]) a++; else b++;
+    }
+    const int np = (int)pa.size();
+    const int m1 = node_ptr1[nn1], m2 = node_ptr2[nn2];
+    for (int i = 0; i < m1; i++) if (idx1[i] < 0 || idx1[i] >= n1) return fail(h, HS_ERR_INVALID, "feature vector index out of range");
+    for (int i = 0; i < m2; i++) if (idx2[i] < 0 || idx2[i] >= n2) return fail(h, HS_ERR_INVALID, "feature vector index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = scratch_begin(h, pad256((size_t)n1 * sizeof(hs_keypoint)) + pad256((size_t)n2 * sizeof(hs_keypoint)) + pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) +
+                              pad256((size_t)(nn1 + 1) * 4) + pad256((size_t)(nn2 + 1) * 4) + pad256((size_t)std::max(m1, 1) * 4) + pad256((size_t)std::max(m2, 1) * 4) +
+                              2 * pad256((size_t)std::max(np, 1) * 4) + pad256(n1) + 3 * pad256((size_t)n1 * 4) + 256);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    hs_keypoint* d_k1 = carve<hs_keypoint>(h, n1); hs_keypoint* d_k2 = carve<hs_keypoint>(h, n2);
+    uint8_t* d_d1 = carve<uint8_t>(h, (size_t)n1 * 32); uint8_t* d_d2 = carve<uint8_t>(h, (size_t)n2 * 32);
+    int32_t* d_p1 = carve<int32_t>(h, nn1 + 1); int32_t* d_p2 = carve<int32_t>(h, nn2 + 1);
+    int32_t* d_i1 = carve<int32_t>(h, std::max(m1, 1)); int32_t* d_i2 = carve<int32_t>(h, std::max(m2, 1));
+    int32_t* d_pa = carve<int32_t>(h, std::max(np, 1)); int32_t* d_pb = carve<int32_t>(h, std::max(np, 1));
+    uint8_t* d_keep = carve<uint8_t>(h, n1);
+    int32_t* d_m = carve<int32_t>(h, n1); float* d_ang = carve<float>(h, n1); int32_t* d_self = carve<int32_t>(h, n1);
+    int32_t* d_nm = carve<int32_t>(h, 1);
+    HIP_TRY(h, hipMemcpyAsync(d_k1, kps1, (size_t)n1 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_k2, kps2, (size_t)n2 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_p1, node_ptr1, (size_t)(nn1 + 1) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_p2, node_ptr2, (size_t)(nn2 + 1) * 4, hipMemcpyHostToDevice, s));
+    if (m1) HIP_TRY(h, hipMemcpyAsync(d_i1, idx1, (size_t)m1 * 4, hipMemcpyHostToDevice, s));
+    if (m2) HIP_TRY(h, hipMemcpyAsync(d_i2, idx2, (size_t)m2 * 4, hipMemcpyHostToDevice, s));
+    if (np) { HIP_TRY(h, hipMemcpyAsync(d_pa, pa.data(), (size_t)np * 4, hipMemcpyHostToDevice, s)); HIP_TRY(h, hipMemcpyAsync(d_pb, pb.data(), (size_t)np * 4, hipMemcpyHostToDevice, s)); }
+    if (keep1) HIP_TRY(h, hipMemcpyAsync(d_keep, keep1, n1, hipMemcpyHostToDevice, s));
+    hs_launch_bow(d_pa, d_pb, np, d_p1, d_i1, d_p2, d_i2, d_d1, d_d2, keep1 ? d_keep : nullptr, score_threshold, second_best_ratio,
+                  d_m, n1, d_k1, d_k2, d_ang, check_rotation, d_self, d_nm, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(match12, d_m, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
+int hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                           int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_best_idx || !d_best_dist || !d_second_dist)) || (nt > 0 && !d_t)) return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hs_launch_knn2(d_q, nq, d_t, nt, d_best_idx, d_best_dist, d_second_dist, stream ? (hipStream_t)stream : h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!q || !best_idx || !best_dist || !second_dist)) || (nt > 0 && !t)) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (nq == 0) return HS_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = scratch_begin(h, pad256((size_t)nq * 32) + pad256((size_t)std::max(nt, 1) * 32) + 3 * pad256((size_t)nq * 4));
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    uint8_t* dq = carve<uint8_t>(h, (size_t)nq * 32); uint8_t* dt = carve<uint8_t>(h, (size_t)std::max(nt, 1) * 32);
+    int32_t* bi = carve<int32_t>(h, nq); int32_t* bd = carve<int32_t>(h, nq); int32_t* sd = carve<int32_t>(h, nq);
+    HIP_TRY(h, hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if (nt) HIP_TRY(h, hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    hs_launch_knn2(dq, nq, dt, nt, bi, bd, sd, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(best_idx, bi, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(best_dist, bd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(second_dist, sd, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
     return HS_OK;
 }
 

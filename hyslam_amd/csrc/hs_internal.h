@@ -79,3 +79,16 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
                       int32_t* best_dist /*[pairs][cap] scratch*/, hipStream_t s);
 void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s);
+
+// kernels_match.hip
+void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, hipStream_t s);
+void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const float* d_uR,
+                                 const int32_t* d_obs, const int8_t* d_cell, const hs_landmark* d_lms, int L, const hs_proj_params& pp,
+                                 int32_t* d_match_idx, float* d_match_dist, int32_t* d_winner, float* d_prev_angle_scratch,
+                                 int32_t* d_n_matches, hipStream_t s);
+void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
+                   const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
+                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, float thr, float ratio,
+                   int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
+                   int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
+void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);

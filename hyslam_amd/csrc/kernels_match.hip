@@ -1,0 +1,356 @@
+// kernels_match.hip — K8b/K8c/K8d: the Hamming matchers of HYSLAM::FeatureMatcher on flat arrays.
+//
+//   k_frame_grid          Frame::AssignFeaturesToGrid / PosInGrid          src/core/Frame.cc:137-153,459-469
+//   k_search_projection   FeatureMatcher::_SearchByProjection_             src/features/FeatureMatcher.cc:57-121
+//                         + Frame::ProjectLandMark / Camera::Project       src/core/Frame.cc:170-180, src/core/Camera.cpp:116-153
+//                         + landMarkSizePixels, GetFeaturesInAreaNEW       src/core/Frame.cc:296-317,416-457
+//                         + the view criteria                              src/features/MatchCriteria.cpp:113-360
+//   k_rotation_filter     RotationConsistency + ComputeThreeMaxima         src/features/MatchCriteria.cpp:684-767
+//   k_bow_match           BestMatchBoWCriterion inside _SearchByBoW_       src/features/FeatureMatcher.cc:281-345, MatchCriteria.cpp:601-635
+//   k_knn2                brute-force Hamming 2-NN (no reference call site; config 5)
+//
+// One wavefront owns one landmark (or one query descriptor).  The reference walks the 64x48 frame grid and filters
+// the few keypoints in range; here every lane tests keypoints against the SAME predicate (cell range of the reference's
+// query, |dx|<r, |dy|<r, then the view criteria): 2000-3000 keypoints per landmark are 32-47 lane iterations, L2-resident.
+// The reference's first-minimum-wins over its candidate order (grid column, then row, then insertion order) is the key
+//   dist<<32 | cellx<<22 | celly<<16 | keypoint index;
+// the second-best distance is order independent (second smallest of the multiset).
+// cv::Mat products in the reference are OpenCV gemm calls (float data, double accumulation, one rounding): restated in fp64.
+#include "hs_internal.h"
+#include <cfloat>
+#include <cstddef>
+
+#define GRID_COLS 64   // FRAME_GRID_COLS, src/core/Frame.h
+#define GRID_ROWS 48
+
+struct HsFrameDev {            // hs_frame_view with device pointers
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy, mbf;
+    int32_t sensor;
+    float min_x, max_x, min_y, max_y, size_ref;
+    int32_t n;
+    const hs_keypoint* kps; const uint8_t* desc; const float* uR; const int32_t* kp_lm_obs;
+    const int8_t* cell;        // [n][2] grid cell of each keypoint, -1 = outside
+};
+
+__global__ void k_frame_grid(HsFrameDev F, int8_t* __restrict__ cell)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F.n) return;
+    const float invW = (float)GRID_COLS / (F.max_x - F.min_x), invH = (float)GRID_ROWS / (F.max_y - F.min_y);
+    int px = (int)roundf((F.kps[i].x - F.min_x) * invW);
+    int py = (int)roundf((F.kps[i].y - F.min_y) * invH);
+    bool ok = !(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS);
+    cell[2 * i] = ok ? (int8_t)px : (int8_t)-1;
+    cell[2 * i + 1] = ok ? (int8_t)py : (int8_t)-1;
+}
+
+// Frame::ProjectLandMark + Camera::Project.  uv = (u, v, ur); returns validity.
+__device__ __forceinline__ bool project(const HsFrameDev& F, float px, float py, float pz, float& u, float& v, float& ur)
+{
+    float Pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double s = 0.0;
+        s = __dadd_rn(s, __dmul_rn((double)F.Rcw[3 * i + 0], (double)px));
+        s = __dadd_rn(s, __dmul_rn((double)F.Rcw[3 * i + 1], (double)py));
+        s = __dadd_rn(s, __dmul_rn((double)F.Rcw[3 * i + 2], (double)pz));
+        Pc[i] = (float)__dadd_rn(s, (double)F.tcw[i]);
+    }
+    const float PcZ = Pc[2];
+    const float invz = __fdiv_rn(1.0f, PcZ);
+    const float hx = __fdiv_rn(Pc[0], PcZ), hy = __fdiv_rn(Pc[1], PcZ), hz = __fdiv_rn(Pc[2], PcZ);
+    u = (float)__dadd_rn(__dadd_rn(__dmul_rn((double)F.fx, (double)hx), __dmul_rn(0.0, (double)hy)), __dmul_rn((double)F.cx, (double)hz));
+    v = (float)__dadd_rn(__dadd_rn(__dmul_rn(0.0, (double)hx), __dmul_rn((double)F.fy, (double)hy)), __dmul_rn((double)F.cy, (double)hz));
+    ur = F.sensor == 1 ? __fsub_rn(u, __fmul_rn(F.mbf, invz)) : -1.0f;
+    return PcZ > 0.0f && u >= F.min_x && u <= F.max_x && v >= F.min_y && v <= F.max_y;
+}
+
+__device__ __forceinline__ int hamming256(const unsigned long long* a, const unsigned long long* b)
+{
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// wave-wide merge of (best key, second-best distance)
+__device__ __forceinline__ void wave_best2(unsigned long long& best, int& second)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        unsigned long long ob = __shfl_xor(best, s, 64);
+        int os = __shfl_xor(second, s, 64);
+        int db = (int)(best >> 32), dob = (int)(ob >> 32);
+        int worse = max(db, dob);          // distance of whichever best loses (0x7FFFFFFF when a side is empty)
+        best = min(best, ob);
+        second = min(min(second, os), worse);
+    }
+}
+#define NO_KEY 0x7FFFFFFFFFFFFFFFull
+#define NO_DIST 0x7FFFFFFF
+
+__global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const hs_landmark* __restrict__ lms, int L, hs_proj_params pp,
+                                                           int32_t* __restrict__ match_idx, float* __restrict__ match_dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= L) return;
+    const hs_landmark& lm = lms[li];
+    int out_idx = -1; float out_dist = -1.f;
+    float u, v, ur;
+    bool ok = !lm.skip && project(F, lm.pos[0], lm.pos[1], lm.pos[2], u, v, ur);                  // ProjectionCriterion
+    if (ok && pp.use_distance) {                                                                    // DistanceCriterionCore
+        const float ox = __fsub_rn(lm.pos[0], F.Ow[0]), oy = __fsub_rn(lm.pos[1], F.Ow[1]), oz = __fsub_rn(lm.pos[2], F.Ow[2]);
+        const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
+        const float dist = (float)sqrt(n2);
+        if (dist < __fmul_rn(0.8f, lm.min_dist) || dist > __fmul_rn(1.2f, lm.max_dist)) ok = false;
+    }
+    if (ok) {
+        // landMarkSizePixels
+        float sizePx;
+        if (lm.assoc_kp >= 0) sizePx = F.kps[lm.assoc_kp].size;
+        else {
+            const float half = __fdiv_rn(lm.size, 2.0f);
+            float ul, vl, url, u2, v2, ur2;
+            project(F, __fsub_rn(lm.pos[0], half), lm.pos[1], lm.pos[2], ul, vl, url);
+            project(F, __fadd_rn(lm.pos[0], half), lm.pos[1], lm.pos[2], u2, v2, ur2);
+            sizePx = __fsub_rn(u2, ul);
+        }
+        const float r = __fdiv_rn(__fmul_rn(pp.th, sizePx), F.size_ref);
+        // GetFeaturesInAreaNEW cell range (with its early returns)
+        const float invW = (float)GRID_COLS / (F.max_x - F.min_x), invH = (float)GRID_ROWS / (F.max_y - F.min_y);
+        const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, F.min_x), r), invW)));
+        const int maxCX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, F.min_x), r), invW)));
+        const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, F.min_y), r), invH)));
+        const int maxCY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, F.min_y), r), invH)));
+        const bool any = !(minCX >= GRID_COLS || maxCX < 0 || minCY >= GRID_ROWS || maxCY < 0);
+        const float smin = __fmul_rn(pp.frac_smaller, sizePx), smax = __fmul_rn(pp.frac_larger, sizePx);
+        const bool stereo = pp.use_stereo && F.sensor != 0;
+        const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(lm.desc);
+        const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
+        unsigned long long best = NO_KEY; int second = NO_DIST;
+        if (any) {
+            for (int i = lane; i < F.n; i += 64) {
+                const int cx = F.cell[2 * i], cy = F.cell[2 * i + 1];
+                if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;           // also drops cx == -1
+                const hs_keypoint kp = F.kps[i];
+                if (!(fabsf(__fsub_rn(kp.x, u)) < r && fabsf(__fsub_rn(kp.y, v)) < r)) continue;
+                if (F.kp_lm_obs && F.kp_lm_obs[i] > 0) continue;                               // PreviouslyMatchedCriterionCore
+                if (!(kp.size > smin && kp.size < smax)) continue;                              // FeatureSizeCriterionCore
+                if (stereo) { const float urv = F.uR[i]; if (!(fabsf(__fsub_rn(ur, urv)) < r && urv > 0.f)) continue; }
+                const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F.desc + (size_t)i * 32);
+                const int d = __popcll(l0 ^ dk[0]) + __popcll(l1 ^ dk[1]) + __popcll(l2 ^ dk[2]) + __popcll(l3 ^ dk[3]);
+                const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned)i;
+                if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+                else second = min(second, d);
+            }
+        }
+        wave_best2(best, second);
+        if (best != NO_KEY) {                                                                   // BestScoreCriterion accept rule
+            const float bestDist = (float)(int)(best >> 32);
+            const float bestDist2 = second == NO_DIST ? FLT_MAX : (float)second;
+            if (bestDist <= pp.score_threshold && !(bestDist > __fmul_rn(pp.second_best_ratio, bestDist2))) {
+                out_idx = (int)(best & 0xFFFF); out_dist = bestDist;
+            }
+        }
+    }
+    if (lane == 0) { match_idx[li] = out_idx; match_dist[li] = out_dist; }
+}
+
+// RotationConsistency on a match list a[i] -> b: keep only pairs whose rotation bin is one of the three most populated.
+// DEDUPE: several entries may share the same key_idx (landmarks that matched the same keypoint); the reference collects them
+// in a std::map keyed by that index, so only the LAST entry survives, the others are dropped.
+__global__ __launch_bounds__(1024) void k_rotation_filter(int n, int32_t* __restrict__ match /*[n] key idx or -1, in/out*/,
+                                                          const float* __restrict__ angle_prev /*[n] per entry*/,
+                                                          const hs_keypoint* __restrict__ kps_curr /*indexed by match[i]*/,
+                                                          int32_t* __restrict__ winner /*[n_keys] scratch*/, int n_keys, int dedupe,
+                                                          int32_t* __restrict__ n_out)
+{
+    __shared__ int hist[30];
+    __shared__ int ind[3];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    if (tid < 30) hist[tid] = 0;
+    if (tid == 0) total = 0;
+    if (dedupe) {
+        for (int k = tid; k < n_keys; k += 1024) winner[k] = -1;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) if (match[i] >= 0) atomicMax(&winner[match[i]], i);
+    }
+    __syncthreads();
+    auto bin_of = [&](int i) {
+        float rot = __fsub_rn(angle_prev[i], kps_curr[match[i]].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int b = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+        return b == 30 ? 0 : b;
+    };
+    for (int i = tid; i < n; i += 1024) {
+        if (match[i] < 0) continue;
+        if (dedupe && winner[match[i]] != i) continue;
+        int b = bin_of(i);
+        if (b >= 0 && b < 30) atomicAdd(&hist[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {   // ComputeThreeMaxima
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < 30; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+            else if (s > max3) { max3 = s; i3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+        ind[0] = i1; ind[1] = i2; ind[2] = i3;
+    }
+    __syncthreads();
+    int kept = 0;
+    for (int i = tid; i < n; i += 1024) {
+        if (match[i] < 0) continue;
+        bool keep = !(dedupe && winner[match[i]] != i);
+        if (keep) { int b = bin_of(i); keep = (b == ind[0] || b == ind[1] || b == ind[2]); }
+        if (!keep) match[i] = -1; else kept++;
+    }
+    atomicAdd(&total, kept);
+    __syncthreads();
+    if (tid == 0) *n_out = total;
+}
+
+__global__ void k_count_matches(int n, const int32_t* __restrict__ match, int32_t* __restrict__ n_out)
+{
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c += match[i] >= 0;
+    atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *n_out = total;
+}
+
+// One workgroup per vocabulary node shared by both feature vectors; one wavefront per side-1 index, lanes over the node's side-2 list.
+__global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ pair_a, const int32_t* __restrict__ pair_b,
+                                                   const int32_t* __restrict__ ptr1, const int32_t* __restrict__ idx1,
+                                                   const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2,
+                                                   const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
+                                                   const uint8_t* __restrict__ keep1, float score_threshold, float ratio,
+                                                   int32_t* __restrict__ match12)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int a = pair_a[blockIdx.x], b = pair_b[blockIdx.x];
+    const int p0 = ptr1[a], p1 = ptr1[a + 1], q0 = ptr2[b], q1 = ptr2[b + 1];
+    for (int p = p0 + wv; p < p1; p += 4) {
+        const int i1 = idx1[p];
+        if (keep1 && !keep1[i1]) continue;                                   // PreviouslyMatchedIndexCriterion
+        const unsigned long long* d1 = reinterpret_cast<const unsigned long long*>(desc1 + (size_t)i1 * 32);
+        unsigned long long best = NO_KEY; int second = NO_DIST;
+        for (int q = q0 + lane; q < q1; q += 64) {
+            const int i2 = idx2[q];
+            const int d = hamming256(d1, reinterpret_cast<const unsigned long long*>(desc2 + (size_t)i2 * 32));
+            const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(q - q0);     // list order breaks ties
+            if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+            else second = min(second, d);
+        }
+        wave_best2(best, second);
+        if (lane == 0 && best != NO_KEY) {
+            const float bd1 = (float)(int)(best >> 32), bd2 = second == NO_DIST ? FLT_MAX : (float)second;
+            if (bd1 < score_threshold && bd1 < __fmul_rn(ratio, bd2)) match12[i1] = idx2[q0 + (int)(best & 0xFFFFFFFFu)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                              int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq) return;
+    const unsigned long long* dq = reinterpret_cast<const unsigned long long*>(q + (size_t)i * 32);
+    const unsigned long long a0 = dq[0], a1 = dq[1], a2 = dq[2], a3 = dq[3];
+    unsigned long long best = NO_KEY; int second = NO_DIST;
+    for (int j = lane; j < nt; j += 64) {
+        const unsigned long long* dt = reinterpret_cast<const unsigned long long*>(t + (size_t)j * 32);
+        const int d = __popcll(a0 ^ dt[0]) + __popcll(a1 ^ dt[1]) + __popcll(a2 ^ dt[2]) + __popcll(a3 ^ dt[3]);
+        const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)j;
+        if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+        else second = min(second, d);
+    }
+    wave_best2(best, second);
+    if (lane == 0) {
+        best_idx[i] = best == NO_KEY ? -1 : (int)(best & 0xFFFFFFFFu);
+        best_dist[i] = best == NO_KEY ? -1 : (int)(best >> 32);
+        second_dist[i] = second == NO_DIST ? -1 : second;
+    }
+}
+
+// ---------------------------------------------------------------- launchers (declared in hs_internal.h)
+void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, hipStream_t s)
+{
+    if (F.n <= 0) return;
+    HsFrameDev D{}; D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.n = F.n; D.kps = d_kps;
+    hipLaunchKernelGGL(k_frame_grid, dim3((F.n + 255) / 256), dim3(256), 0, s, D, d_cell);
+}
+
+void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const float* d_uR,
+                                 const int32_t* d_obs, const int8_t* d_cell, const hs_landmark* d_lms, int L, const hs_proj_params& pp,
+                                 int32_t* d_match_idx, float* d_match_dist, int32_t* d_winner, float* d_prev_angle_scratch,
+                                 int32_t* d_n_matches, hipStream_t s)
+{
+    HsFrameDev D{};
+    for (int i = 0; i < 9; i++) D.Rcw[i] = F.Rcw[i];
+    for (int i = 0; i < 3; i++) { D.tcw[i] = F.tcw[i]; D.Ow[i] = F.Ow[i]; }
+    D.fx = F.fx; D.fy = F.fy; D.cx = F.cx; D.cy = F.cy; D.mbf = F.mbf; D.sensor = F.sensor;
+    D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.size_ref = F.size_ref; D.n = F.n;
+    D.kps = d_kps; D.desc = d_desc; D.uR = d_uR; D.kp_lm_obs = d_obs; D.cell = d_cell;
+    hipLaunchKernelGGL(k_search_projection, dim3((L + 3) / 4), dim3(256), 0, s, D, d_lms, L, pp, d_match_idx, d_match_dist);
+    if (pp.check_rotation) {
+        // prev_angle lives inside the landmark records; the filter wants a flat float array per entry
+        hipMemcpy2DAsync(d_prev_angle_scratch, sizeof(float), reinterpret_cast<const uint8_t*>(d_lms) + offsetof(hs_landmark, prev_angle),
+                         sizeof(hs_landmark), sizeof(float), L, hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(k_rotation_filter, dim3(1), dim3(1024), 0, s, L, d_match_idx, d_prev_angle_scratch, d_kps, d_winner, F.n, 1, d_n_matches);
+    } else {
+        hipLaunchKernelGGL(k_count_matches, dim3(1), dim3(1024), 0, s, L, d_match_idx, d_n_matches);
+    }
+}
+
+__global__ void k_gather_angle(int n, const int32_t* __restrict__ match, const hs_keypoint* __restrict__ kps2, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = match[i] >= 0 ? kps2[match[i]].angle : 0.f;
+}
+__global__ void k_iota_where(int n, const int32_t* __restrict__ match, int32_t* __restrict__ self)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) self[i] = match[i] >= 0 ? i : -1;
+}
+__global__ void k_mask_by(int n, const int32_t* __restrict__ self, int32_t* __restrict__ match)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && self[i] < 0) match[i] = -1;
+}
+
+void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
+                   const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
+                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, float thr, float ratio,
+                   int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
+                   int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s)
+{
+    hipMemsetAsync(d_match12, 0xFF, (size_t)n1 * 4, s);
+    if (n_pairs > 0)
+        hipLaunchKernelGGL(k_bow_match, dim3(n_pairs), dim3(256), 0, s, d_pair_a, d_pair_b, d_ptr1, d_idx1, d_ptr2, d_idx2, d_desc1, d_desc2,
+                           d_keep1, thr, ratio, d_match12);
+    if (check_rotation && n1 > 0) {
+        // RotationConsistencyBoW::apply(matches, views1, views2): rot = angle2[match] - angle1[i]; entries are keyed by side-1 index (unique)
+        const int g = (n1 + 255) / 256;
+        hipLaunchKernelGGL(k_gather_angle, dim3(g), dim3(256), 0, s, n1, d_match12, d_kps2, d_angle2_scratch);
+        hipLaunchKernelGGL(k_iota_where, dim3(g), dim3(256), 0, s, n1, d_match12, d_self_scratch);
+        hipLaunchKernelGGL(k_rotation_filter, dim3(1), dim3(1024), 0, s, n1, d_self_scratch, d_angle2_scratch, d_kps1, (int32_t*)nullptr, 0, 0, d_n_matches);
+        hipLaunchKernelGGL(k_mask_by, dim3(g), dim3(256), 0, s, n1, d_self_scratch, d_match12);
+    } else {
+        hipLaunchKernelGGL(k_count_matches, dim3(1), dim3(1024), 0, s, n1, d_match12, d_n_matches);
+    }
+}
+
+void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, d_q, nq, d_t, nt, d_bi, d_bd, d_sd);
+}

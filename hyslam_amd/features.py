@@ -220,6 +220,65 @@ class Stereomatcher:
         return self.mvuRight, self.mvDepth
 
 
+class FeatureMatcher:
+    """HYSLAM::FeatureMatcher (src/features/FeatureMatcher.h:105-176) on flat arrays.  `frame` is a _native.FrameView,
+    `landmarks` a numpy array of _native.LM_DTYPE (one record per MapPoint, in the order the reference would iterate them)."""
+
+    def __init__(self, settings=None, extractor=None):
+        s = settings or FeatureMatcherSettings()
+        self.mfNNratio, self.mbCheckOrientation, self.TH_LOW, self.TH_HIGH = s.nnratio, s.checkOri, s.TH_LOW, s.TH_HIGH
+        self._ex = extractor or ORBExtractor()
+
+    def _project(self, frame, landmarks, pp):
+        ex = self._ex
+        lms = np.ascontiguousarray(landmarks, N.LM_DTYPE)
+        L = len(lms)
+        midx = np.full(L, -1, np.int32)
+        mdist = np.full(L, -1, np.float32)
+        n = C.c_int32()
+        N.check(ex._h, ex._lib.hs_search_by_projection(ex._h, C.byref(frame), lms.ctypes.data_as(C.c_void_p), L, C.byref(pp),
+                                                       midx.ctypes.data_as(C.c_void_p), mdist.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return midx, mdist, n.value
+
+    def SearchByProjection(self, frame, landmarks, th=3.0):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th) — track the local map (FeatureMatcher.cc:123-143)."""
+        return self._project(frame, landmarks, N.ProjParams(th, self.TH_HIGH, self.mfNNratio, 0.5, 1.5, 1, 1, 0))
+
+    def SearchByProjectionLastFrame(self, frame, landmarks, th):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (FeatureMatcher.cc:145-176): landmarks = LastFrame's map points,
+        prev_angle = angle of each one's keypoint in LastFrame."""
+        return self._project(frame, landmarks, N.ProjParams(th, self.TH_HIGH, self.mfNNratio, 0.5, 1.5, 0, 1, 1))
+
+    def SearchByProjectionKeyFrame(self, frame, landmarks, th, ORBdist):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) — relocalisation (FeatureMatcher.cc:180-212);
+        landmarks = pKF's map points minus sAlreadyFound.  Its rotation criterion is a no-op in the reference (no previous frame)."""
+        return self._project(frame, landmarks, N.ProjParams(th, float(ORBdist), 1.0, 0.5, 1.5, 1, 0, 0))
+
+    def SearchByBoW(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, check_rotation=True):
+        """The matching core of SearchByBoW / SearchByBoW2 (FeatureMatcher.cc:216-371).  featvec = (node_id, node_ptr, idx) CSR arrays."""
+        ex = self._ex
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in featvec1]
+        b = [np.ascontiguousarray(x, np.int32) for x in featvec2]
+        keep = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+        m = np.full(len(k1), -1, np.int32)
+        n = C.c_int32()
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_by_bow(ex._h, p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                                p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                                None if keep is None else p(keep), self.TH_LOW, self.mfNNratio, int(check_rotation), p(m), C.byref(n)))
+        return m, n.value
+
+    def HammingKnn2(self, query, train):
+        ex = self._ex
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        bi, bd, sd = (np.zeros(len(q), np.int32) for _ in range(3))
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_hamming_knn2(ex._h, p(q), len(q), p(t), len(t), p(bi), p(bd), p(sd)))
+        return bi, bd, sd
+
+
 class ORBFactory:
     """HYSLAM::ORBFactory: hands out extractors and matcher settings (FeatureFactory.h:21-33, ORBFactory.cpp:13-45)."""
 
@@ -230,6 +289,9 @@ class ORBFactory:
 
     def getExtractor(self, settings=None):
         return ORBExtractor(settings or self.extractor_settings, self.device)
+
+    def getFeatureMatcher(self, extractor=None):
+        return FeatureMatcher(self.matcher_settings, extractor)
 
     def getFeatureExtractorSettings(self):
         return self.extractor_settings

@@ -127,6 +127,76 @@ int  hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uin
 /* block until everything enqueued on the handle's own stream (or `stream`) has finished */
 int  hs_orb_synchronize(hs_orb* h, void* stream);
 
+/* ================= matchers on flat arrays: the cores of HYSLAM::FeatureMatcher (src/features/FeatureMatcher.h:105-176) =================
+ * The C++ adaptor gathers Frame / KeyFrame / MapPoint fields into these arrays and replays associations
+ * (Frame::associateLandMark) from the returned per-landmark results, in the reference's order.  Containers the
+ * reference orders by MapPoint* address are replaced by landmark ARRAY ORDER (pass landmarks sorted by address to
+ * reproduce its iteration order).  Host pointers; synchronous. */
+
+/* what _SearchByProjection_ reads from Frame / Camera / FeatureViews / LandMarkMatches
+ * (src/core/Frame.cc:45-72,137-180,416-469; src/core/Camera.cpp:116-153) */
+typedef struct hs_frame_view {
+    float Rcw[9], tcw[3], Ow[3];       /* mRcw (row-major), mtcw, mOw                                  */
+    float fx, fy, cx, cy, mbf;         /* K, Camera::mbf                                                */
+    int32_t sensor;                    /* Camera::sensor: 0 mono, 1 stereo, 2 RGBD                      */
+    float min_x, max_x, min_y, max_y;  /* mnMinX .. mnMaxY                                              */
+    float size_ref;                    /* views.orbParams().size_ref (31)                               */
+    int32_t n;                         /* number of keypoints                                           */
+    const hs_keypoint* kps;            /* [n]                                                           */
+    const uint8_t* desc;               /* [n][32]                                                       */
+    const float* uR;                   /* [n], < 0 = no stereo correspondence                           */
+    const int32_t* kp_lm_obs;          /* [n]: -1 = keypoint has no landmark, else Observations() of it */
+} hs_frame_view;
+
+/* the MapPoint fields the matchers read (src/core/MapPoint.h:54-169) */
+typedef struct hs_landmark {
+    float pos[3];                      /* GetWorldPos()                                                 */
+    float size;                        /* getSize(), world units                                        */
+    float min_dist, max_dist;          /* mfMinDistance, mfMaxDistance (before the 0.8 / 1.2 factors, MapPoint.cc:139-149) */
+    float normal[3];                   /* GetNormal()                                                   */
+    int32_t assoc_kp;                  /* Frame::hasAssociation(lm) in THIS frame, -1 if none (Frame.cc:296-300) */
+    float prev_angle;                  /* angle of its keypoint in the previous frame (rotation check)  */
+    int32_t skip;                      /* 1 = nullptr entry                                             */
+    uint8_t desc[32];                  /* GetDescriptor()                                               */
+} hs_landmark;
+
+typedef struct hs_proj_params {
+    float th;                          /* search radius factor                                          */
+    float score_threshold;             /* BestScoreCriterion threshold: TH_HIGH or ORBdist              */
+    float second_best_ratio;           /* mfNNratio or 1.0                                              */
+    float frac_smaller, frac_larger;   /* FeatureSizeCriterion(0.5, 1.5)                                */
+    int32_t use_distance;              /* DistanceCriterion among the landmark criteria                 */
+    int32_t use_stereo;                /* StereoConsistencyCriterion(th)                                */
+    int32_t check_rotation;            /* RotationConsistencyCriterion (uses prev_angle)                */
+} hs_proj_params;
+
+/* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria of SearchByProjection(Frame, MapPoints, th)
+ * (:123-143: use_distance=1,use_stereo=1,check_rotation=0), (CurrentFrame, LastFrame, th, bMono) (:145-176: 0,1,1) and
+ * (CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:180-212: 1,0,0, ratio 1.0).  match_idx[L] = keypoint index or -1,
+ * match_dist[L] = Hamming distance of the match, *n_matches = matches.size(). */
+int  hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
+                             int32_t* match_idx, float* match_dist, int32_t* n_matches);
+
+/* the inner loops of SearchByBoW / SearchByBoW2 / _SearchByBoW_ (FeatureMatcher.cc:216-371): for every vocabulary node present in
+ * both feature vectors, best / second-best Hamming of each side-1 index over the node's side-2 indices (BestMatchBoWCriterion,
+ * MatchCriteria.cpp:601-635: d < threshold and d < ratio*d2, both strict), then RotationConsistencyBoW (:679-726).
+ * Feature vectors (DBoW2::FeatureVector) as CSR: node ids ascending, node_ptr[n_nodes+1], idx[].  keep1[n1] (may be NULL) = 1 for
+ * side-1 indices that pass the index criteria (PreviouslyMatchedIndexCriterion).  match12[n1] = side-2 index or -1. */
+int  hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                      const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int n_nodes1,
+                      const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                      const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int n_nodes2,
+                      const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation,
+                      int32_t* match12, int32_t* n_matches);
+
+/* brute-force Hamming 2-NN (cross-camera matching without a vocabulary): for each of nq query descriptors the first-minimum
+ * train index, its distance and the second-smallest distance (-1 when absent). */
+int  hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                     int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* same on device pointers, asynchronous */
+int  hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                            int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
+
 /* ---- per-stage device timing (HIP events recorded on the stream the kernels run on) ----
  * Stages: 0 pyramid, 1 FAST+NMS cells, 2 quadtree distribution, 3 blur+orient+rBRIEF, 4 stereo match, 5 stereo median.
  * begin: start collecting (events are recorded around every stage of every later call on this handle);

@@ -124,3 +124,73 @@ int hso_stereo_frontend(const hso_orb_params* p, const hso_stereo_params* sp,
 }
 #endif
 #endif
+
+/* ======================================================================================================
+ * Matchers on flat arrays (restated in oracle/hs_oracle_match.cpp).  Same status: test infrastructure,
+ * parity unpinned.  The structs are the gather of what the reference reads from Frame / KeyFrame / Camera /
+ * FeatureViews / MapPoint / LandMarkMatches; pointer-ordered containers (std::map<MapPoint*,...>) are replaced
+ * by landmark ARRAY ORDER (documented deviation D6: the adaptor passes landmarks sorted by address to
+ * reproduce the reference's iteration order).
+ * ====================================================================================================== */
+#ifndef HS_ORACLE_MATCH_DECLS
+#define HS_ORACLE_MATCH_DECLS
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hso_frame_view {        /* Frame.cc:45-72,137-180,416-469; Camera.cpp:116-153 */
+    float Rcw[9], tcw[3], Ow[3];       /* mRcw (row-major), mtcw, mOw */
+    float fx, fy, cx, cy, mbf;
+    int32_t sensor;                    /* Camera::sensor: 0 mono, 1 stereo, 2 RGBD */
+    float min_x, max_x, min_y, max_y;  /* mnMinX.. */
+    float size_ref;                    /* FeatureExtractorSettings::size_ref of the views (31) */
+    int32_t n;                         /* number of keypoints */
+    const hso_keypoint* kps;
+    const uint8_t* desc;               /* n x 32 */
+    const float* uR;                   /* n, <0 = no stereo correspondence */
+    const int32_t* kp_lm_obs;          /* n: -1 = keypoint has no landmark, else Observations() of the associated landmark */
+} hso_frame_view;
+
+typedef struct hso_landmark {          /* MapPoint.h:54-169 fields the matchers read */
+    float pos[3];                      /* GetWorldPos() */
+    float size;                        /* getSize(), world units */
+    float min_dist, max_dist;          /* mfMinDistance, mfMaxDistance (before the 0.8 / 1.2 factors) */
+    float normal[3];                   /* GetNormal() */
+    int32_t assoc_kp;                  /* Frame::hasAssociation(lm) in THIS frame, -1 if none */
+    float prev_angle;                  /* angle of the keypoint it is associated with in the previous frame (rotation check) */
+    int32_t skip;                      /* 1 = nullptr entry in the reference's vector */
+    uint8_t desc[32];                  /* GetDescriptor() */
+} hso_landmark;
+
+typedef struct hso_proj_params {
+    float th;                          /* search radius factor */
+    float score_threshold;             /* BestScoreCriterion: TH_HIGH or ORBdist */
+    float second_best_ratio;           /* mfNNratio or 1.0 */
+    float frac_smaller, frac_larger;   /* FeatureSizeCriterion(0.5, 1.5) */
+    int32_t use_distance;              /* DistanceCriterion in the landmark criteria */
+    int32_t use_stereo;                /* StereoConsistencyCriterion(th) */
+    int32_t check_rotation;            /* RotationConsistencyCriterion (needs prev_angle) */
+} hso_proj_params;
+
+/* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria lists of the three Frame variants
+ * (:123-143, :145-176, :180-212).  match_idx[L] = keypoint index or -1, match_dist[L].  Returns matches.size(). */
+int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, int L, const hso_proj_params* pp,
+                             int32_t* match_idx, float* match_dist);
+/* Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:137-153,459-469): cell_xy[2*i] = column or -1 (outside), cell_xy[2*i+1] = row */
+void hso_frame_grid(const hso_frame_view* F, int32_t* cell_xy);
+/* the inner loops of SearchByBoW / _SearchByBoW_ (FeatureMatcher.cc:216-345) + BestMatchBoWCriterion (MatchCriteria.cpp:601-635)
+ * + RotationConsistencyBoW (:679-726).  Feature vectors are CSR: node ids ascending, node_ptr[n_nodes+1], idx[].
+ * keep1[n1] = 1 for indices of side 1 that pass the index criteria.  match12[n1] = index in side 2 or -1.  Returns #matches. */
+int hso_search_by_bow(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                      const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                      const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12);
+/* brute-force Hamming 2-NN of every query against every train descriptor: best index, best and second-best distance
+ * (first minimum wins, like every best/second-best loop of the reference, e.g. MatchCriteria.cpp:248-280) */
+void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* RotationConsistency (MatchCriteria.cpp:684-726) + ComputeThreeMaxima (:727-767): keep[i] = 1 if pair i survives */
+void hso_rotation_consistency(const float* angle_a, const float* angle_b, int n, uint8_t* keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

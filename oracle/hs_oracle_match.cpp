@@ -1,0 +1,306 @@
+/* hs_oracle_match.cpp — CPU ORACLE, matcher half (test infrastructure; parity unpinned, see hs_oracle.h).
+ *
+ * Restates on flat arrays:
+ *   FeatureMatcher::_SearchByProjection_ + wrappers    /root/reference/src/features/FeatureMatcher.cc:57-212
+ *   the criteria classes                               /root/reference/src/features/MatchCriteria.cpp
+ *   Frame grid / projection / landMarkSizePixels       /root/reference/src/core/Frame.cc:137-180,296-317,416-469
+ *   Camera::Project                                    /root/reference/src/core/Camera.cpp:116-153
+ *   MapPoint distance invariance                       /root/reference/src/core/MapPoint.cc:139-149
+ *   SearchByBoW / _SearchByBoW_ inner loops            /root/reference/src/features/FeatureMatcher.cc:216-345
+ * cv::Mat products (mRcw*P+mtcw, K*Pch) are OpenCV gemm calls: float inputs, double accumulation, one rounding to float
+ * (GEMMSingleMul<float,double>); restated as such.
+ */
+#include "hs_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <vector>
+
+namespace {
+
+const int FRAME_GRID_COLS = 64, FRAME_GRID_ROWS = 48;   // Frame.h
+
+float ORBDistance(const uint8_t* D1, const uint8_t* D2)   // DescriptorDistance.cpp:9-25
+{
+    int32_t pa[8], pb[8];
+    std::memcpy(pa, D1, 32); std::memcpy(pb, D2, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned int v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return static_cast<float>(dist);
+}
+
+struct Frame {
+    const hso_frame_view& V;
+    float mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+
+    explicit Frame(const hso_frame_view& v) : V(v) {
+        mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (V.max_x - V.min_x);     // Frame.cc:66-67
+        mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (V.max_y - V.min_y);
+        for (int i = 0; i < V.n; i++) {                                                          // AssignFeaturesToGrid :137-153
+            int x, y;
+            if (PosInGrid(V.kps[i], x, y)) mGrid[x][y].push_back(i);
+        }
+    }
+    bool PosInGrid(const hso_keypoint& kp, int& posX, int& posY) const {                         // :459-469
+        posX = (int)std::round((kp.x - V.min_x) * mfGridElementWidthInv);
+        posY = (int)std::round((kp.y - V.min_y) * mfGridElementHeightInv);
+        if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) return false;
+        return true;
+    }
+    // Frame::ProjectLandMark(cv::Mat P, uv_ur) :170-180 + Camera::Project (Camera.cpp:116-153)
+    bool ProjectLandMark(const float P[3], float uv[3]) const {
+        float Pc[3];
+        for (int i = 0; i < 3; i++) {   // Pc = mRcw*P + mtcw : one gemm, double accumulation
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)V.Rcw[3 * i + k] * (double)P[k];
+            Pc[i] = (float)(s + (double)V.tcw[i]);
+        }
+        float PcZ = Pc[2];
+        float invz = 1.0f / PcZ;
+        float Pch[3] = { Pc[0] / PcZ, Pc[1] / PcZ, Pc[2] / PcZ };
+        // uv = K*Pch, K = [fx 0 cx; 0 fy cy; 0 0 1]
+        float u = (float)((double)V.fx * (double)Pch[0] + 0.0 * (double)Pch[1] + (double)V.cx * (double)Pch[2]);
+        float v = (float)(0.0 * (double)Pch[0] + (double)V.fy * (double)Pch[1] + (double)V.cy * (double)Pch[2]);
+        uv[0] = u; uv[1] = v;
+        if (V.sensor == 1) uv[2] = u - V.mbf * invz; else uv[2] = -1.0f;
+        bool valid = false;
+        if (PcZ > 0.0f) if (u >= V.min_x && u <= V.max_x) if (v >= V.min_y && v <= V.max_y) valid = true;
+        return valid;
+    }
+    // Frame::landMarkSizePixels :296-317
+    float landMarkSizePixels(const hso_landmark& lm) const {
+        if (lm.assoc_kp >= 0) return V.kps[lm.assoc_kp].size;
+        float left[3] = { lm.pos[0] - lm.size / 2, lm.pos[1], lm.pos[2] };
+        float right[3] = { lm.pos[0] + lm.size / 2, lm.pos[1], lm.pos[2] };
+        float uvl[3], uvr[3];
+        ProjectLandMark(left, uvl);
+        ProjectLandMark(right, uvr);
+        return uvr[0] - uvl[0];
+    }
+    // Frame::GetFeaturesInAreaNEW :416-457
+    std::vector<size_t> GetFeaturesInAreaNEW(float x, float y, float r) const {
+        std::vector<size_t> vIndices;
+        const int nMinCellX = std::max(0, (int)std::floor((x - V.min_x - r) * mfGridElementWidthInv));
+        if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+        const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)std::ceil((x - V.min_x + r) * mfGridElementWidthInv));
+        if (nMaxCellX < 0) return vIndices;
+        const int nMinCellY = std::max(0, (int)std::floor((y - V.min_y - r) * mfGridElementHeightInv));
+        if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+        const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)std::ceil((y - V.min_y + r) * mfGridElementHeightInv));
+        if (nMaxCellY < 0) return vIndices;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<size_t>& vCell = mGrid[ix][iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const hso_keypoint& kpUn = V.kps[vCell[j]];
+                    const float distx = kpUn.x - x, disty = kpUn.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+                }
+            }
+        return vIndices;
+    }
+};
+
+struct SingleMatchData { int idx; float distance; float distance_2ndbest; };
+
+// ComputeThreeMaxima, MatchCriteria.cpp:727-767
+void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// RotationConsistency, MatchCriteria.cpp:684-726; matches: idx_curr -> idx_prev; angle lookups through callbacks
+typedef std::map<size_t, size_t> MatchesIdx;
+template <class AC, class AP>
+MatchesIdx RotationConsistency(const MatchesIdx& current_matches, AC angle_curr, AP angle_prev)
+{
+    const int HISTO_LENGTH = 30;
+    MatchesIdx matches_passed = current_matches;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (auto it = current_matches.begin(); it != current_matches.end(); ++it) {
+        size_t idx_curr = it->first, idx_prev = it->second;
+        float rot = angle_prev(idx_prev) - angle_curr(idx_curr);
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back((int)idx_curr);
+    }
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+        if (i != ind1 && i != ind2 && i != ind3)
+            for (size_t j = 0; j < rotHist[i].size(); j++) matches_passed.erase(rotHist[i][j]);
+    return matches_passed;
+}
+
+} // namespace
+
+extern "C" {
+
+void hso_frame_grid(const hso_frame_view* F, int32_t* cell_xy)
+{
+    Frame fr(*F);
+    for (int i = 0; i < F->n; i++) {
+        int x, y;
+        if (fr.PosInGrid(F->kps[i], x, y)) { cell_xy[2 * i] = x; cell_xy[2 * i + 1] = y; }
+        else { cell_xy[2 * i] = -1; cell_xy[2 * i + 1] = -1; }
+    }
+}
+
+int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, int L, const hso_proj_params* pp,
+                             int32_t* match_idx, float* match_dist)
+{
+    Frame frame(*F);
+    for (int i = 0; i < L; i++) { match_idx[i] = -1; match_dist[i] = -1.f; }
+    // ---- landmark criteria (FeatureMatcher.cc:71-74): ProjectionCriterion, then DistanceCriterion
+    std::vector<int> cand_lms;
+    for (int i = 0; i < L; i++) {
+        if (lms[i].skip) continue;
+        float uv[3];
+        if (frame.ProjectLandMark(lms[i].pos, uv)) cand_lms.push_back(i);            // MatchCriteria.cpp:13-28
+    }
+    if (pp->use_distance) {                                                          // DistanceCriterionCore :58-78
+        std::vector<int> passed;
+        for (int i : cand_lms) {
+            const hso_landmark& lm = lms[i];
+            float PO[3] = { lm.pos[0] - F->Ow[0], lm.pos[1] - F->Ow[1], lm.pos[2] - F->Ow[2] };
+            const float lm_dist = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);   // cv::norm: double accumulation
+            const float maxDistance = 1.2f * lm.max_dist, minDistance = 0.8f * lm.min_dist;                                   // MapPoint.cc:139-149
+            if (lm_dist < minDistance || lm_dist > maxDistance) continue;
+            passed.push_back(i);
+        }
+        cand_lms.swap(passed);
+    }
+    // ---- per landmark: candidate views and view criteria (:77-103)
+    std::map<int, SingleMatchData> matches;   // key: landmark array index (stands in for MapPoint*; D6)
+    for (int li : cand_lms) {
+        const hso_landmark& lm = lms[li];
+        float uv[3];
+        frame.ProjectLandMark(lm.pos, uv);
+        const float u = uv[0], v = uv[1], ur = uv[2];
+        const float sizePx = frame.landMarkSizePixels(lm);
+        const float radius = pp->th * sizePx / F->size_ref;
+        std::vector<size_t> cand = frame.GetFeaturesInAreaNEW(u, v, radius);
+        {   // PreviouslyMatchedCriterionCore :124-144
+            std::vector<size_t> passed;
+            for (size_t idx : cand) { bool save = true; if (F->kp_lm_obs && F->kp_lm_obs[idx] >= 0 && F->kp_lm_obs[idx] > 0) save = false; if (save) passed.push_back(idx); }
+            cand.swap(passed);
+        }
+        {   // FeatureSizeCriterionCore :350-360
+            std::vector<size_t> passed;
+            for (size_t idx : cand) { const hso_keypoint& kp = F->kps[idx]; if (kp.size > pp->frac_smaller * sizePx && kp.size < pp->frac_larger * sizePx) passed.push_back(idx); }
+            cand.swap(passed);
+        }
+        if (pp->use_stereo && F->sensor != 0) {   // StereoConsistencyCriterion :149-177
+            std::vector<size_t> passed;
+            const float radius2 = pp->th * sizePx / F->size_ref;
+            for (size_t idx : cand) { float ur_view = F->uR[idx]; const float er = std::fabs(ur - ur_view); if (er < radius2 && ur_view > 0) passed.push_back(idx); }
+            cand.swap(passed);
+        }
+        // BestScoreCriterionCore :248-280 + accept rule :214-230
+        float bestDist = std::numeric_limits<float>::max(), bestDist2 = std::numeric_limits<float>::max();
+        int bestIdx = -1;
+        for (size_t idx : cand) {
+            const float d = ORBDistance(lm.desc, F->desc + idx * 32);
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx = (int)idx; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= pp->score_threshold) {
+            if (bestDist > pp->second_best_ratio * bestDist2) { }
+            else matches[li] = SingleMatchData{ bestIdx, bestDist, bestDist2 };
+        }
+    }
+    // ---- global criteria: RotationConsistencyCriterion :363-401
+    if (pp->check_rotation) {
+        MatchesIdx current_matches_idx; std::map<size_t, int> inverse;
+        for (auto& m : matches) { current_matches_idx[m.second.idx] = (size_t)m.first; inverse[m.second.idx] = m.first; }   // later landmark overwrites
+        MatchesIdx passed = RotationConsistency(current_matches_idx,
+                                                [&](size_t idx_curr) { return F->kps[idx_curr].angle; },
+                                                [&](size_t li) { return lms[li].prev_angle; });
+        std::map<int, SingleMatchData> alt;
+        for (auto& p : passed) { int li = inverse[p.first]; alt[li] = matches[li]; }
+        matches.swap(alt);
+    }
+    for (auto& m : matches) { match_idx[m.first] = m.second.idx; match_dist[m.first] = m.second.distance; }
+    return (int)matches.size();
+}
+
+int hso_search_by_bow(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                      const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                      const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12)
+{
+    (void)n2;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    MatchesIdx matches_internal;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {                                   // merge-walk of the two feature vectors, FeatureMatcher.cc:230-265
+        if (node_id1[a] == node_id2[b]) {
+            for (int p = node_ptr1[a]; p < node_ptr1[a + 1]; p++) {
+                const int i1 = idx1[p];
+                if (keep1 && !keep1[i1]) continue;                  // PreviouslyMatchedIndexCriterion, MatchCriteria.cpp:555-574
+                float bestDist1 = std::numeric_limits<float>::max(), bestDist2 = std::numeric_limits<float>::max();
+                int bestIdx2 = -1;
+                for (int q = node_ptr2[b]; q < node_ptr2[b + 1]; q++) {   // BestMatchBoWCriterion :601-635
+                    const int i2 = idx2[q];
+                    const float dist = ORBDistance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < score_threshold)
+                    if (static_cast<float>(bestDist1) < second_best_ratio * static_cast<float>(bestDist2))
+                        matches_internal.insert(std::make_pair((size_t)i1, (size_t)bestIdx2));
+            }
+            a++; b++;
+        } else if (node_id1[a] < node_id2[b]) { while (a < nn1 && node_id1[a] < node_id2[b]) a++; }   // lower_bound
+        else { while (b < nn2 && node_id2[b] < node_id1[a]) b++; }
+    }
+    if (check_rotation)   // RotationConsistencyBoW::apply(matches, views1, views2): "curr" = side 1, "prev" = side 2
+        matches_internal = RotationConsistency(matches_internal, [&](size_t i) { return kps1[i].angle; }, [&](size_t i) { return kps2[i].angle; });
+    for (auto& m : matches_internal) match12[m.first] = (int32_t)m.second;
+    return (int)matches_internal.size();
+}
+
+void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    for (int i = 0; i < nq; i++) {
+        float b1 = std::numeric_limits<float>::max(), b2 = std::numeric_limits<float>::max();
+        int bi = -1;
+        for (int j = 0; j < nt; j++) {
+            const float d = ORBDistance(q + (size_t)i * 32, t + (size_t)j * 32);
+            if (d < b1) { b2 = b1; b1 = d; bi = j; }
+            else if (d < b2) b2 = d;
+        }
+        best_idx[i] = bi;
+        best_dist[i] = bi >= 0 ? (int)b1 : -1;
+        second_dist[i] = b2 == std::numeric_limits<float>::max() ? -1 : (int)b2;
+    }
+}
+
+void hso_rotation_consistency(const float* angle_a, const float* angle_b, int n, uint8_t* keep)
+{
+    MatchesIdx m;
+    for (int i = 0; i < n; i++) m[i] = i;
+    MatchesIdx p = RotationConsistency(m, [&](size_t i) { return angle_a[i]; }, [&](size_t i) { return angle_b[i]; });
+    for (int i = 0; i < n; i++) keep[i] = p.count(i) ? 1 : 0;
+}
+
+} // extern "C"

@@ -231,3 +231,90 @@ def stereo_frontend(p, sp, imgL, imgR, cap=None):
                               kR.ctypes.data_as(C.c_void_p), dR.ctypes.data_as(C.c_void_p), C.byref(nR), cap,
                               uR.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p))
     return kL[:nL.value], dL[:nL.value], kR[:nR.value], dR[:nR.value], uR[:nL.value], depth[:nL.value]
+
+
+# ---------------------------------------------------------------- matchers (oracle/hs_oracle_match.cpp)
+LM_DTYPE = np.dtype([("pos", "<f4", 3), ("size", "<f4"), ("min_dist", "<f4"), ("max_dist", "<f4"), ("normal", "<f4", 3),
+                     ("assoc_kp", "<i4"), ("prev_angle", "<f4"), ("skip", "<i4"), ("desc", "u1", 32)])
+assert LM_DTYPE.itemsize == 80
+
+
+class FrameView(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float),
+                ("sensor", C.c_int32), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("size_ref", C.c_float), ("n", C.c_int32),
+                ("kps", C.c_void_p), ("desc", C.c_void_p), ("uR", C.c_void_p), ("kp_lm_obs", C.c_void_p)]
+
+
+class ProjParams(C.Structure):
+    _fields_ = [("th", C.c_float), ("score_threshold", C.c_float), ("second_best_ratio", C.c_float),
+                ("frac_smaller", C.c_float), ("frac_larger", C.c_float),
+                ("use_distance", C.c_int32), ("use_stereo", C.c_int32), ("check_rotation", C.c_int32)]
+
+
+def make_frame_view(cls, Rcw, tcw, fx, fy, cx, cy, mbf, sensor, bounds, kps, desc, uR=None, kp_lm_obs=None, size_ref=31.0):
+    """Builds a FrameView-like ctypes struct of class `cls`; returns (struct, keepalive list)."""
+    Rcw = np.asarray(Rcw, np.float32).reshape(3, 3)
+    tcw = np.asarray(tcw, np.float32).reshape(3)
+    Ow = (-(Rcw.T.astype(np.float32) @ tcw)).astype(np.float32)          # mOw = -mRcw.t()*mtcw (Frame.cc:160-166)
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    keep = [kps, desc]
+    F = cls()
+    F.Rcw[:] = Rcw.ravel().tolist(); F.tcw[:] = tcw.tolist(); F.Ow[:] = Ow.tolist()
+    F.fx, F.fy, F.cx, F.cy, F.mbf, F.sensor = fx, fy, cx, cy, mbf, sensor
+    F.min_x, F.max_x, F.min_y, F.max_y = bounds
+    F.size_ref, F.n = size_ref, len(kps)
+    F.kps, F.desc = kps.ctypes.data, desc.ctypes.data
+    if uR is not None:
+        uR = np.ascontiguousarray(uR, np.float32); keep.append(uR); F.uR = uR.ctypes.data
+    if kp_lm_obs is not None:
+        o = np.ascontiguousarray(kp_lm_obs, np.int32); keep.append(o); F.kp_lm_obs = o.ctypes.data
+    return F, keep
+
+
+def search_by_projection(F, lms, pp):
+    lms = np.ascontiguousarray(lms, LM_DTYPE)
+    L = len(lms)
+    midx = np.full(L, -1, np.int32)
+    mdist = np.full(L, -1, np.float32)
+    n = lib().hso_search_by_projection(C.byref(F), lms.ctypes.data_as(C.c_void_p), L, C.byref(pp),
+                                       midx.ctypes.data_as(C.c_void_p), mdist.ctypes.data_as(C.c_void_p))
+    return midx, mdist, n
+
+
+def frame_grid(F):
+    out = np.zeros((F.n, 2), np.int32)
+    lib().hso_frame_grid(C.byref(F), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, thr, ratio, check_rotation):
+    """fv = (node_id, node_ptr, idx) int32 arrays (CSR feature vector)."""
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    a = [np.ascontiguousarray(x, np.int32) for x in fv1]
+    b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+    keep = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+    m = np.full(len(k1), -1, np.int32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    n = lib().hso_search_by_bow(p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                None if keep is None else p(keep), C.c_float(thr), C.c_float(ratio), int(check_rotation), p(m))
+    return m, n
+
+
+def hamming_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    bi, bd, sd = (np.zeros(len(q), np.int32) for _ in range(3))
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().hso_hamming_knn2(p(q), len(q), p(t), len(t), p(bi), p(bd), p(sd))
+    return bi, bd, sd
+
+
+def rotation_consistency(angle_a, angle_b):
+    a = np.ascontiguousarray(angle_a, np.float32); b = np.ascontiguousarray(angle_b, np.float32)
+    keep = np.zeros(len(a), np.uint8)
+    lib().hso_rotation_consistency(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(a), keep.ctypes.data_as(C.c_void_p))
+    return keep.astype(bool)

@@ -1,0 +1,103 @@
+"""GPU parity of the FeatureMatcher cores (projection search, BoW-grouped search, brute-force 2-NN) against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+import scenes
+import hyslam_amd as HS
+from hyslam_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher(gpu):
+    return HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=0.8), HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500)))
+
+
+def both_views(sc):
+    Fo, k1 = oracle.make_frame_view(oracle.FrameView, **sc["frame_args"])
+    Fg, k2 = oracle.make_frame_view(N.FrameView, **sc["frame_args"])
+    return Fo, Fg, (k1, k2)
+
+
+@pytest.mark.parametrize("sensor", [1, 0])
+def test_projection_variants_small(matcher, sensor):
+    sc = scenes.projection_scene(31, 640, 480, nfeat=1000, copies=3, sensor=sensor)
+    Fo, Fg, keep = both_views(sc)
+    lms = sc["lms"]
+    for name, call, pp in (
+        ("local map", lambda: matcher.SearchByProjection(Fg, lms, 5.0), oracle.ProjParams(5.0, 100.0, 0.8, 0.5, 1.5, 1, 1, 0)),
+        ("last frame", lambda: matcher.SearchByProjectionLastFrame(Fg, lms, 7.0), oracle.ProjParams(7.0, 100.0, 0.8, 0.5, 1.5, 0, 1, 1)),
+        ("keyframe", lambda: matcher.SearchByProjectionKeyFrame(Fg, lms, 4.0, 70), oracle.ProjParams(4.0, 70.0, 1.0, 0.5, 1.5, 1, 0, 0)),
+    ):
+        gi, gd, gn = call()
+        oi, od, on = oracle.search_by_projection(Fo, lms, pp)
+        assert on > 100, name
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od) and gn == on, name
+
+
+def test_c4_projection_50k_landmarks_1080p(matcher):
+    """BASELINE config 4 shape: one 1920x1080 / 2000-feature frame against a 50 000-point local map, th = 5, nnratio 0.8."""
+    sc = scenes.projection_scene(33, 1920, 1080, nfeat=2000, copies=25, fx=1050.0)
+    assert len(sc["lms"]) > 50000
+    Fo, Fg, keep = both_views(sc)
+    gi, gd, gn = matcher.SearchByProjection(Fg, sc["lms"], 5.0)
+    oi, od, on = oracle.search_by_projection(Fo, sc["lms"], oracle.ProjParams(5.0, 100.0, 0.8, 0.5, 1.5, 1, 1, 0))
+    assert on > 5000 and gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
+    gi, gd, gn = matcher.SearchByProjectionLastFrame(Fg, sc["lms"], 5.0)
+    oi, od, on = oracle.search_by_projection(Fo, sc["lms"], oracle.ProjParams(5.0, 100.0, 0.8, 0.5, 1.5, 0, 1, 1))
+    assert gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+def test_projection_edge_cases(matcher):
+    sc = scenes.projection_scene(35, 320, 240, nfeat=300, copies=1, fx=260.0)
+    Fo, Fg, keep = both_views(sc)
+    gi, gd, gn = matcher.SearchByProjection(Fg, sc["lms"][:0], 5.0)          # no landmarks
+    assert len(gi) == 0 and gn == 0
+    lms = sc["lms"].copy()
+    lms["skip"] = 1                                                            # all nullptr
+    gi, gd, gn = matcher.SearchByProjection(Fg, lms, 5.0)
+    assert (gi == -1).all() and gn == 0
+    fa = dict(sc["frame_args"]); fa["kps"] = fa["kps"][:0]; fa["desc"] = fa["desc"][:0]; fa["uR"] = fa["uR"][:0]; fa["kp_lm_obs"] = fa["kp_lm_obs"][:0]
+    Fg0, k0 = oracle.make_frame_view(N.FrameView, **fa)                         # frame without keypoints
+    gi, gd, gn = matcher.SearchByProjection(Fg0, sc["lms"], 5.0)
+    assert (gi == -1).all() and gn == 0
+
+
+def test_bow_grouped_search(matcher):
+    sc = scenes.projection_scene(37, 640, 480, nfeat=1000, copies=1)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(k1))
+    k2, d2 = k1[perm].copy(), d1[perm].copy()
+    d2[::2, 7] ^= 0x3C
+    k2["angle"] = (k2["angle"] + rng.normal(0, 3, len(k2)) + (rng.random(len(k2)) < 0.15) * 120) % 360
+    for nodes in (61, 500):
+        fv1, fv2 = scenes.synthetic_featvec(d1, nodes, 11), scenes.synthetic_featvec(d2, nodes, 11)
+        keep1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+        for kp, rot in ((None, False), (keep1, True)):
+            gm, gn = matcher.SearchByBoW(k1, d1, fv1, k2, d2, fv2, kp, rot)
+            om, on = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, kp, 50.0, 0.8, rot)
+            assert on > 100 and gn == on and np.array_equal(gm, om), (nodes, rot)
+    # disjoint vocabularies: nothing matches
+    fv2 = (fv2[0] + 1, fv2[1], fv2[2])
+    gm, gn = matcher.SearchByBoW(k1, d1, fv1, k2, d2, fv2, None, True)
+    assert gn == 0 and (gm == -1).all()
+
+
+def test_knn2(matcher):
+    rng = np.random.default_rng(6)
+    q = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (2003, 32), dtype=np.uint8)
+    t[100:600] = q[500:1000]
+    t[700] = t[100]                                                              # duplicate: first index wins, second distance 0
+    g = matcher.HammingKnn2(q, t)
+    o = oracle.hamming_knn2(q, t)
+    for a, b in zip(g, o):
+        assert np.array_equal(a, b)
+    assert g[0][500] == 100 and g[1][500] == 0 and g[2][500] == 0
+    g = matcher.HammingKnn2(q[:3], t[:1])
+    assert g[0].tolist() == [0, 0, 0] and g[2].tolist() == [-1, -1, -1]
+    g = matcher.HammingKnn2(q[:3], t[:0])
+    assert g[0].tolist() == [-1, -1, -1]

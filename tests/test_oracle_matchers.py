@@ -1,0 +1,166 @@
+"""CPU checks of the matcher half of the oracle: an independent python restatement of the projection search on a small
+scene, known answers for ComputeThreeMaxima / the rotation histogram quirk, and brute-force 2-NN against numpy."""
+import numpy as np
+
+import oracle
+import scenes
+
+
+def three_maxima(counts):
+    """ComputeThreeMaxima (MatchCriteria.cpp:727-767) on a list of bin sizes."""
+    m1 = m2 = m3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(counts):
+        if s > m1:
+            m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+        elif s > m2:
+            m3, m2, i3, i2 = m2, s, i2, i
+        elif s > m3:
+            m3, i3 = s, i
+    if m2 < np.float32(0.1) * np.float32(m1):
+        i2 = i3 = -1
+    elif m3 < np.float32(0.1) * np.float32(m1):
+        i3 = -1
+    return [i for i in (i1, i2, i3) if i >= 0]
+
+
+def test_rotation_histogram_uses_only_13_bins():
+    # factor = 1/30 and bin = round(rot*factor): rot in [0,360) lands in bins 0..12
+    a = np.zeros(360, np.float32)
+    b = np.arange(360, dtype=np.float32)
+    keep = oracle.rotation_consistency(a, b)          # rot = b - a
+    bins = np.floor(b * np.float32(1.0 / 30) + np.float32(0.5)).astype(int)      # round half away from zero, positive values
+    assert bins.max() == 12
+    counts = np.bincount(bins, minlength=30)
+    top3 = three_maxima(counts)
+    assert np.array_equal(keep, np.isin(bins, top3))
+
+
+def test_three_maxima_ten_percent_rule():
+    # 100 matches at rot 0, 9 at rot 90, 9 at rot 180: second/third < 10 % of the first -> only the first bin survives
+    a = np.zeros(118, np.float32)
+    b = np.concatenate([np.zeros(100), np.full(9, 90), np.full(9, 180)]).astype(np.float32)
+    keep = oracle.rotation_consistency(a, b)
+    assert keep[:100].all() and not keep[100:].any()
+    b = np.concatenate([np.zeros(100), np.full(10, 90), np.full(9, 180)]).astype(np.float32)
+    keep = oracle.rotation_consistency(np.zeros(119, np.float32), b)
+    assert keep[:110].all() and not keep[110:].any()
+    # negative rotations wrap by +360
+    keep = oracle.rotation_consistency(np.full(4, 350, np.float32), np.array([340, 341, 100, 342], np.float32))
+    assert keep.tolist() == [True, True, True, True]
+
+
+def test_knn2_against_numpy():
+    rng = np.random.default_rng(2)
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (130, 32), dtype=np.uint8)
+    t[5] = t[90] = q[3]                                  # exact duplicate: first index must win, second distance = 0
+    bi, bd, sd = oracle.hamming_knn2(q, t)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    assert np.array_equal(bi, D.argmin(1)) and np.array_equal(bd, D.min(1))
+    assert np.array_equal(sd, np.sort(D, 1)[:, 1]) and bi[3] == 5 and sd[3] == 0
+    bi, bd, sd = oracle.hamming_knn2(q[:2], t[:1])
+    assert bi.tolist() == [0, 0] and sd.tolist() == [-1, -1]
+
+
+def py_search_by_projection(fa, lms, pp):
+    """Independent restatement (per landmark, brute force over keypoints) of SURVEY.md §8a.1 R3."""
+    f32 = np.float32
+    Rcw, tcw = np.asarray(fa["Rcw"], f32), np.asarray(fa["tcw"], f32)
+    Ow = (-(Rcw.T @ tcw)).astype(f32)
+    kps, desc, uR, obs = fa["kps"], fa["desc"], fa["uR"], fa["kp_lm_obs"]
+    minx, maxx, miny, maxy = (f32(v) for v in fa["bounds"])
+    invW, invH = f32(64) / (maxx - minx), f32(48) / (maxy - miny)
+    gx = np.round((kps["x"] - minx) * invW).astype(int)            # numpy rounds half to even; coordinates never sit on .5 cells here
+    gy = np.round((kps["y"] - miny) * invH).astype(int)
+    ingrid = (gx >= 0) & (gx < 64) & (gy >= 0) & (gy < 48)
+
+    def proj(P):
+        Pc = (Rcw.astype(np.float64) @ P.astype(np.float64) + tcw.astype(np.float64)).astype(f32)
+        z = Pc[2]
+        xh, yh = f32(Pc[0] / z), f32(Pc[1] / z)
+        u = f32(np.float64(fa["fx"]) * np.float64(xh) + np.float64(fa["cx"]) * np.float64(f32(z / z)))
+        v = f32(np.float64(fa["fy"]) * np.float64(yh) + np.float64(fa["cy"]) * np.float64(f32(z / z)))
+        ur = f32(u - f32(f32(fa["mbf"]) * f32(f32(1) / z))) if fa["sensor"] == 1 else f32(-1)
+        return u, v, ur, bool(z > 0 and minx <= u <= maxx and miny <= v <= maxy)
+
+    out = {}
+    for li, lm in enumerate(lms):
+        if lm["skip"]:
+            continue
+        with np.errstate(all="ignore"):
+            u, v, ur, ok = proj(lm["pos"])
+        if not ok:
+            continue
+        if pp.use_distance:
+            dist = f32(np.sqrt(((lm["pos"] - Ow).astype(np.float64) ** 2).sum()))
+            if dist < f32(0.8) * lm["min_dist"] or dist > f32(1.2) * lm["max_dist"]:
+                continue
+        if lm["assoc_kp"] >= 0:
+            size = kps["size"][lm["assoc_kp"]]
+        else:
+            half = f32(lm["size"] / f32(2))
+            size = f32(proj(lm["pos"] + np.array([half, 0, 0], f32))[0] - proj(lm["pos"] - np.array([half, 0, 0], f32))[0])
+        r = f32(f32(f32(pp.th) * size) / f32(31))
+        x0 = max(0, int(np.floor(f32(f32(f32(u - minx) - r) * invW)))); x1 = min(63, int(np.ceil(f32(f32(f32(u - minx) + r) * invW))))
+        y0 = max(0, int(np.floor(f32(f32(f32(v - miny) - r) * invH)))); y1 = min(47, int(np.ceil(f32(f32(f32(v - miny) + r) * invH))))
+        m = ingrid & (gx >= x0) & (gx <= x1) & (gy >= y0) & (gy <= y1) & (np.abs(kps["x"] - u) < r) & (np.abs(kps["y"] - v) < r)
+        m &= ~(obs > 0)
+        m &= (kps["size"] > f32(pp.frac_smaller) * size) & (kps["size"] < f32(pp.frac_larger) * size)
+        if pp.use_stereo and fa["sensor"] != 0:
+            m &= (np.abs(ur - uR) < r) & (uR > 0)
+        cand = np.nonzero(m)[0]
+        if len(cand) == 0:
+            continue
+        cand = cand[np.lexsort((cand, gy[cand], gx[cand]))]           # grid column, then row, then insertion order
+        d = np.unpackbits(desc[cand] ^ lm["desc"][None, :], axis=1).sum(1)
+        b = int(np.argmin(d))
+        second = np.sort(d)[1] if len(d) > 1 else np.finfo(np.float32).max
+        if d[b] <= pp.score_threshold and not (f32(d[b]) > f32(pp.second_best_ratio) * f32(second)):
+            out[li] = (int(cand[b]), float(d[b]))
+    return out
+
+
+def test_projection_search_against_python_restatement():
+    sc = scenes.projection_scene(21, 320, 240, nfeat=400, copies=2, fx=260.0)
+    F, keep = oracle.make_frame_view(oracle.FrameView, **sc["frame_args"])
+    for (ud, us, rot, thr, ratio, th) in ((1, 1, 0, 100.0, 0.8, 5.0), (1, 0, 0, 60.0, 1.0, 8.0), (0, 1, 0, 100.0, 0.9, 3.0)):
+        pp = oracle.ProjParams(th, thr, ratio, 0.5, 1.5, ud, us, rot)
+        midx, mdist, n = oracle.search_by_projection(F, sc["lms"], pp)
+        ref = py_search_by_projection(sc["frame_args"], sc["lms"], pp)
+        got = {int(i): (int(midx[i]), float(mdist[i])) for i in np.nonzero(midx >= 0)[0]}
+        assert n == len(got) > 50
+        assert got == ref
+
+
+def test_projection_rotation_check_drops_duplicates_and_outlier_bins():
+    sc = scenes.projection_scene(22, 320, 240, nfeat=400, copies=3, fx=260.0)
+    F, keep = oracle.make_frame_view(oracle.FrameView, **sc["frame_args"])
+    base = oracle.search_by_projection(F, sc["lms"], oracle.ProjParams(5.0, 100.0, 0.9, 0.5, 1.5, 0, 1, 0))
+    rot = oracle.search_by_projection(F, sc["lms"], oracle.ProjParams(5.0, 100.0, 0.9, 0.5, 1.5, 0, 1, 1))
+    m0, m1 = base[0], rot[0]
+    assert (m1[m0 < 0] < 0).all() and rot[2] < base[2]
+    kept = m1[m1 >= 0]
+    assert len(np.unique(kept)) == len(kept) == rot[2]                    # one landmark per keypoint survives ...
+    for kp in np.unique(m0[m0 >= 0]):                                      # ... and it is the LAST landmark that matched it
+        owners = np.nonzero(m0 == kp)[0]
+        assert (m1[owners[:-1]] < 0).all()
+
+
+def test_bow_core_properties():
+    sc = scenes.projection_scene(23, 320, 240, nfeat=400, copies=1, fx=260.0)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(4)
+    perm = rng.permutation(len(k1))
+    k2, d2 = k1[perm].copy(), d1[perm].copy()
+    d2[::3, 5] ^= 0x11
+    fv1 = scenes.synthetic_featvec(d1, 37, 9)
+    fv2 = scenes.synthetic_featvec(d2, 37, 9)
+    m, n = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, None, 50.0, 0.9, False)
+    inv = np.argsort(perm)
+    ok = m >= 0
+    assert n == ok.sum() > len(k1) // 2
+    assert (m[ok] == inv[ok]).mean() > 0.95
+    keep1 = (np.arange(len(k1)) % 2 == 0).astype(np.uint8)
+    m2, n2 = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, 50.0, 0.9, True)
+    assert (m2[keep1 == 0] < 0).all() and 0 < n2 <= (keep1 == 1).sum()
