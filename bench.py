@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
+                    help="c2 = stereo extract+match (the headline metric); c5 = one mono stream per GPU + all-gather + cross-camera 2-NN")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,6 +71,9 @@ def main():
     import hyslam_amd as HS
     from hyslam_amd import _native as N
     from hyslam_amd.synth import synth_stereo_pair
+
+    if args.config == "c5":
+        return run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N)
 
     # ---- synthetic input, resident in HBM before the timed region
     B = args.pairs
@@ -160,6 +165,61 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
+    """BASELINE config 5: one 1920x1080 mono stream per GPU; per step every rank extracts its frame straight into the
+    all-gather record, one RCCL all-gather moves all records, then each rank runs the Hamming 2-NN of its descriptors against
+    every peer's.  value = frames/s over all ranks."""
+    from hyslam_amd import distributed as D
+    from hyslam_amd.synth import synth_image
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+    cap = ex.max_keypoints()
+    frame = torch.from_numpy(synth_image(200 + rank, W, H)).to(dev)
+    rec = torch.zeros(D.record_bytes(cap), dtype=torch.uint8, device=dev)
+    o_n, o_k, o_d = D.record_offsets(cap)
+    ex.reserve(W, H, 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_matches = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ex.extract_batch_device(frame.data_ptr(), 1, W, H, W, W * H, rec.data_ptr() + o_k, rec.data_ptr() + o_d, rec.data_ptr() + o_n, cap, stream)
+        g = D.all_gather_records(rec) if world > 1 else rec.unsqueeze(0)
+        res, counts = D.cross_camera_knn2(ex, g, rank, cap, stream)
+        return res, counts
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, counts = step()
+    fence()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    good = 0
+    for peer, (bi, bd, sd) in res.items():
+        n = counts[rank]
+        good += int(((bd[:n] < 50) & (bd[:n].float() < 0.8 * sd[:n].float())).sum().item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "mono frames/sec ORB extract + all-gather + cross-camera 2-NN, 1920x1080 @2000 feat", "value": round(world * args.steps / elapsed, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C5: one 1920x1080 mono stream per GPU, 2000 features, all-gather of %d-byte records, brute-force Hamming 2-NN vs every peer"
+                                   % D.record_bytes(cap), "keypoints_rank0": counts[0], "ratio_test_matches_rank0": good}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

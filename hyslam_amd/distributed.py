@@ -1,0 +1,96 @@
+"""Frame-per-GPU sharding and the one collective of the path (BASELINE config 5).
+
+Frames are independent, so extraction and stereo matching shard across ranks with no data-path collective.  Only
+cross-camera matching needs an exchange: an all-gather of one fixed-size record per rank,
+
+    [ int32 count | 12 B pad | hs_keypoint[cap] (24 B each) | uint8 desc[cap][32] ]      (~113 KB for cap = 2012)
+
+The extractor writes its outputs straight into that layout (the C ABI takes separate pointers, so `d_n`, `d_kps`, `d_desc`
+simply point into one buffer): packing costs nothing and the exchange is ONE collective per step.  On the 8-GPU xGMI mesh
+the payload is ~1 us of wire time per link, i.e. the step is latency-bound; RCCL's all-gather (backend "nccl" on ROCm)
+moves it in one hop over the 7 direct links.  With backend "gloo" the same code runs on CPU tensors (world-size-2 tests).
+"""
+import numpy as np
+
+from ._native import KP_DTYPE
+
+HEADER = 16
+KP_BYTES = KP_DTYPE.itemsize      # 24
+DESC_BYTES = 32
+
+
+def record_bytes(cap):
+    return HEADER + cap * (KP_BYTES + DESC_BYTES)
+
+
+def record_offsets(cap):
+    """byte offsets of (count, keypoints, descriptors) inside one record"""
+    return 0, HEADER, HEADER + cap * KP_BYTES
+
+
+def pack_record(kps, desc, cap):
+    """numpy -> one record (uint8[record_bytes(cap)]); padding beyond `count` is zero."""
+    n = len(kps)
+    if n > cap:
+        raise ValueError("more keypoints than the record holds")
+    rec = np.zeros(record_bytes(cap), np.uint8)
+    rec[:4] = np.frombuffer(np.int32(n).tobytes(), np.uint8)
+    o_n, o_k, o_d = record_offsets(cap)
+    rec[o_k:o_k + n * KP_BYTES] = np.ascontiguousarray(kps, KP_DTYPE).view(np.uint8)
+    rec[o_d:o_d + n * DESC_BYTES] = np.ascontiguousarray(desc, np.uint8).reshape(-1)
+    return rec
+
+
+def unpack_record(rec, cap):
+    """one record (numpy uint8) -> (keypoints[count], descriptors[count,32]); counts beyond cap are rejected."""
+    rec = np.ascontiguousarray(rec, np.uint8)
+    n = int(rec[:4].view(np.int32)[0])
+    if n < 0 or n > cap:
+        raise ValueError("corrupt frame record: count %d, cap %d" % (n, cap))
+    o_n, o_k, o_d = record_offsets(cap)
+    kps = rec[o_k:o_k + n * KP_BYTES].view(KP_DTYPE).copy()
+    desc = rec[o_d:o_d + n * DESC_BYTES].reshape(n, DESC_BYTES).copy()
+    return kps, desc
+
+
+def shard_range(n_items, rank, world):
+    """contiguous block of the `n_items` frames owned by `rank` (sizes differ by at most one)"""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_records(record, group=None):
+    """record: torch uint8 tensor [record_bytes] on this rank's device -> [world, record_bytes] on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world, record.numel()), dtype=torch.uint8, device=record.device)
+    dist.all_gather_into_tensor(out.view(-1), record.contiguous().view(-1), group=group)
+    return out
+
+
+def cross_camera_knn2(extractor, gathered, rank, cap, stream=0):
+    """Brute-force Hamming 2-NN of this rank's descriptors against every other rank's (hs_hamming_knn2_device).
+    gathered: torch uint8 [world, record_bytes(cap)] on the GPU.  Returns {peer: (best_idx, best_dist, second_dist)} int32 tensors
+    of length cap (entries beyond this rank's count are meaningless)."""
+    import ctypes as C
+    import torch
+    from . import _native as N
+    world = gathered.shape[0]
+    counts = gathered[:, :4].contiguous().view(torch.int32).view(-1).cpu().tolist()
+    o_n, o_k, o_d = record_offsets(cap)
+    base = gathered.data_ptr()
+    stride = gathered.shape[1]
+    out = {}
+    for peer in range(world):
+        if peer == rank:
+            continue
+        bi = torch.empty(cap, dtype=torch.int32, device=gathered.device)
+        bd = torch.empty_like(bi)
+        sd = torch.empty_like(bi)
+        N.check(extractor._h, extractor._lib.hs_hamming_knn2_device(
+            extractor._h, C.c_void_p(base + rank * stride + o_d), counts[rank], C.c_void_p(base + peer * stride + o_d), counts[peer],
+            C.c_void_p(bi.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(sd.data_ptr()), C.c_void_p(stream) if stream else None))
+        out[peer] = (bi, bd, sd)
+    return out, counts

@@ -1,0 +1,96 @@
+"""The N>1 path on CPU: two `gloo` ranks shard frames, all-gather the per-frame records and must end up with identical
+gathered bytes and identical cross-camera match lists (the matcher used here is the oracle — test infrastructure; the
+product's GPU 2-NN is covered in tests/test_gpu_matchers.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from hyslam_amd import distributed as D
+    from hyslam_amd.synth import synth_image
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cap = 1000 + 4 * 8 + 4
+    lo, hi = D.shard_range(5, rank, world)                       # 5 camera frames over 2 ranks: 3 + 2
+    p = oracle.default_params(1000)
+    frames = [synth_image(200 + i, 320, 240) for i in range(lo, hi)]
+    k, d = oracle.extract(p, frames[0])                          # each rank publishes its first frame
+    rec = torch.from_numpy(D.pack_record(k, d, cap))
+    g = D.all_gather_records(rec)
+    assert g.shape == (world, D.record_bytes(cap))
+    mine = D.unpack_record(g[rank].numpy(), cap)
+    assert mine[0].tobytes() == k.tobytes() and np.array_equal(mine[1], d)
+    matches = {}
+    for a in range(world):
+        for b in range(world):
+            if a != b:
+                ka, da = D.unpack_record(g[a].numpy(), cap)
+                kb, db = D.unpack_record(g[b].numpy(), cap)
+                bi, bd, sd = oracle.hamming_knn2(da, db)
+                matches[(a, b)] = hashlib.sha256(bi.tobytes() + bd.tobytes() + sd.tobytes()).hexdigest()
+    q.put((rank, (lo, hi), hashlib.sha256(g.numpy().tobytes()).hexdigest(), matches, len(k)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allgather_and_identical_match_lists():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(0, 3), (3, 5)]
+    assert res[0][2] == res[1][2], "ranks disagree on the gathered bytes"
+    assert res[0][3] == res[1][3], "ranks disagree on the cross-camera match lists"
+    assert res[0][4] > 100 and res[1][4] > 100
+
+
+def test_record_layout_and_sharding():
+    from hyslam_amd import distributed as D
+    cap = 50
+    assert D.record_bytes(cap) == 16 + cap * 56 and D.record_offsets(cap) == (0, 16, 16 + cap * 24)
+    rng = np.random.default_rng(0)
+    from hyslam_amd._native import KP_DTYPE
+    k = np.zeros(7, KP_DTYPE); k["x"] = rng.random(7); k["octave"] = np.arange(7)
+    d = rng.integers(0, 256, (7, 32), dtype=np.uint8)
+    rec = D.pack_record(k, d, cap)
+    k2, d2 = D.unpack_record(rec, cap)
+    assert k2.tobytes() == k.tobytes() and np.array_equal(d, d2)
+    e = D.unpack_record(D.pack_record(k[:0], d[:0], cap), cap)
+    assert len(e[0]) == 0 and e[1].shape == (0, 32)
+    with pytest.raises(ValueError):
+        D.pack_record(np.zeros(cap + 1, KP_DTYPE), np.zeros((cap + 1, 32), np.uint8), cap)
+    bad = rec.copy(); bad[:4] = np.frombuffer(np.int32(cap + 1).tobytes(), np.uint8)
+    with pytest.raises(ValueError):
+        D.unpack_record(bad, cap)
+    for n in (0, 1, 7, 8, 9, 64):
+        for w in (1, 2, 3, 8):
+            r = [D.shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
