@@ -18,13 +18,14 @@ struct hs_orb {
     hipStream_t stream = nullptr;
     std::string err;
     uint16_t taps[7];
+    bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> quota;
     // geometry currently configured
     int w = 0, h = 0, batch_cap = 0;
     std::vector<HsLevel> lv;
-    int total_cells = 0;
+    int total_cells = 0, max_wcell = 1, max_hcell = 1;
     uint64_t cand_img_stride = 0;      // candidate entries per image
     int sel_img_stride = 0;            // selection entries per image
     int max_kp = 0;
@@ -155,6 +156,8 @@ int configure(hs_orb* h, int w, int hh, int batch)
         }
     }
     pyr_per_img = (pyr_per_img + 255) & ~(size_t)255;
+    h->max_wcell = h->max_hcell = 1;
+    for (int l = 0; l < L; l++) { h->max_wcell = std::max(h->max_wcell, h->lv[l].wcell); h->max_hcell = std::max(h->max_hcell, h->lv[l].hcell); }
     h->total_cells = cells; h->cand_img_stride = cand; h->sel_img_stride = sel; h->max_kp = sel;
 
     HIP_TRY(h, hipMalloc(&h->d_pyr, std::max<size_t>(pyr_per_img * batch, 256)));
@@ -218,13 +221,13 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
     hs_launch_fast(h->d_lv, L, img0, batch, h->total_cells, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, s);
+                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->sel_img_stride, h->max_kp,
-                       h->d_taps, out, s);
+                       h->d_taps, out, s, h->fast_taps);
     mark(h, -1, s);
     HIP_TRY(h, hipGetLastError());
     h->last_batch = batch; h->last_img0 = img0;
@@ -314,6 +317,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
     static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
     for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];
+    { uint32_t sum = 0; bool bytes = true; for (int k = 0; k < 7; k++) { sum += h->taps[k]; bytes = bytes && h->taps[k] <= 255; } h->fast_taps = bytes && sum * 255u <= 0xFFFFu; }
 
     // ORBExtractor::ORBExtractor (ORBExtractor.cpp:86-118); scaleFactor is a double member fed from a float setting
     const int L = p->nlevels;

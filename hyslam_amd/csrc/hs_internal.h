@@ -66,14 +66,15 @@ struct HsOut {                     // extractor outputs, split the same way
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
 void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
-                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride, hipStream_t s);
+                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                    int max_wcell, int max_hcell, hipStream_t s);
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s);
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, int sel_img_stride, int max_sel,
-                        const uint16_t* taps7, HsOut out, hipStream_t s);
+                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps);
 void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,

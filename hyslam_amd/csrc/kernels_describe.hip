@@ -15,6 +15,13 @@
 //   angle  : integer moments over the 749-px disc (umax table), cv::fastAtan2 polynomial in fp32, no FMA
 //   rBRIEF : a=(float)cos(theta), b=(float)sin(theta) evaluated in double; offsets = round-half-even of
 //            separately rounded fp32 products; bit i of byte j = test 8j+i -> one ballot per 64 tests.
+//
+// Fast path (FT = true: every tap <= 255 and 255*sum(taps) <= 65535, i.e. the row sums cannot saturate — true for the
+// default taps): the patch is fetched as aligned dwords straight into an LDS tile that keeps the source misalignment,
+// the row pass is two v_dot4_u32_u8 per output on v_alignbyte'd windows, the row sums are stored TRANSPOSED as u16
+// so that the column pass is four v_dot2_u32_u16 per output (two vertically adjacent outputs share their loads; odd
+// rows use a tap packing shifted by one element instead of shifting data).  Integer sums are exact, so this is
+// bit-identical to the generic path, which stays for exotic taps and for keypoints whose patch crosses the border.
 #include "hs_internal.h"
 #include "../../include/hyslam_orb_pattern.h"
 
@@ -22,9 +29,12 @@ __constant__ int8_t c_pattern[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
 __constant__ int8_t c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBFinder.cpp:131-149
 
 #define RAW_N 43
-#define RAW_P 44
+#define RAW_P 48                 // raw tile pitch: 12 dwords hold 43 bytes at any source misalignment (3 + 43 <= 48)
+#define RAW_BYTES (RAW_N * RAW_P + 16)
 #define BL_N 37
-#define H_P 38
+#define H_P 38                   // generic path: row-major u16 row sums
+#define HT_P 44                  // fast path: transposed u16 row sums, 43 rows + 1 pad (multiplied by a zero tap)
+#define H_ELEMS (RAW_N * H_P)    // 1634 >= BL_N * HT_P = 1628
 #define BL_P 40
 #define KP_PER_BLOCK 4
 
@@ -58,14 +68,23 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+typedef unsigned short hs_ushort2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)      // v_dot2_u32_u16: a.lo*b.lo + a.hi*b.hi + c
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(hs_ushort2, a), __builtin_bit_cast(hs_ushort2, b), c, false);
+}
+
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)   // lgkmcnt(0)
+
+template <bool FT>
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0,
                                                                  const uint32_t* __restrict__ sel_xys, const int32_t* __restrict__ sel_count,
                                                                  int sel_img_stride, const uint16_t* __restrict__ taps7,
                                                                  HsOut O)
 {
-    __shared__ uint8_t s_raw[KP_PER_BLOCK][RAW_N * RAW_P];
-    __shared__ uint16_t s_h[KP_PER_BLOCK][RAW_N * H_P];
-    __shared__ uint8_t s_bl[KP_PER_BLOCK][BL_N * BL_P];
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][H_ELEMS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bl[KP_PER_BLOCK][BL_N * BL_P];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int img = blockIdx.y;
@@ -96,45 +115,96 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     else { base = L.base + (size_t)img * L.img_stride; pitch = L.pitch; }
 
     uint8_t* raw = s_raw[wv]; uint16_t* hb = s_h[wv]; uint8_t* bl = s_bl[wv];
-
-    // ---- raw 43x43 neighbourhood, BORDER_REFLECT_101 at the level border
-    for (int i = lane; i < RAW_N * RAW_N; i += 64) {
-        int r = i / RAW_N, q = i - r * RAW_N;
-        int y = reflect101(cy - 21 + r, L.h), x = reflect101(cx - 21 + q, L.w);
-        raw[r * RAW_P + q] = base[(size_t)y * pitch + x];
-    }
     uint32_t tp[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) tp[k] = taps7[k];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are done before the reads below
-    // ---- horizontal pass: ufixedpoint16 saturating sums
-    for (int i = lane; i < RAW_N * BL_N; i += 64) {
-        int r = i / BL_N, c = i - r * BL_N;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            uint32_t t = min(tp[k] * (uint32_t)raw[r * RAW_P + c + k], 0xFFFFu);
-            acc = min(acc + t, 0xFFFFu);
+
+    // ---- raw 43x43 neighbourhood.  Interior keypoints: aligned dword rows, the tile keeps the source misalignment `sh`.
+    //      Patches that touch the level border: byte loads with BORDER_REFLECT_101.
+    const int x0 = cx - 21, y0 = cy - 21;
+    const bool interior = x0 >= 0 && y0 >= 0 && cy + 21 < L.h && cx + 24 < L.w && (((uintptr_t)base | pitch) & 3) == 0;
+    const int sh = (FT && interior) ? (x0 & 3) : 0;
+    if (FT && interior) {
+        const uint8_t* src = base + (size_t)y0 * pitch + (x0 - sh);
+        const int ndw = (sh + RAW_N + 3) >> 2;             // 11 or 12
+        for (int i = lane; i < RAW_N * 12; i += 64) {
+            int r = i / 12, q = i - r * 12;
+            if (q < ndw) *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = *reinterpret_cast<const uint32_t*>(src + (size_t)r * pitch + 4 * q);
         }
-        hb[r * H_P + c] = (uint16_t)acc;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    // ---- vertical pass: ufixedpoint32 saturating sums, round, saturate to u8
-    for (int i = lane; i < BL_N * BL_N; i += 64) {
-        int r = i / BL_N, c = i - r * BL_N;
-        unsigned long long acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            acc += (unsigned long long)tp[k] * hb[(r + k) * H_P + c];
-            acc = acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc;
+    } else {
+        for (int i = lane; i < RAW_N * RAW_N; i += 64) {
+            int r = i / RAW_N, q = i - r * RAW_N;
+            int y = reflect101(y0 + r, L.h), x = reflect101(x0 + q, L.w);
+            raw[r * RAW_P + q] = base[(size_t)y * pitch + x];
         }
-        unsigned long long v = (acc + 0x8000ull) >> 16;
-        bl[r * BL_P + c] = (uint8_t)(v > 255 ? 255 : v);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    WAVE_LDS_SYNC();
+
+    if (FT) {
+        // ---- row pass: H[r][c..c+3] from three/four aligned dwords, two dot4 per output; stored transposed HT[c][r]
+        const uint32_t t0123 = tp[0] | (tp[1] << 8) | (tp[2] << 16) | (tp[3] << 24);
+        const uint32_t t456 = tp[4] | (tp[5] << 8) | (tp[6] << 16);
+        for (int i = lane; i < RAW_N * 10; i += 64) {
+            const int r = i / 10, gq = i - r * 10;
+            const int b0 = sh + 4 * gq;                        // first byte of the first window of this group
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(&raw[r * RAW_P + (b0 & ~3)]);
+            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];   // bytes beyond the row only meet the zero tap
+            const int s = b0 & 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * gq + j;
+                const int t = s + j;                            // 0..6
+                const uint32_t lo = t < 4 ? __builtin_amdgcn_alignbyte(d1, d0, t) : __builtin_amdgcn_alignbyte(d2, d1, t - 4);
+                const uint32_t hi = t < 4 ? __builtin_amdgcn_alignbyte(d2, d1, t) : __builtin_amdgcn_alignbyte(d3, d2, t - 4);
+                const uint32_t hsum = __builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
+                if (c < BL_N) hb[c * HT_P + r] = (uint16_t)hsum;
+            }
+        }
+        if (lane < BL_N) hb[lane * HT_P + 43] = 0;              // pad element (only ever multiplied by a zero tap)
+        WAVE_LDS_SYNC();
+        // ---- column pass: lane = (column c, even row r): dwords (r,r+1)..(r+6,r+7) of HT[c]; even rows use taps (t0,t1)(t2,t3)(t4,t5)(t6,0),
+        //      the odd row r+1 uses (0,t0)(t1,t2)(t3,t4)(t5,t6) on the SAME dwords
+        const uint32_t e0 = tp[0] | (tp[1] << 16), e1 = tp[2] | (tp[3] << 16), e2 = tp[4] | (tp[5] << 16), e3 = tp[6];
+        const uint32_t o0 = tp[0] << 16, o1 = tp[1] | (tp[2] << 16), o2 = tp[3] | (tp[4] << 16), o3 = tp[5] | (tp[6] << 16);
+        for (int i = lane; i < BL_N * 19; i += 64) {
+            const int c = i / 19, rp = i - c * 19;              // rows 2rp, 2rp+1 (row 37 does not exist)
+            const int r = 2 * rp;
+            const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
+            const uint32_t a0 = col[0], a1 = col[1], a2 = col[2], a3 = col[3];
+            const uint32_t ve = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0u))));
+            bl[r * BL_P + c] = (uint8_t)min((ve + 0x8000u) >> 16, 255u);
+            if (r + 1 < BL_N) {
+                const uint32_t vo = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0u))));
+                bl[(r + 1) * BL_P + c] = (uint8_t)min((vo + 0x8000u) >> 16, 255u);
+            }
+        }
+    } else {
+        // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
+        for (int i = lane; i < RAW_N * BL_N; i += 64) {
+            int r = i / BL_N, c = i - r * BL_N;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                uint32_t t = min(tp[k] * (uint32_t)raw[r * RAW_P + c + k], 0xFFFFu);
+                acc = min(acc + t, 0xFFFFu);
+            }
+            hb[r * H_P + c] = (uint16_t)acc;
+        }
+        WAVE_LDS_SYNC();
+        // ---- vertical pass: ufixedpoint32 saturating sums, round, saturate to u8
+        for (int i = lane; i < BL_N * BL_N; i += 64) {
+            int r = i / BL_N, c = i - r * BL_N;
+            unsigned long long acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                acc += (unsigned long long)tp[k] * hb[(r + k) * H_P + c];
+                acc = acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc;
+            }
+            unsigned long long v = (acc + 0x8000ull) >> 16;
+            bl[r * BL_P + c] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+    WAVE_LDS_SYNC();
 
     // ---- intensity centroid (ORBFinder.cpp:16-43): integer moments over the umax disc
     int m10 = 0, m01 = 0;
@@ -158,12 +228,12 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int t = 64 * r + lane;
-        float x0 = (float)c_pattern[4 * t + 0], y0 = (float)c_pattern[4 * t + 1];
-        float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
-        int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        float px0 = (float)c_pattern[4 * t + 0], py0 = (float)c_pattern[4 * t + 1];
+        float px1 = (float)c_pattern[4 * t + 2], py1 = (float)c_pattern[4 * t + 3];
+        int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
+        int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
+        int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
+        int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
         int t0 = bl[(18 + dy0) * BL_P + 18 + dx0];
         int t1 = bl[(18 + dy1) * BL_P + 18 + dx1];
         unsigned long long m = __ballot(t0 < t1);
@@ -181,11 +251,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, int sel_img_stride, int max_sel,
-                        const uint16_t* taps7, HsOut out, hipStream_t s)
+                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps)
 {
     int per_img = max_sel < out.cap ? max_sel : out.cap;
     dim3 grid((per_img + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch, 1);
     if (grid.x == 0) grid.x = 1;
-    hipLaunchKernelGGL(k_describe, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride,
-                       taps7, out);
+    if (fast_taps)
+        hipLaunchKernelGGL(k_describe<true>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride, taps7, out);
+    else
+        hipLaunchKernelGGL(k_describe<false>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride, taps7, out);
 }

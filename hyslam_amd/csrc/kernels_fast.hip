@@ -25,13 +25,22 @@
 //   cell_count[image][global cell] = number of slots used.
 // Bound: integer VALU + LDS byte reads; HBM bytes = P per frame.
 #include "hs_internal.h"
+#include <algorithm>
 
-#define TILE_PITCH 80                        // >= 3 (dword misalignment) + HS_MAX_CELL + 6, multiple of 4
-#define TILE_ROWS (HS_MAX_CELL + 6)
-#define SCORE_PITCH (HS_MAX_CELL + 4)        // interior + 1 px zero frame, padded
-#define SCORE_ROWS (HS_MAX_CELL + 2)
-#define MAX_OUT (HS_MAX_CELL * HS_MAX_CELL / 4)
-#define NPRE 6                               // prefetched dwords per thread: 1536 >= 70 rows x 19 dwords
+// LDS layout, sized on the host from the largest cell of the configured geometry (a 1080p frame needs ~9 KB per workgroup,
+// so the wave limit, not LDS, decides how many cells a CU has in flight)
+// TILE_PITCH / SCORE_PITCH are template parameters: compile-time pitches keep the 16 ring offsets immediate operands.
+// Two variants: cells up to 37 px wide (every standard configuration) and the general one (up to HS_MAX_CELL).
+struct FastLds {
+    int32_t tile_pitch;      // >= 3 (dword misalignment) + max cell width + 6, multiple of 4
+    int32_t score_pitch;     // max cell width + 2 (1 px zero frame), multiple of 4
+    int32_t score_bytes;     // (max cell height + 2) * score_pitch
+    int32_t off_score, off_mlist, off_clist, off_outxy, off_outs, off_ctr, total;
+};
+#ifndef FAST_NT
+#define FAST_NT 128                          // threads per workgroup (one cell at a time)
+#endif
+#define NPRE (1536 / FAST_NT)                // prefetched dwords per thread: 1536 >= 70 rows x 19 dwords
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would expose the latency of
 // the next cell's prefetch at the first barrier after it is issued; the tile/list hand-offs inside a cell are LDS-only.
@@ -94,18 +103,22 @@ __device__ __forceinline__ CellGeom cell_geom(const HsLevel* __restrict__ lv, in
     return g;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0, int fast_th,
+template <int TILE_PITCH, int SCORE_PITCH>
+__global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0, int fast_th,
                                                     uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
                                                     int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
-                                                    int total_cells, int total_work)
+                                                    int total_cells, int total_work, FastLds lds)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_ROWS * TILE_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t score[SCORE_ROWS * SCORE_PITCH];
-    __shared__ uint16_t mlist[HS_MAX_CELL * HS_MAX_CELL];      // "maybe" pixels (py<<8 | px)
-    __shared__ uint16_t clist[HS_MAX_CELL * HS_MAX_CELL];      // corners
-    __shared__ uint32_t out_xy[MAX_OUT];
-    __shared__ uint8_t out_s[MAX_OUT];
-    __shared__ int n_maybe, n_corner, n_out;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const tile = smem;
+    uint8_t* const score = smem + lds.off_score;
+    uint16_t* const mlist = reinterpret_cast<uint16_t*>(smem + lds.off_mlist);      // "maybe" pixels (py<<8 | px)
+    uint16_t* const clist = reinterpret_cast<uint16_t*>(smem + lds.off_clist);      // corners
+    uint32_t* const out_xy = reinterpret_cast<uint32_t*>(smem + lds.off_outxy);
+    uint8_t* const out_s = smem + lds.off_outs;
+    int& n_maybe = reinterpret_cast<int*>(smem + lds.off_ctr)[0];
+    int& n_corner = reinterpret_cast<int*>(smem + lds.off_ctr)[1];
+    int& n_out = reinterpret_cast<int*>(smem + lds.off_ctr)[2];
 
     const int tid = threadIdx.x;
     const int t = fast_th;
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
     const int w_begin = chunk * per, w_end = min(total_work, w_begin + per);
     if (w_begin >= w_end) return;
 
-    for (int i = tid; i < SCORE_ROWS * SCORE_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(score)[i] = 0;
+    for (int i = tid; i < lds.score_bytes / 4; i += FAST_NT) reinterpret_cast<uint32_t*>(score)[i] = 0;
     if (tid == 0) n_out = 0;
 
     uint32_t pre[NPRE];
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
         const int n = q.th * q.ndw;
 #pragma unroll
         for (int j = 0; j < NPRE; j++) {
-            int i = tid + 256 * j;
+            int i = tid + FAST_NT * j;
             if (i < n) {
                 int r = (int)(((float)i + 0.5f) * rcp), c = i - r * q.ndw;
                 pre[j] = *reinterpret_cast<const uint32_t*>(q.rows + (size_t)r * q.pitch + 4 * c);
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
             const int n = g.th * g.ndw;
 #pragma unroll
             for (int j = 0; j < NPRE; j++) {
-                int i = tid + 256 * j;
+                int i = tid + FAST_NT * j;
                 if (i < n) {
                     int r = (int)(((float)i + 0.5f) * rcp), c = i - r * g.ndw;
                     *reinterpret_cast<uint32_t*>(&tile[r * TILE_PITCH + 4 * c]) = pre[j];
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
             }
         } else {
             const uint8_t* src = g.rows + off;                  // (iniX, iniY)
-            for (int i = tid; i < g.th * g.tw; i += 256) {
+            for (int i = tid; i < g.th * g.tw; i += FAST_NT) {
                 int r = i / g.tw, c = i - r * g.tw;
                 tile[r * TILE_PITCH + off + c] = src[(size_t)r * g.pitch + c];
             }
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
         //      ADJACENT compass points, i.e. (p0 or p8) and (p4 or p12).
         const int npix = iw * ih;
         const float rcp_iw = 1.0f / (float)iw;                  // exact floor(p/iw) for p < 4096, iw <= 64
-        for (int p = tid; p < npix; p += 256) {
+        for (int p = tid; p < npix; p += FAST_NT) {
             int py = (int)(((float)p + 0.5f) * rcp_iw), px = p - py * iw;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
             int v = ctr[0];
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
 
         // ---- pass 2 (maybe pixels): 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits
         const int nm = n_maybe;
-        for (int i = tid; i < nm; i += 256) {
+        for (int i = tid; i < nm; i += FAST_NT) {
             int pos = mlist[i];
             int py = pos >> 8, px = pos & 255;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
 
         // ---- pass 3 (corners): corner score
         const int nc = n_corner;
-        for (int i = tid; i < nc; i += 256) {
+        for (int i = tid; i < nc; i += FAST_NT) {
             int pos = clist[i];
             int py = pos >> 8, px = pos & 255;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
         LDS_BARRIER();                                           // S3
 
         // ---- pass 4: 3x3 strict NMS inside the cell
-        for (int i = tid; i < nc; i += 256) {
+        for (int i = tid; i < nc; i += FAST_NT) {
             int pos = clist[i];
             int py = pos >> 8, px = pos & 255;
             const uint8_t* sc = &score[(py + 1) * SCORE_PITCH + px + 1];
@@ -257,11 +270,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
         const int no = n_out;
         if (tid == 0) *cnt = no;
         const size_t slot0 = (size_t)cur.img * cand_img_stride + L.cand_off + (size_t)cur.c * cur.ccap;
-        for (int i = tid; i < no; i += 256) {
+        for (int i = tid; i < no; i += FAST_NT) {
             cand_xy[slot0 + i] = out_xy[i];
             cand_sk[slot0 + i] = ((uint32_t)out_s[i] << 24) | (uint32_t)cur.c;
         }
-        for (int i = tid; i < nc; i += 256) {
+        for (int i = tid; i < nc; i += FAST_NT) {
             int pos = clist[i];
             score[((pos >> 8) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0;
         }
@@ -269,12 +282,33 @@ __global__ __launch_bounds__(256) void k_fast_cells(const HsLevel* __restrict__ 
 }
 
 void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
-                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride, hipStream_t s)
+                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                    int max_wcell, int max_hcell, hipStream_t s)
 {
     if (total_cells <= 0) return;
+    auto up = [](int v, int a) { return (v + a - 1) / a * a; };
+    FastLds L;
+    const bool small = max_wcell <= 37;
+    L.tile_pitch = small ? 48 : 80;                        // >= 3 + max_wcell + 6, multiple of 4
+    L.score_pitch = small ? 40 : HS_MAX_CELL + 4;          // >= max_wcell + 2, multiple of 4
+    L.score_bytes = up((max_hcell + 2) * L.score_pitch, 4);
+    int o = up((max_hcell + 6) * L.tile_pitch + 16, 16);
+    L.off_score = o; o = up(o + L.score_bytes, 16);
+    L.off_mlist = o; o = up(o + 2 * max_wcell * max_hcell, 16);
+    L.off_clist = o; o = up(o + 2 * max_wcell * max_hcell, 16);
+    const int max_out = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
+    L.off_outxy = o; o = up(o + 4 * max_out, 16);
+    L.off_outs = o; o = up(o + max_out, 16);
+    L.off_ctr = o; o += 16;
+    L.total = o;
     const int total_work = total_cells * batch;
-    int nblk = 256 * 4;                                   // 4 persistent workgroups per CU
-    while (nblk > 8 && nblk / 2 >= total_work) nblk /= 2;  // tiny jobs: do not launch idle workgroups
-    hipLaunchKernelGGL(k_fast_cells, dim3(nblk), dim3(256), 0, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
-                       cand_img_stride, total_cells, total_work);
+    int per_cu = std::min(2048 / FAST_NT, std::max(1, (160 * 1024) / L.total));   // wave limit (32 per CU) or LDS
+    int nblk = 256 * per_cu;                               // persistent workgroups
+    while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD dealing)
+    if (small)
+        hipLaunchKernelGGL((k_fast_cells<48, 40>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+                           cand_img_stride, total_cells, total_work, L);
+    else
+        hipLaunchKernelGGL((k_fast_cells<80, HS_MAX_CELL + 4>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+                           cand_img_stride, total_cells, total_work, L);
 }
