@@ -93,3 +93,4 @@ void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs
                    int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
+void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);

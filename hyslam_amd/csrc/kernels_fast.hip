@@ -65,7 +65,7 @@ __device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t)
 }
 
 struct CellGeom {           // wave-uniform description of one work item
-    int img, level, c, gcell;
+    int img, level, ci, cj, c, gcell;
     int xoff, yoff;         // j*wCell, i*hCell: what the reference adds to cv::FAST's local coordinates (:463-464)
     int iniX, iniY, tw, th; // sub-image handed to cv::FAST
     int off, ndw;           // dword staging: tile x = off + (x - iniX); ndw dwords per row
@@ -75,32 +75,54 @@ struct CellGeom {           // wave-uniform description of one work item
     bool valid, aligned;
 };
 
-__device__ __forceinline__ CellGeom cell_geom(const HsLevel* __restrict__ lv, int nlevels, const HsImg0& img0, int total_cells, int w)
+// geometry of cell (ci, cj) of `level` in image `img` — no divisions (the walk below steps cells incrementally)
+__device__ __forceinline__ void cell_fill(CellGeom& g, const HsLevel* __restrict__ lv, const HsImg0& img0)
 {
-    CellGeom g;
-    g.img = w / total_cells;
-    g.gcell = w - g.img * total_cells;
-    int level = 0;
-    while (level + 1 < nlevels && g.gcell >= lv[level + 1].cell_begin) level++;
-    const HsLevel& L = lv[level];
-    g.level = level;
-    g.c = g.gcell - L.cell_begin;
-    const int ci = g.c / L.ncols, cj = g.c - ci * L.ncols;
-    g.xoff = cj * L.wcell; g.yoff = ci * L.hcell;
+    const HsLevel& L = lv[g.level];
+    g.c = g.ci * L.ncols + g.cj;
+    g.gcell = L.cell_begin + g.c;
+    g.xoff = g.cj * L.wcell; g.yoff = g.ci * L.hcell;
     g.iniX = HS_BORDER + g.xoff; g.iniY = HS_BORDER + g.yoff;
     const int maxX = min(g.iniX + L.wcell + 6, L.w - HS_BORDER), maxY = min(g.iniY + L.hcell + 6, L.h - HS_BORDER);
     g.tw = maxX - g.iniX; g.th = maxY - g.iniY;
     g.valid = g.tw >= 7 && g.th >= 7;                 // reference skip rules (:435,444) / cv::FAST on < 7 rows or columns
     g.ccap = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
     const uint8_t* base;
-    if (level == 0) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
+    if (g.level == 0) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
     else { base = L.base + (size_t)g.img * L.img_stride; g.pitch = L.pitch; }
     const int a0 = g.iniX & ~3;
     g.off = g.iniX - a0;
     g.ndw = (g.off + g.tw + 3) >> 2;
     g.aligned = (((uintptr_t)base | g.pitch) & 3) == 0;
     g.rows = base + (size_t)g.iniY * g.pitch + a0;
+}
+
+// work item w -> geometry (used once per workgroup)
+__device__ __forceinline__ CellGeom cell_geom(const HsLevel* __restrict__ lv, int nlevels, const HsImg0& img0, int total_cells, int w)
+{
+    CellGeom g;
+    g.img = w / total_cells;
+    const int gcell = w - g.img * total_cells;
+    int level = 0;
+    while (level + 1 < nlevels && gcell >= lv[level + 1].cell_begin) level++;
+    g.level = level;
+    const int c = gcell - lv[level].cell_begin;
+    g.ci = c / lv[level].ncols; g.cj = c - g.ci * lv[level].ncols;
+    cell_fill(g, lv, img0);
     return g;
+}
+
+// the next work item: next column, row, level (skipping levels without cells), image
+__device__ __forceinline__ void cell_next(CellGeom& g, const HsLevel* __restrict__ lv, int nlevels, const HsImg0& img0)
+{
+    if (++g.cj == lv[g.level].ncols) {
+        g.cj = 0;
+        if (++g.ci == lv[g.level].nrows) {
+            g.ci = 0;
+            do { if (++g.level == nlevels) { g.level = 0; g.img++; } } while (lv[g.level].ncols * lv[g.level].nrows == 0);
+        }
+    }
+    cell_fill(g, lv, img0);
 }
 
 template <int TILE_PITCH, int SCORE_PITCH>
@@ -141,10 +163,11 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
     CellGeom g = cell_geom(lv, nlevels, img0, total_cells, w_begin);
     auto prefetch = [&](const CellGeom& q) {
         if (!(q.valid && q.aligned)) return;
-        const float rcp = 1.0f / (float)q.ndw;
+        const float rcp = __builtin_amdgcn_rcpf((float)q.ndw);    // 1 ulp is plenty: (i+0.5)/ndw is >= 1/(2*19) away from an integer
         const int n = q.th * q.ndw;
 #pragma unroll
         for (int j = 0; j < NPRE; j++) {
+            if (FAST_NT * j >= n) break;                            // uniform: typical cells need 4 of the 12 slots
             int i = tid + FAST_NT * j;
             if (i < n) {
                 int r = (int)(((float)i + 0.5f) * rcp), c = i - r * q.ndw;
@@ -159,17 +182,18 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         int32_t* cnt = &cell_count[(size_t)g.img * total_cells + g.gcell];
         if (!g.valid) {
             if (tid == 0) *cnt = 0;
-            if (w + 1 < w_end) { g = cell_geom(lv, nlevels, img0, total_cells, w + 1); prefetch(g); }
+            if (w + 1 < w_end) { cell_next(g, lv, nlevels, img0); prefetch(g); }
             continue;
         }
         const int iw = g.tw - 6, ih = g.th - 6;                 // interior = pixels FAST can report
         const int off = g.off;
         // ---- stage the tile
         if (g.aligned) {
-            const float rcp = 1.0f / (float)g.ndw;
+            const float rcp = __builtin_amdgcn_rcpf((float)g.ndw);
             const int n = g.th * g.ndw;
 #pragma unroll
             for (int j = 0; j < NPRE; j++) {
+                if (FAST_NT * j >= n) break;
                 int i = tid + FAST_NT * j;
                 if (i < n) {
                     int r = (int)(((float)i + 0.5f) * rcp), c = i - r * g.ndw;
@@ -186,12 +210,16 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         if (tid == 0) { n_maybe = 0; n_corner = 0; }
         LDS_BARRIER();                                           // S0: tile ready, previous cell fully drained
         const CellGeom cur = g;
-        if (w + 1 < w_end) { g = cell_geom(lv, nlevels, img0, total_cells, w + 1); prefetch(g); }   // in flight during the passes
+        if (w + 1 < w_end) { cell_next(g, lv, nlevels, img0); prefetch(g); }   // in flight during the passes
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 1
+        if (tid == 0) *cnt = 0;
+        continue;
+#endif
         // ---- pass 1 (every pixel): quick reject on the four compass points.  A 9-arc of the 16-ring always holds two
         //      ADJACENT compass points, i.e. (p0 or p8) and (p4 or p12).
         const int npix = iw * ih;
-        const float rcp_iw = 1.0f / (float)iw;                  // exact floor(p/iw) for p < 4096, iw <= 64
+        const float rcp_iw = __builtin_amdgcn_rcpf((float)iw);  // floor(p/iw) via (p+0.5)*rcp: exact for p < 4096, iw <= 64 even at 1 ulp
         for (int p = tid; p < npix; p += FAST_NT) {
             int py = (int)(((float)p + 0.5f) * rcp_iw), px = p - py * iw;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
@@ -208,6 +236,10 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         LDS_BARRIER();                                           // S1
         if (tid == 0) n_out = 0;                                 // everyone has left the previous cell's emit
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 2
+        if (tid == 0) *cnt = n_maybe;
+        continue;
+#endif
         // ---- pass 2 (maybe pixels): 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits
         const int nm = n_maybe;
         for (int i = tid; i < nm; i += FAST_NT) {
@@ -216,12 +248,14 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
             int v = ctr[0];
             int lo = v - t, hi = v + t;
+            // one subtract + one v_alignbit per ring pixel and polarity: the sign bit of (r - lo) / (hi - r) is shifted into the mask
+            // (bit order comes out reversed, which a cyclic run test does not care about)
             uint32_t mdark = 0, mbright = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                int r = ctr[RO[k]];
-                mdark |= (uint32_t)(r < lo) << k;
-                mbright |= (uint32_t)(r > hi) << k;
+                const int r = ctr[RO[k]];
+                mdark = __builtin_amdgcn_alignbit(mdark, (uint32_t)(r - lo), 31);
+                mbright = __builtin_amdgcn_alignbit(mbright, (uint32_t)(hi - r), 31);
             }
             uint32_t m = mdark | (mdark << 16);
             uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
@@ -234,6 +268,10 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         }
         LDS_BARRIER();                                           // S2
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 3
+        if (tid == 0) *cnt = n_corner;
+        continue;
+#endif
         // ---- pass 3 (corners): corner score
         const int nc = n_corner;
         for (int i = tid; i < nc; i += FAST_NT) {
@@ -248,6 +286,11 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         }
         LDS_BARRIER();                                           // S3
 
+#if defined(FAST_ABLATE) && FAST_ABLATE == 4
+        if (tid == 0) *cnt = 0;
+        { const int ncc = n_corner; for (int i = tid; i < ncc; i += FAST_NT) { int pos = clist[i]; score[((pos >> 8) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0; } }
+        continue;
+#endif
         // ---- pass 4: 3x3 strict NMS inside the cell
         for (int i = tid; i < nc; i += FAST_NT) {
             int pos = clist[i];

@@ -99,3 +99,18 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
         else hipLaunchKernelGGL(k_resize_level<false>, grid, block, 0, s, d_lv, l, img0);
     }
 }
+
+// ---- calibration kernels of known HBM traffic (hs_debug_stream_copy): one dword / one 16-byte vector per lane, grid-stride
+__global__ __launch_bounds__(256) void k_copy_u32(uint32_t* __restrict__ d, const uint32_t* __restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void k_copy_u128(uint4* __restrict__ d, const uint4* __restrict__ s, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s)
+{
+    if (width == 4) hipLaunchKernelGGL(k_copy_u32, dim3(2048), dim3(256), 0, s, (uint32_t*)d_dst, (const uint32_t*)d_src, bytes / 4);
+    else hipLaunchKernelGGL(k_copy_u128, dim3(2048), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)d_src, bytes / 16);
+}

@@ -206,6 +206,10 @@ int  hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t
 int  hs_orb_profile_begin(hs_orb* h);
 int  hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches);
 
+/* Measurement utility: streams `bytes` from d_src to d_dst with `width` (4 or 16) bytes per lane — a kernel of KNOWN HBM traffic
+ * in this library's own access widths, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py). */
+int  hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes, int width, void* stream);
+
 /* ---- stage taps for parity tests (host outputs; synchronous; valid after an extract call) ---- */
 /* pyramid level `level` of image `image` of the last batch: tight w*h bytes; ORBExtractor::ComputePyramid :564-589 */
 int  hs_orb_debug_level(hs_orb* h, int image, int level, uint8_t* out, size_t cap_bytes, int32_t* lw, int32_t* lh);
