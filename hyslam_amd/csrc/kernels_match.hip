@@ -87,7 +87,29 @@ __device__ __forceinline__ void wave_best2(unsigned long long& best, int& second
 #define NO_KEY 0x7FFFFFFFFFFFFFFFull
 #define NO_DIST 0x7FFFFFFF
 
-__global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const hs_landmark* __restrict__ lms, int L, hs_proj_params pp,
+struct HsProjDev : hs_proj_params { float cos_view_angle; };   // cosf(max_view_angle), evaluated on the host like the reference does
+
+// Fuse: fuse_matches.insert(idx, lm) — the first landmark (array order) that matched a keypoint keeps it
+__global__ __launch_bounds__(1024) void k_first_wins(int n, int32_t* __restrict__ match, int32_t* __restrict__ winner, int n_keys, int32_t* __restrict__ n_out)
+{
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    if (tid == 0) total = 0;
+    for (int k = tid; k < n_keys; k += 1024) winner[k] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) if (match[i] >= 0) atomicMin(&winner[match[i]], i);
+    __syncthreads();
+    int kept = 0;
+    for (int i = tid; i < n; i += 1024) {
+        if (match[i] < 0) continue;
+        if (winner[match[i]] != i) match[i] = -1; else kept++;
+    }
+    atomicAdd(&total, kept);
+    __syncthreads();
+    if (tid == 0) *n_out = total;
+}
+
+__global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const hs_landmark* __restrict__ lms, int L, HsProjDev pp,
                                                            int32_t* __restrict__ match_idx, float* __restrict__ match_dist)
 {
     const int lane = threadIdx.x & 63;
@@ -102,6 +124,17 @@ __global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const h
         const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
         const float dist = (float)sqrt(n2);
         if (dist < __fmul_rn(0.8f, lm.min_dist) || dist > __fmul_rn(1.2f, lm.max_dist)) ok = false;
+    }
+    if (ok && pp.use_viewing_angle) {                                                               // ViewingAngleCriterionCore
+        const float ox = __fsub_rn(lm.pos[0], F.Ow[0]), oy = __fsub_rn(lm.pos[1], F.Ow[1]), oz = __fsub_rn(lm.pos[2], F.Ow[2]);
+        const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
+        const float distance = (float)sqrt(n2);
+        const double alpha = __ddiv_rn(1.0, (double)distance);
+        double dot = 0.0;
+        dot = __dadd_rn(dot, __dmul_rn((double)(float)__dmul_rn((double)ox, alpha), (double)lm.normal[0]));
+        dot = __dadd_rn(dot, __dmul_rn((double)(float)__dmul_rn((double)oy, alpha), (double)lm.normal[1]));
+        dot = __dadd_rn(dot, __dmul_rn((double)(float)__dmul_rn((double)oz, alpha), (double)lm.normal[2]));
+        if (!(dot > (double)pp.cos_view_angle)) ok = false;
     }
     if (ok) {
         // landMarkSizePixels
@@ -133,9 +166,19 @@ __global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const h
                 if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;           // also drops cx == -1
                 const hs_keypoint kp = F.kps[i];
                 if (!(fabsf(__fsub_rn(kp.x, u)) < r && fabsf(__fsub_rn(kp.y, v)) < r)) continue;
-                if (F.kp_lm_obs && F.kp_lm_obs[i] > 0) continue;                               // PreviouslyMatchedCriterionCore
+                if (pp.use_prev_matched && F.kp_lm_obs && F.kp_lm_obs[i] > 0) continue;        // PreviouslyMatchedCriterionCore
                 if (!(kp.size > smin && kp.size < smax)) continue;                              // FeatureSizeCriterionCore
                 if (stereo) { const float urv = F.uR[i]; if (!(fabsf(__fsub_rn(ur, urv)) < r && urv > 0.f)) continue; }
+                if (pp.use_reprojection) {                                                      // ProjectionViewCriterion + KeyFrame::ReprojectionError
+                    const float ex = __fsub_rn(u, kp.x), ey = __fsub_rn(v, kp.y);
+                    const float urv = F.uR ? F.uR[i] : -1.f;
+                    const float er = urv >= 0.0f ? __fsub_rn(ur, urv) : 0.0f;
+                    const float err = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                    const float sf = __fdiv_rn(kp.size, F.size_ref);
+                    const float sigma = __fmul_rn(pp.sigma_ref, __fmul_rn(sf, sf));
+                    const float stereo_factor = urv > 0.f ? 1.30f : 1.00f;
+                    if (!(__fdiv_rn(err, sigma) < __fmul_rn(stereo_factor, pp.reproj_threshold))) continue;
+                }
                 const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F.desc + (size_t)i * 32);
                 const int d = __popcll(l0 ^ dk[0]) + __popcll(l1 ^ dk[1]) + __popcll(l2 ^ dk[2]) + __popcll(l3 ^ dk[3]);
                 const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned)i;
@@ -300,8 +343,11 @@ void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kp
     D.fx = F.fx; D.fy = F.fy; D.cx = F.cx; D.cy = F.cy; D.mbf = F.mbf; D.sensor = F.sensor;
     D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.size_ref = F.size_ref; D.n = F.n;
     D.kps = d_kps; D.desc = d_desc; D.uR = d_uR; D.kp_lm_obs = d_obs; D.cell = d_cell;
-    hipLaunchKernelGGL(k_search_projection, dim3((L + 3) / 4), dim3(256), 0, s, D, d_lms, L, pp, d_match_idx, d_match_dist);
-    if (pp.check_rotation) {
+    HsProjDev P; static_cast<hs_proj_params&>(P) = pp; P.cos_view_angle = cosf(pp.max_view_angle);
+    hipLaunchKernelGGL(k_search_projection, dim3((L + 3) / 4), dim3(256), 0, s, D, d_lms, L, P, d_match_idx, d_match_dist);
+    if (pp.first_wins) {
+        hipLaunchKernelGGL(k_first_wins, dim3(1), dim3(1024), 0, s, L, d_match_idx, d_winner, F.n, d_n_matches);
+    } else if (pp.check_rotation) {
         // prev_angle lives inside the landmark records; the filter wants a flat float array per entry
         hipMemcpy2DAsync(d_prev_angle_scratch, sizeof(float), reinterpret_cast<const uint8_t*>(d_lms) + offsetof(hs_landmark, prev_angle),
                          sizeof(hs_landmark), sizeof(float), L, hipMemcpyDeviceToDevice, s);

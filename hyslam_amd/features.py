@@ -254,6 +254,13 @@ class FeatureMatcher:
         landmarks = pKF's map points minus sAlreadyFound.  Its rotation criterion is a no-op in the reference (no previous frame)."""
         return self._project(frame, landmarks, N.ProjParams(th, float(ORBdist), 1.0, 0.5, 1.5, 1, 0, 0))
 
+    def Fuse(self, keyframe, landmarks, th=3.0, reprojection_err=5.99):
+        """Fuse(pKF, vpMapPoints, fuse_matches, th, reprojection_err) (FeatureMatcher.cc:464-521).  The caller sets skip = 1 on landmarks
+        that are bad, already observed in pKF or protected (:480-485).  Returns per-landmark keypoint indices (first landmark per keypoint)."""
+        return self._project(keyframe, landmarks, N.ProjParams(th, self.TH_LOW, 1.0, 0.5, 1.5, use_distance=1, use_stereo=0, check_rotation=0,
+                                                               use_prev_matched=0, use_viewing_angle=1, max_view_angle=1.047,
+                                                               use_reprojection=1, reproj_threshold=reprojection_err, sigma_ref=1.0, first_wins=1))
+
     def SearchByBoW(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, check_rotation=True):
         """The matching core of SearchByBoW / SearchByBoW2 (FeatureMatcher.cc:216-371).  featvec = (node_id, node_ptr, idx) CSR arrays."""
         ex = self._ex

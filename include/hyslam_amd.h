@@ -168,11 +168,20 @@ typedef struct hs_proj_params {
     int32_t use_distance;              /* DistanceCriterion among the landmark criteria                 */
     int32_t use_stereo;                /* StereoConsistencyCriterion(th)                                */
     int32_t check_rotation;            /* RotationConsistencyCriterion (uses prev_angle)                */
+    int32_t use_prev_matched;          /* PreviouslyMatchedCriterion (all Frame variants; not Fuse)     */
+    int32_t use_viewing_angle;         /* ViewingAngleCriterion(max_view_angle): Fuse, FeatureMatcher.cc:469 */
+    float   max_view_angle;            /* radians (1.047)                                               */
+    int32_t use_reprojection;          /* ProjectionViewCriterion(reproj_threshold): Fuse, :473         */
+    float   reproj_threshold;          /* 5.99                                                          */
+    float   sigma_ref;                 /* FeatureExtractorSettings::sigma_ref (1.0), determineSigma2    */
+    int32_t first_wins;                /* Fuse: the first landmark that matched a keypoint keeps it (:515) */
 } hs_proj_params;
 
 /* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria of SearchByProjection(Frame, MapPoints, th)
  * (:123-143: use_distance=1,use_stereo=1,check_rotation=0), (CurrentFrame, LastFrame, th, bMono) (:145-176: 0,1,1) and
- * (CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:180-212: 1,0,0, ratio 1.0).  match_idx[L] = keypoint index or -1,
+ * (CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (:180-212: 1,0,0, ratio 1.0), and of Fuse(pKF, MapPoints, matches, th, err)
+ * (:464-521: distance + viewing angle, size + reprojection + best score TH_LOW/1.0, first landmark per keypoint wins; the caller
+ * marks bad / already-observed / protected landmarks with skip = 1).  match_idx[L] = keypoint index or -1,
  * match_dist[L] = Hamming distance of the match, *n_matches = matches.size(). */
 int  hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
                              int32_t* match_idx, float* match_dist, int32_t* n_matches);

@@ -170,6 +170,13 @@ typedef struct hso_proj_params {
     int32_t use_distance;              /* DistanceCriterion in the landmark criteria */
     int32_t use_stereo;                /* StereoConsistencyCriterion(th) */
     int32_t check_rotation;            /* RotationConsistencyCriterion (needs prev_angle) */
+    int32_t use_prev_matched;          /* PreviouslyMatchedCriterion (all Frame variants; not Fuse) */
+    int32_t use_viewing_angle;         /* ViewingAngleCriterion(max_view_angle) — Fuse, FeatureMatcher.cc:469 */
+    float   max_view_angle;            /* radians (1.047) */
+    int32_t use_reprojection;          /* ProjectionViewCriterion(reproj_threshold) — Fuse, :473 */
+    float   reproj_threshold;          /* 5.99 */
+    float   sigma_ref;                 /* FeatureExtractorSettings::sigma_ref (1.0) for determineSigma2 */
+    int32_t first_wins;                /* Fuse: fuse_matches.insert(idx, lm) keeps the FIRST landmark that matched a keypoint (:515) */
 } hso_proj_params;
 
 /* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria lists of the three Frame variants

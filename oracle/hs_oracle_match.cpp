@@ -190,6 +190,20 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
         }
         cand_lms.swap(passed);
     }
+    if (pp->use_viewing_angle) {                                                     // ViewingAngleCriterionCore :94-110
+        std::vector<int> passed;
+        const float thr = std::cos(pp->max_view_angle);                              // <math.h> in C++: the float overload
+        for (int i : cand_lms) {
+            const hso_landmark& lm = lms[i];
+            float PO[3] = { lm.pos[0] - F->Ow[0], lm.pos[1] - F->Ow[1], lm.pos[2] - F->Ow[2] };
+            const float distance = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+            const double alpha = 1.0 / (double)distance;                             // PO = PO/distance: cv::Mat scaled by 1/s
+            double dot = 0;
+            for (int k = 0; k < 3; k++) dot += (double)(float)((double)PO[k] * alpha) * (double)lm.normal[k];   // Mat::dot accumulates in double
+            if (dot > thr) passed.push_back(i);
+        }
+        cand_lms.swap(passed);
+    }
     // ---- per landmark: candidate views and view criteria (:77-103)
     std::map<int, SingleMatchData> matches;   // key: landmark array index (stands in for MapPoint*; D6)
     for (int li : cand_lms) {
@@ -200,7 +214,7 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
         const float sizePx = frame.landMarkSizePixels(lm);
         const float radius = pp->th * sizePx / F->size_ref;
         std::vector<size_t> cand = frame.GetFeaturesInAreaNEW(u, v, radius);
-        {   // PreviouslyMatchedCriterionCore :124-144
+        if (pp->use_prev_matched) {   // PreviouslyMatchedCriterionCore :124-144
             std::vector<size_t> passed;
             for (size_t idx : cand) { bool save = true; if (F->kp_lm_obs && F->kp_lm_obs[idx] >= 0 && F->kp_lm_obs[idx] > 0) save = false; if (save) passed.push_back(idx); }
             cand.swap(passed);
@@ -214,6 +228,25 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
             std::vector<size_t> passed;
             const float radius2 = pp->th * sizePx / F->size_ref;
             for (size_t idx : cand) { float ur_view = F->uR[idx]; const float er = std::fabs(ur - ur_view); if (er < radius2 && ur_view > 0) passed.push_back(idx); }
+            cand.swap(passed);
+        }
+        if (pp->use_reprojection) {   // ProjectionViewCriterion :285-307 with KeyFrame::ReprojectionError (KeyFrame.cc:548-573)
+            std::vector<size_t> passed;
+            for (size_t idx : cand) {
+                float reproj_err;
+                {
+                    const hso_keypoint& kpt = F->kps[idx];
+                    float errX = u - kpt.x, errY = v - kpt.y, errXr = 0.000f;
+                    float ur_view = F->uR ? F->uR[idx] : -1.f;
+                    if (ur_view >= 0.0) errXr = ur - ur_view;
+                    reproj_err = errX * errX + errY * errY + errXr * errXr;        // the landmark projects (it passed ProjectionCriterion)
+                }
+                float scale_factor = F->kps[idx].size / F->size_ref;                // determineSigma2, FeatureExtractorSettings.cpp:5-8
+                float sigma_size_corrected = pp->sigma_ref * (scale_factor * scale_factor);
+                float stereo_factor = 1.00;
+                if (F->uR && F->uR[idx] > 0) stereo_factor = 1.30;
+                if ((reproj_err / sigma_size_corrected) < stereo_factor * pp->reproj_threshold) passed.push_back(idx);
+            }
             cand.swap(passed);
         }
         // BestScoreCriterionCore :248-280 + accept rule :214-230
@@ -238,6 +271,13 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
                                                 [&](size_t li) { return lms[li].prev_angle; });
         std::map<int, SingleMatchData> alt;
         for (auto& p : passed) { int li = inverse[p.first]; alt[li] = matches[li]; }
+        matches.swap(alt);
+    }
+    if (pp->first_wins) {   // Fuse: std::map<idx, MapPoint*>::insert keeps the first landmark (in candidate order) per keypoint
+        std::map<int, int> owner;
+        for (auto& m : matches) owner.insert(std::make_pair(m.second.idx, m.first));
+        std::map<int, SingleMatchData> alt;
+        for (auto& o : owner) alt[o.second] = matches[o.second];
         matches.swap(alt);
     }
     for (auto& m : matches) { match_idx[m.first] = m.second.idx; match_dist[m.first] = m.second.distance; }

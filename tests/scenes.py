@@ -41,7 +41,7 @@ def projection_scene(seed, w=640, h=480, nfeat=1000, copies=3, sensor=1, fx=500.
         dist = np.linalg.norm(Pw - Ow, axis=1)
         lms["min_dist"][sl] = (dist * rng.uniform(0.3, 1.1, n)).astype(np.float32)       # some fail the 0.8*min test
         lms["max_dist"][sl] = (dist * rng.uniform(0.9, 3.0, n)).astype(np.float32)       # some fail the 1.2*max test
-        nrm = (Ow - Pw) / dist[:, None]
+        nrm = (Pw - Ow) / dist[:, None]                                 # mean viewing direction: camera -> point (MapPoint::UpdateNormalAndDepth)
         lms["normal"][sl] = nrm.astype(np.float32)
         dd = desc.copy()
         flips = rng.integers(0, 30 if c else 8, n)

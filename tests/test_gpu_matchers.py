@@ -50,6 +50,21 @@ def test_c4_projection_50k_landmarks_1080p(matcher):
     assert gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
 
 
+def test_fuse(matcher):
+    sc = scenes.projection_scene(39, 640, 480, nfeat=1000, copies=4)
+    Fo, Fg, keep = both_views(sc)
+    lms = sc["lms"].copy()
+    lms["normal"][::5] *= -1
+    lms["skip"][::11] = 1                                      # bad / already in the keyframe / protected (FeatureMatcher.cc:480-485)
+    gi, gd, gn = matcher.Fuse(Fg, lms, 3.0, 5.99)
+    pp = oracle.ProjParams(3.0, 50.0, 1.0, 0.5, 1.5, use_distance=1, use_stereo=0, check_rotation=0, use_prev_matched=0,
+                           use_viewing_angle=1, max_view_angle=1.047, use_reprojection=1, reproj_threshold=5.99, sigma_ref=1.0, first_wins=1)
+    oi, od, on = oracle.search_by_projection(Fo, lms, pp)
+    assert on > 200 and gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
+    kept = gi[gi >= 0]
+    assert len(np.unique(kept)) == len(kept)
+
+
 def test_projection_edge_cases(matcher):
     sc = scenes.projection_scene(35, 320, 240, nfeat=300, copies=1, fx=260.0)
     Fo, Fg, keep = both_views(sc)

@@ -96,6 +96,12 @@ def py_search_by_projection(fa, lms, pp):
             dist = f32(np.sqrt(((lm["pos"] - Ow).astype(np.float64) ** 2).sum()))
             if dist < f32(0.8) * lm["min_dist"] or dist > f32(1.2) * lm["max_dist"]:
                 continue
+        if pp.use_viewing_angle:
+            po = (lm["pos"] - Ow).astype(f32)
+            dist = f32(np.sqrt((po.astype(np.float64) ** 2).sum()))
+            pon = (po.astype(np.float64) * (1.0 / np.float64(dist))).astype(f32)
+            if not (float((pon.astype(np.float64) * lm["normal"].astype(np.float64)).sum()) > float(f32(np.cos(f32(pp.max_view_angle))))):
+                continue
         if lm["assoc_kp"] >= 0:
             size = kps["size"][lm["assoc_kp"]]
         else:
@@ -105,7 +111,16 @@ def py_search_by_projection(fa, lms, pp):
         x0 = max(0, int(np.floor(f32(f32(f32(u - minx) - r) * invW)))); x1 = min(63, int(np.ceil(f32(f32(f32(u - minx) + r) * invW))))
         y0 = max(0, int(np.floor(f32(f32(f32(v - miny) - r) * invH)))); y1 = min(47, int(np.ceil(f32(f32(f32(v - miny) + r) * invH))))
         m = ingrid & (gx >= x0) & (gx <= x1) & (gy >= y0) & (gy <= y1) & (np.abs(kps["x"] - u) < r) & (np.abs(kps["y"] - v) < r)
-        m &= ~(obs > 0)
+        if pp.use_prev_matched:
+            m &= ~(obs > 0)
+        if pp.use_reprojection:
+            ex, ey = (u - kps["x"]).astype(f32), (v - kps["y"]).astype(f32)
+            er = np.where(uR >= 0, (ur - uR).astype(f32), f32(0)).astype(f32)
+            err = ((ex * ex).astype(f32) + (ey * ey).astype(f32)).astype(f32) + (er * er).astype(f32)
+            sf = (kps["size"] / f32(31)).astype(f32)
+            sigma = (f32(pp.sigma_ref) * (sf * sf).astype(f32)).astype(f32)
+            factor = np.where(uR > 0, f32(1.30), f32(1.00)).astype(f32)
+            m &= (err / sigma).astype(f32) < (factor * f32(pp.reproj_threshold)).astype(f32)
         m &= (kps["size"] > f32(pp.frac_smaller) * size) & (kps["size"] < f32(pp.frac_larger) * size)
         if pp.use_stereo and fa["sensor"] != 0:
             m &= (np.abs(ur - uR) < r) & (uR > 0)
@@ -118,6 +133,12 @@ def py_search_by_projection(fa, lms, pp):
         second = np.sort(d)[1] if len(d) > 1 else np.finfo(np.float32).max
         if d[b] <= pp.score_threshold and not (f32(d[b]) > f32(pp.second_best_ratio) * f32(second)):
             out[li] = (int(cand[b]), float(d[b]))
+    if pp.first_wins:
+        seen, keep = set(), {}
+        for li in sorted(out):
+            if out[li][0] not in seen:
+                seen.add(out[li][0]); keep[li] = out[li]
+        out = keep
     return out
 
 
@@ -131,6 +152,21 @@ def test_projection_search_against_python_restatement():
         got = {int(i): (int(midx[i]), float(mdist[i])) for i in np.nonzero(midx >= 0)[0]}
         assert n == len(got) > 50
         assert got == ref
+
+
+def test_fuse_against_python_restatement():
+    sc = scenes.projection_scene(24, 320, 240, nfeat=400, copies=3, fx=260.0)
+    F, keep = oracle.make_frame_view(oracle.FrameView, **sc["frame_args"])
+    pp = oracle.ProjParams(3.0, 50.0, 1.0, 0.5, 1.5, use_distance=1, use_stereo=0, check_rotation=0, use_prev_matched=0,
+                           use_viewing_angle=1, max_view_angle=1.047, use_reprojection=1, reproj_threshold=5.99, sigma_ref=1.0, first_wins=1)
+    lms = sc["lms"].copy()
+    lms["normal"][::7] *= -1                                   # seen from behind: fails the 60 degree viewing-angle test
+    midx, mdist, n = oracle.search_by_projection(F, lms, pp)
+    ref = py_search_by_projection(sc["frame_args"], lms, pp)
+    got = {int(i): (int(midx[i]), float(mdist[i])) for i in np.nonzero(midx >= 0)[0]}
+    assert n == len(got) > 50 and got == ref
+    assert len(set(v[0] for v in got.values())) == len(got)     # one landmark per keypoint
+    assert (midx[::7] < 0).all()
 
 
 def test_projection_rotation_check_drops_duplicates_and_outlier_bins():
