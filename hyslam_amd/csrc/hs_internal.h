@@ -89,7 +89,8 @@ void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kp
                                  int32_t* d_n_matches, hipStream_t s);
 void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
                    const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
-                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, float thr, float ratio,
+                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, const uint8_t* d_keep2,
+                   const float* F12, float size_ref, float sigma_ref, float thr, float ratio,
                    int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);

@@ -269,13 +269,16 @@ __global__ void k_count_matches(int n, const int32_t* __restrict__ match, int32_
     if (threadIdx.x == 0) *n_out = total;
 }
 
+struct HsEpi { int32_t on; float F[9]; float size_ref, sigma_ref; };   // EpipolarConsistencyBoWCriterion (SearchForTriangulation)
+
 // One workgroup per vocabulary node shared by both feature vectors; one wavefront per side-1 index, lanes over the node's side-2 list.
 __global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ pair_a, const int32_t* __restrict__ pair_b,
                                                    const int32_t* __restrict__ ptr1, const int32_t* __restrict__ idx1,
                                                    const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2,
                                                    const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
-                                                   const uint8_t* __restrict__ keep1, float score_threshold, float ratio,
-                                                   int32_t* __restrict__ match12)
+                                                   const uint8_t* __restrict__ keep1, const uint8_t* __restrict__ keep2,
+                                                   HsEpi epi, const hs_keypoint* __restrict__ kps1, const hs_keypoint* __restrict__ kps2,
+                                                   float score_threshold, float ratio, int32_t* __restrict__ match12)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int a = pair_a[blockIdx.x], b = pair_b[blockIdx.x];
@@ -285,8 +288,26 @@ __global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ p
         if (keep1 && !keep1[i1]) continue;                                   // PreviouslyMatchedIndexCriterion
         const unsigned long long* d1 = reinterpret_cast<const unsigned long long*>(desc1 + (size_t)i1 * 32);
         unsigned long long best = NO_KEY; int second = NO_DIST;
+        float ea = 0.f, eb = 0.f, ec = 0.f;
+        if (epi.on) {   // epipolar line of kp1 in image 2: l = x1' F12 (MatchCriteria.cpp:661-663)
+            const float x1 = kps1[i1].x, y1 = kps1[i1].y;
+            ea = __fadd_rn(__fadd_rn(__fmul_rn(x1, epi.F[0]), __fmul_rn(y1, epi.F[3])), epi.F[6]);
+            eb = __fadd_rn(__fadd_rn(__fmul_rn(x1, epi.F[1]), __fmul_rn(y1, epi.F[4])), epi.F[7]);
+            ec = __fadd_rn(__fadd_rn(__fmul_rn(x1, epi.F[2]), __fmul_rn(y1, epi.F[5])), epi.F[8]);
+        }
         for (int q = q0 + lane; q < q1; q += 64) {
             const int i2 = idx2[q];
+            if (keep2 && !keep2[i2]) continue;
+            if (epi.on) {
+                const hs_keypoint k2 = kps2[i2];
+                const float num = __fadd_rn(__fadd_rn(__fmul_rn(ea, k2.x), __fmul_rn(eb, k2.y)), ec);
+                const float den = __fadd_rn(__fmul_rn(ea, ea), __fmul_rn(eb, eb));
+                if (den == 0.f) continue;
+                const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                const float sf = __fdiv_rn(k2.size, epi.size_ref);
+                const float sigma2 = __fmul_rn(epi.sigma_ref, __fmul_rn(sf, sf));
+                if (!((double)dsqr < __dmul_rn(3.84, (double)sigma2))) continue;
+            }
             const int d = hamming256(d1, reinterpret_cast<const unsigned long long*>(desc2 + (size_t)i2 * 32));
             const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(q - q0);     // list order breaks ties
             if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
@@ -375,14 +396,17 @@ __global__ void k_mask_by(int n, const int32_t* __restrict__ self, int32_t* __re
 
 void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
                    const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
-                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, float thr, float ratio,
+                   const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, const uint8_t* d_keep2,
+                   const float* F12, float size_ref, float sigma_ref, float thr, float ratio,
                    int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s)
 {
+    HsEpi epi{}; epi.on = F12 != nullptr; epi.size_ref = size_ref; epi.sigma_ref = sigma_ref;
+    if (F12) for (int i = 0; i < 9; i++) epi.F[i] = F12[i];
     hipMemsetAsync(d_match12, 0xFF, (size_t)n1 * 4, s);
     if (n_pairs > 0)
         hipLaunchKernelGGL(k_bow_match, dim3(n_pairs), dim3(256), 0, s, d_pair_a, d_pair_b, d_ptr1, d_idx1, d_ptr2, d_idx2, d_desc1, d_desc2,
-                           d_keep1, thr, ratio, d_match12);
+                           d_keep1, d_keep2, epi, d_kps1, d_kps2, thr, ratio, d_match12);
     if (check_rotation && n1 > 0) {
         // RotationConsistencyBoW::apply(matches, views1, views2): rot = angle2[match] - angle1[i]; entries are keyed by side-1 index (unique)
         const int g = (n1 + 255) / 256;

@@ -261,7 +261,14 @@ class FeatureMatcher:
                                                                use_prev_matched=0, use_viewing_angle=1, max_view_angle=1.047,
                                                                use_reprojection=1, reproj_threshold=reprojection_err, sigma_ref=1.0, first_wins=1))
 
-    def SearchByBoW(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, check_rotation=True):
+    def SearchForTriangulation(self, kps1, desc1, featvec1, kps2, desc2, featvec2, F12, keep1=None, keep2=None, size_ref=31.0, sigma_ref=1.0):
+        """The matching core of SearchForTriangulation (FeatureMatcher.cc:373-402): keep1/keep2 = keypoints WITHOUT a landmark (and with a
+        stereo observation when bOnlyStereo), epipolar gate with F12, best match under TH_LOW with ratio 1.0, rotation check."""
+        return self.SearchByBoW(kps1, desc1, featvec1, kps2, desc2, featvec2, keep1, True, keep2=keep2, F12=F12, ratio=1.0,
+                                size_ref=size_ref, sigma_ref=sigma_ref)
+
+    def SearchByBoW(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, check_rotation=True, keep2=None, F12=None, ratio=None,
+                    size_ref=31.0, sigma_ref=1.0):
         """The matching core of SearchByBoW / SearchByBoW2 (FeatureMatcher.cc:216-371).  featvec = (node_id, node_ptr, idx) CSR arrays."""
         ex = self._ex
         k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
@@ -269,12 +276,15 @@ class FeatureMatcher:
         a = [np.ascontiguousarray(x, np.int32) for x in featvec1]
         b = [np.ascontiguousarray(x, np.int32) for x in featvec2]
         keep = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+        kp2 = None if keep2 is None else np.ascontiguousarray(keep2, np.uint8)
+        Fm = None if F12 is None else np.ascontiguousarray(F12, np.float32).reshape(9)
         m = np.full(len(k1), -1, np.int32)
         n = C.c_int32()
-        p = lambda x: x.ctypes.data_as(C.c_void_p)
-        N.check(ex._h, ex._lib.hs_search_by_bow(ex._h, p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
-                                                p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
-                                                None if keep is None else p(keep), self.TH_LOW, self.mfNNratio, int(check_rotation), p(m), C.byref(n)))
+        p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_by_bow_ex(ex._h, p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                                   p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                                   p(keep), p(kp2), p(Fm), size_ref, sigma_ref, self.TH_LOW,
+                                                   self.mfNNratio if ratio is None else ratio, int(check_rotation), p(m), C.byref(n)))
         return m, n.value
 
     def HammingKnn2(self, query, train):

@@ -197,6 +197,16 @@ int  hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, 
                       const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int n_nodes2,
                       const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation,
                       int32_t* match12, int32_t* n_matches);
+/* the same with the index criteria on BOTH sides (keep2, may be NULL: _SearchByBoW_, FeatureMatcher.cc:306-309) and, when F12 (row-major
+ * 3x3, may be NULL) is given, EpipolarConsistencyBoWCriterion (MatchCriteria.cpp:641-676: dsqr < 3.84*sigma2(kp2.size)) ahead of the
+ * best-match criterion — the core of SearchForTriangulation (FeatureMatcher.cc:373-402; threshold TH_LOW, ratio 1.0). */
+int  hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                         const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int n_nodes1,
+                         const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                         const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int n_nodes2,
+                         const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
+                         float score_threshold, float second_best_ratio, int check_rotation,
+                         int32_t* match12, int32_t* n_matches);
 
 /* brute-force Hamming 2-NN (cross-camera matching without a vocabulary): for each of nq query descriptors the first-minimum
  * train index, its distance and the second-smallest distance (-1 when absent). */

@@ -191,6 +191,12 @@ void hso_frame_grid(const hso_frame_view* F, int32_t* cell_xy);
 int hso_search_by_bow(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
                       const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
                       const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12);
+/* the same with the index criteria applied to BOTH sides (keep1, keep2: _SearchByBoW_, FeatureMatcher.cc:306-309) and, when F12 != NULL,
+ * EpipolarConsistencyBoWCriterion (MatchCriteria.cpp:641-676) ahead of the best-match criterion: SearchForTriangulation (:373-402) */
+int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                         const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                         const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
+                         float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12);
 /* brute-force Hamming 2-NN of every query against every train descriptor: best index, best and second-best distance
  * (first minimum wins, like every best/second-best loop of the reference, e.g. MatchCriteria.cpp:248-280) */
 void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);

@@ -284,9 +284,31 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
     return (int)matches.size();
 }
 
+// EpipolarConsistencyBoWCriterion::CheckDistEpipolarLine, MatchCriteria.cpp:658-676
+static bool CheckDistEpipolarLine(const hso_keypoint& kp1, const hso_keypoint& kp2, const float* F12, float sigma2)
+{
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
 int hso_search_by_bow(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
                       const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
                       const uint8_t* keep1, float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12)
+{
+    return hso_search_by_bow_ex(kps1, desc1, n1, node_id1, node_ptr1, idx1, nn1, kps2, desc2, n2, node_id2, node_ptr2, idx2, nn2,
+                                keep1, nullptr, nullptr, 31.f, 1.f, score_threshold, second_best_ratio, check_rotation, match12);
+}
+
+int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                         const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                         const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
+                         float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12)
 {
     (void)n2;
     for (int i = 0; i < n1; i++) match12[i] = -1;
@@ -301,6 +323,12 @@ int hso_search_by_bow(const hso_keypoint* kps1, const uint8_t* desc1, int n1, co
                 int bestIdx2 = -1;
                 for (int q = node_ptr2[b]; q < node_ptr2[b + 1]; q++) {   // BestMatchBoWCriterion :601-635
                     const int i2 = idx2[q];
+                    if (keep2 && !keep2[i2]) continue;             // index criteria on side 2 (:308)
+                    if (F12) {                                      // EpipolarConsistencyBoWCriterion::apply :645-657
+                        float scale_factor = kps2[i2].size / size_ref;
+                        float sigma_size_corrected = sigma_ref * (scale_factor * scale_factor);
+                        if (!CheckDistEpipolarLine(kps1[i1], kps2[i2], F12, sigma_size_corrected)) continue;
+                    }
                     const float dist = ORBDistance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
                     if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
                     else if (dist < bestDist2) bestDist2 = dist;

@@ -298,18 +298,21 @@ def frame_grid(F):
     return out
 
 
-def search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, thr, ratio, check_rotation):
+def search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, thr, ratio, check_rotation, keep2=None, F12=None, size_ref=31.0, sigma_ref=1.0):
     """fv = (node_id, node_ptr, idx) int32 arrays (CSR feature vector)."""
     k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
     d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
     a = [np.ascontiguousarray(x, np.int32) for x in fv1]
     b = [np.ascontiguousarray(x, np.int32) for x in fv2]
     keep = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+    kp2 = None if keep2 is None else np.ascontiguousarray(keep2, np.uint8)
+    Fm = None if F12 is None else np.ascontiguousarray(F12, np.float32).reshape(9)
     m = np.full(len(k1), -1, np.int32)
-    p = lambda x: x.ctypes.data_as(C.c_void_p)
-    n = lib().hso_search_by_bow(p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
-                                p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
-                                None if keep is None else p(keep), C.c_float(thr), C.c_float(ratio), int(check_rotation), p(m))
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    n = lib().hso_search_by_bow_ex(p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                   p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                   p(keep), p(kp2), p(Fm), C.c_float(size_ref), C.c_float(sigma_ref),
+                                   C.c_float(thr), C.c_float(ratio), int(check_rotation), p(m))
     return m, n
 
 

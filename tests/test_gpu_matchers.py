@@ -101,6 +101,29 @@ def test_bow_grouped_search(matcher):
     assert gn == 0 and (gm == -1).all()
 
 
+def test_search_for_triangulation_core(matcher):
+    from hyslam_amd.synth import synth_stereo_pair
+    matcher = HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=0.8, TH_LOW=90.0), matcher._ex)
+    Limg, Rimg = synth_stereo_pair(41, 640, 480)
+    p = oracle.default_params(1000)
+    k1, d1 = oracle.extract(p, Limg)
+    k2, d2 = oracle.extract(p, Rimg)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    rng = np.random.default_rng(8)
+    for nodes in (7, 90):
+        fv1, fv2 = scenes.synthetic_featvec(d1, nodes, 13), scenes.synthetic_featvec(d2, nodes, 13)
+        keep1 = (rng.random(len(k1)) < 0.85).astype(np.uint8)
+        keep2 = (rng.random(len(k2)) < 0.85).astype(np.uint8)
+        gm, gn = matcher.SearchForTriangulation(k1, d1, fv1, k2, d2, fv2, F12, keep1, keep2)
+        om, on = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, 90.0, 1.0, True, keep2=keep2, F12=F12)
+        assert on > 15 and gn == on and np.array_equal(gm, om), nodes
+    # a general (non-degenerate) fundamental matrix
+    F12 = (rng.normal(0, 1, (3, 3)) * np.array([[1e-5, 1e-5, 1e-2], [1e-5, 1e-5, 1e-2], [1e-2, 1e-2, 1.0]])).astype(np.float32)
+    gm, gn = matcher.SearchForTriangulation(k1, d1, fv1, k2, d2, fv2, F12, None, None, 31.0, 4.0)
+    om, on = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, None, 90.0, 1.0, True, keep2=None, F12=F12, sigma_ref=4.0)
+    assert gn == on and np.array_equal(gm, om)
+
+
 def test_knn2(matcher):
     rng = np.random.default_rng(6)
     q = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
