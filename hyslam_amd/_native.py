@@ -38,6 +38,11 @@ class FrameView(C.Structure):
                 ("kps", C.c_void_p), ("desc", C.c_void_p), ("uR", C.c_void_p), ("kp_lm_obs", C.c_void_p)]
 
 
+class VocabTree(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("levels", C.c_int32), ("child_begin", C.c_void_p), ("child_count", C.c_void_p),
+                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
+
+
 class ProjParams(C.Structure):
     _fields_ = [("th", C.c_float), ("score_threshold", C.c_float), ("second_best_ratio", C.c_float),
                 ("frac_smaller", C.c_float), ("frac_larger", C.c_float),
@@ -64,7 +69,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
-    "hs_search_by_projection", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_hamming_knn2", "hs_hamming_knn2_device",
+    "hs_search_by_projection", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
@@ -112,6 +117,7 @@ def lib():
                                    vp, f32, f32, C.c_int, vp, vp]
     L.hs_search_by_bow_ex.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                       vp, vp, vp, f32, f32, f32, f32, C.c_int, vp, vp]
+    L.hs_bow_transform.argtypes = [vp, C.POINTER(VocabTree), vp, C.c_int, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     L.hs_debug_stream_copy.argtypes = [vp, vp, vp, sz, C.c_int, vp]

@@ -653,6 +653,42 @@ int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1
     return HS_OK;
 }
 
+int hs_bow_transform(hs_orb* h, const hs_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!T || n < 0 || T->n_nodes < 2 || T->levels < 1 || !T->child_begin || !T->child_count || !T->desc || !T->word_id || !T->weight ||
+        (n > 0 && (!desc || !word_id || !weight || !node_id)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    if (n == 0) return HS_OK;
+    // the walk must terminate inside the tree: children in range, the root has children
+    if (T->child_count[0] < 1) return fail(h, HS_ERR_INVALID, "vocabulary root has no children");
+    for (int i = 0; i < T->n_nodes; i++) {
+        const long cb = T->child_begin[i], cc = T->child_count[i];
+        if (cc < 0 || (cc > 0 && (cb <= i || cb + cc > T->n_nodes))) return fail(h, HS_ERR_INVALID, "vocabulary tree is not a forward-linked flat tree");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nn = T->n_nodes;
+    int rc = scratch_begin(h, pad256(nn * 4) * 3 + pad256(nn * 4) + pad256(nn * 32) + pad256((size_t)n * 32) + 3 * pad256((size_t)n * 4));
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    int32_t* d_cb = carve<int32_t>(h, nn); int32_t* d_cc = carve<int32_t>(h, nn); int32_t* d_w = carve<int32_t>(h, nn);
+    float* d_wt = carve<float>(h, nn); uint8_t* d_nd = carve<uint8_t>(h, nn * 32); uint8_t* d_d = carve<uint8_t>(h, (size_t)n * 32);
+    int32_t* o_w = carve<int32_t>(h, n); float* o_wt = carve<float>(h, n); int32_t* o_n = carve<int32_t>(h, n);
+    HIP_TRY(h, hipMemcpyAsync(d_cb, T->child_begin, nn * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_cc, T->child_count, nn * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_w, T->word_id, nn * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_wt, T->weight, nn * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_nd, T->desc, nn * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_d, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    hs_launch_bow_transform(n, d_d, d_cb, d_cc, d_nd, d_w, d_wt, T->levels, levelsup, o_w, o_wt, o_n, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(word_id, o_w, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(weight, o_wt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(node_id, o_n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
 int hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                            int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream)
 {

@@ -95,3 +95,5 @@ void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);
+void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, const int32_t* d_cc, const uint8_t* d_ndesc, const int32_t* d_word,
+                             const float* d_weight, int levels, int levelsup, int32_t* d_out_word, float* d_out_weight, int32_t* d_out_node, hipStream_t s);

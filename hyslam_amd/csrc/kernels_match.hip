@@ -424,3 +424,37 @@ void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int3
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, d_q, nq, d_t, nt, d_bi, d_bd, d_sd);
 }
+
+// DBoW2 transform: one lane per descriptor walks the tree (k children x L levels Hamming distances; the tree is L2-resident)
+__global__ __launch_bounds__(256) void k_bow_transform(int n, const uint8_t* __restrict__ desc, const int32_t* __restrict__ child_begin,
+                                                       const int32_t* __restrict__ child_count, const uint8_t* __restrict__ ndesc,
+                                                       const int32_t* __restrict__ nword, const float* __restrict__ nweight, int levels, int levelsup,
+                                                       int32_t* __restrict__ word_id, float* __restrict__ weight, int32_t* __restrict__ node_id)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(desc + (size_t)i * 32);
+    const unsigned long long f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    const int nid_level = levels - levelsup;
+    int final_id = 0, level = 0, nid = 0;
+    do {
+        ++level;
+        const int cb = child_begin[final_id], cc = child_count[final_id];
+        int best = 0x7FFFFFFF;
+        for (int c = cb; c < cb + cc; c++) {
+            const unsigned long long* d = reinterpret_cast<const unsigned long long*>(ndesc + (size_t)c * 32);
+            const int dist = __popcll(f0 ^ d[0]) + __popcll(f1 ^ d[1]) + __popcll(f2 ^ d[2]) + __popcll(f3 ^ d[3]);
+            if (dist < best) { best = dist; final_id = c; }      // strict: the first minimum wins
+        }
+        if (level == nid_level) nid = final_id;
+    } while (child_count[final_id] != 0 && level < 64);
+    word_id[i] = nword[final_id]; weight[i] = nweight[final_id]; node_id[i] = nid;
+}
+
+void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, const int32_t* d_cc, const uint8_t* d_ndesc, const int32_t* d_word,
+                             const float* d_weight, int levels, int levelsup, int32_t* d_out_word, float* d_out_weight, int32_t* d_out_node, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, s, n, d_desc, d_cb, d_cc, d_ndesc, d_word, d_weight, levels, levelsup,
+                       d_out_word, d_out_weight, d_out_node);
+}

@@ -296,6 +296,41 @@ class FeatureMatcher:
         return bi, bd, sd
 
 
+class ORBVocabulary:
+    """HYSLAM::ORBVocabulary::transform (src/features/low_level/ORBVocabulary.cpp:31-42) over a flat vocabulary tree
+    (_native.VocabTree; DBoW2 and ORBvoc are external to the reference).  `transform` returns the two containers Frame::ComputeBoW fills:
+    the BoW vector {word id: L1-normalised tf-idf weight} and the feature vector as CSR (node ids ascending, node_ptr, indices ascending)."""
+
+    def __init__(self, tree, extractor=None):
+        self.tree = tree
+        self._ex = extractor or ORBExtractor()
+
+    def transform(self, descriptors, levelsup=4):
+        ex = self._ex
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        w = np.zeros(n, np.int32); wt = np.zeros(n, np.float32); nd = np.zeros(n, np.int32)
+        N.check(ex._h, ex._lib.hs_bow_transform(ex._h, C.byref(self.tree), d.ctypes.data_as(C.c_void_p), n, levelsup,
+                                                w.ctypes.data_as(C.c_void_p), wt.ctypes.data_as(C.c_void_p), nd.ctypes.data_as(C.c_void_p)))
+        return self.containers(w, wt, nd)
+
+    @staticmethod
+    def containers(word, weight, node):
+        """DBoW2: `if (w > 0) { bow.addWeight(id, w); fv.addFeature(nid, i); }`, then L1 normalisation of the BoW vector."""
+        use = weight > 0
+        bow = {}
+        for wid, wv in zip(word[use].tolist(), weight[use].tolist()):
+            bow[wid] = bow.get(wid, 0.0) + wv
+        tot = sum(abs(v) for _, v in sorted(bow.items()))
+        if tot > 0:
+            bow = {k: v / tot for k, v in bow.items()}
+        idx = np.nonzero(use)[0]
+        order = np.lexsort((idx, node[idx]))
+        ids, counts = np.unique(node[idx], return_counts=True)
+        ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        return bow, (ids.astype(np.int32), ptr, idx[order].astype(np.int32)), (word, weight, node)
+
+
 class ORBFactory:
     """HYSLAM::ORBFactory: hands out extractors and matcher settings (FeatureFactory.h:21-33, ORBFactory.cpp:13-45)."""
 

@@ -208,6 +208,22 @@ int  hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc
                          float score_threshold, float second_best_ratio, int check_rotation,
                          int32_t* match12, int32_t* n_matches);
 
+/* Vocabulary transform: what Frame::ComputeBoW / KeyFrame::ComputeBoW obtain from ORBVocabulary::transform -> DBoW2::TemplatedVocabulary<FORB>
+ * ::transform(features, bow, fv, levelsup=4) (src/core/Frame.cc:472-479, src/features/low_level/ORBVocabulary.cpp:31-42).  DBoW2 and the
+ * ORBvoc data are not part of the reference tree; the tree descent follows DBoW2's published algorithm (first minimum wins at every level).
+ * Flat tree: node 0 = root, the children of a node are contiguous, child_count == 0 marks a leaf (word).  Outputs per descriptor: word id,
+ * word weight and the id of the node passed at level (levels - levelsup), which keys DBoW2::FeatureVector.  Host pointers; synchronous. */
+typedef struct hs_vocab_tree {
+    int32_t n_nodes, levels;
+    const int32_t* child_begin;        /* [n_nodes] */
+    const int32_t* child_count;        /* [n_nodes] */
+    const uint8_t* desc;               /* [n_nodes][32] */
+    const int32_t* word_id;            /* [n_nodes], valid at leaves */
+    const float* weight;               /* [n_nodes], valid at leaves */
+} hs_vocab_tree;
+int  hs_bow_transform(hs_orb* h, const hs_vocab_tree* tree, const uint8_t* desc, int n, int levelsup,
+                      int32_t* word_id, float* weight, int32_t* node_id);
+
 /* brute-force Hamming 2-NN (cross-camera matching without a vocabulary): for each of nq query descriptors the first-minimum
  * train index, its distance and the second-smallest distance (-1 when absent). */
 int  hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int nt,

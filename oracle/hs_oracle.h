@@ -197,6 +197,20 @@ int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1,
                          const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
                          const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
                          float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12);
+/* DBoW2::TemplatedVocabulary<FORB>::transform(features, bow, fv, levelsup) as called by Frame::ComputeBoW (Frame.cc:472-479) through
+ * ORBVocabulary::transform (ORBVocabulary.cpp:31-42).  DBoW2 is NOT in the reference tree; restated from its published
+ * algorithm: descend from the root, at each level take the child with the smallest Hamming distance (first minimum wins);
+ * the leaf gives word id + weight, the node passed at level (L - levelsup) keys the feature vector.  Flat tree: node 0 = root, children of a
+ * node are contiguous [child_begin, child_begin+child_count), child_count == 0 marks a leaf. */
+typedef struct hso_vocab_tree {
+    int32_t n_nodes, levels;
+    const int32_t* child_begin; const int32_t* child_count;
+    const uint8_t* desc;               /* n_nodes x 32 (root's is unused) */
+    const int32_t* word_id;            /* leaves */
+    const float* weight;               /* leaves */
+} hso_vocab_tree;
+void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id);
+
 /* brute-force Hamming 2-NN of every query against every train descriptor: best index, best and second-best distance
  * (first minimum wins, like every best/second-best loop of the reference, e.g. MatchCriteria.cpp:248-280) */
 void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);

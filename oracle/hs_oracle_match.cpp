@@ -347,6 +347,27 @@ int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1,
     return (int)matches_internal.size();
 }
 
+void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id)
+{
+    const int nid_level = T->levels - levelsup;
+    for (int i = 0; i < n; i++) {
+        const uint8_t* f = desc + (size_t)i * 32;
+        int final_id = 0, current_level = 0, nid = 0;      // nid stays 0 (root) when nid_level <= 0
+        do {
+            ++current_level;
+            const int cb = T->child_begin[final_id], cc = T->child_count[final_id];
+            final_id = cb;
+            double best_d = ORBDistance(f, T->desc + (size_t)final_id * 32);
+            for (int c = cb + 1; c < cb + cc; c++) {
+                double d = ORBDistance(f, T->desc + (size_t)c * 32);
+                if (d < best_d) { best_d = d; final_id = c; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (T->child_count[final_id] != 0);
+        word_id[i] = T->word_id[final_id]; weight[i] = T->weight[final_id]; node_id[i] = nid;
+    }
+}
+
 void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
 {
     for (int i = 0; i < nq; i++) {

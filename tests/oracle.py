@@ -247,6 +247,11 @@ class FrameView(C.Structure):
                 ("kps", C.c_void_p), ("desc", C.c_void_p), ("uR", C.c_void_p), ("kp_lm_obs", C.c_void_p)]
 
 
+class VocabTree(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("levels", C.c_int32), ("child_begin", C.c_void_p), ("child_count", C.c_void_p),
+                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
+
+
 class ProjParams(C.Structure):
     _fields_ = [("th", C.c_float), ("score_threshold", C.c_float), ("second_best_ratio", C.c_float),
                 ("frac_smaller", C.c_float), ("frac_larger", C.c_float),
@@ -329,3 +334,31 @@ def rotation_consistency(angle_a, angle_b):
     keep = np.zeros(len(a), np.uint8)
     lib().hso_rotation_consistency(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(a), keep.ctypes.data_as(C.c_void_p))
     return keep.astype(bool)
+
+
+def make_vocab_tree(cls, k, levels, seed):
+    """A seeded synthetic k-ary vocabulary of `levels` levels below the root (stands in for ORBvoc, which is not available):
+    node descriptors are random, leaves get consecutive word ids and idf-like weights.  Returns (struct, keepalive, n_words)."""
+    rng = np.random.default_rng(seed)
+    n_nodes = sum(k ** l for l in range(levels + 1))
+    cb = np.zeros(n_nodes, np.int32); cc = np.zeros(n_nodes, np.int32)
+    nxt = 1
+    first_leaf = sum(k ** l for l in range(levels))
+    for i in range(first_leaf):
+        cb[i], cc[i] = nxt, k
+        nxt += k
+    desc = rng.integers(0, 256, (n_nodes, 32), dtype=np.uint8)
+    desc[rng.integers(1, n_nodes, n_nodes // 20)] = desc[rng.integers(1, n_nodes, n_nodes // 20)]     # duplicate node descriptors: ties
+    word = np.full(n_nodes, -1, np.int32); word[first_leaf:] = np.arange(n_nodes - first_leaf)
+    weight = np.zeros(n_nodes, np.float32); weight[first_leaf:] = rng.uniform(0.5, 9.0, n_nodes - first_leaf)
+    T = cls(n_nodes, levels, cb.ctypes.data, cc.ctypes.data, desc.ctypes.data, word.ctypes.data, weight.ctypes.data)
+    return T, [cb, cc, desc, word, weight], n_nodes - first_leaf
+
+
+def bow_transform(T, desc, levelsup):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(desc)
+    w = np.zeros(n, np.int32); wt = np.zeros(n, np.float32); nd = np.zeros(n, np.int32)
+    lib().hso_bow_transform(C.byref(T), desc.ctypes.data_as(C.c_void_p), n, levelsup, w.ctypes.data_as(C.c_void_p),
+                            wt.ctypes.data_as(C.c_void_p), nd.ctypes.data_as(C.c_void_p))
+    return w, wt, nd

@@ -124,6 +124,31 @@ def test_search_for_triangulation_core(matcher):
     assert gn == on and np.array_equal(gm, om)
 
 
+def test_vocabulary_transform_and_bow_pipeline(matcher):
+    """Frame::ComputeBoW + SearchByBoW end to end on a synthetic 10-ary vocabulary: transform on the GPU == oracle, then the
+    feature vectors it produces drive the BoW-grouped matcher."""
+    To, ko, n_words = oracle.make_vocab_tree(oracle.VocabTree, 10, 4, 17)
+    Tg, kg, _ = oracle.make_vocab_tree(N.VocabTree, 10, 4, 17)
+    sc = scenes.projection_scene(43, 640, 480, nfeat=1000, copies=1)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(10)
+    perm = rng.permutation(len(k1))
+    k2, d2 = k1[perm].copy(), d1[perm].copy()
+    d2[::4, 3] ^= 0x81
+    voc = HS.ORBVocabulary(Tg, matcher._ex)
+    for levelsup in (2, 4):
+        bow1, fv1, raw1 = voc.transform(d1, levelsup)
+        bow2, fv2, raw2 = voc.transform(d2, levelsup)
+        for raw, d in ((raw1, d1), (raw2, d2)):
+            ow, owt, ond = oracle.bow_transform(To, d, levelsup)
+            assert np.array_equal(raw[0], ow) and np.array_equal(raw[1], owt) and np.array_equal(raw[2], ond)
+        assert abs(sum(bow1.values()) - 1.0) < 1e-5 and len(fv1[0]) == len(np.unique(raw1[2]))
+        gm, gn = matcher.SearchByBoW(k1, d1, fv1, k2, d2, fv2, None, True)
+        om, on = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, None, 50.0, 0.8, True)
+        assert gn == on and np.array_equal(gm, om)
+    assert gn > 300                                                     # levelsup 4 = root node: one big group, most points re-found
+
+
 def test_knn2(matcher):
     rng = np.random.default_rng(6)
     q = rng.integers(0, 256, (2000, 32), dtype=np.uint8)

@@ -243,3 +243,26 @@ def test_triangulation_core_epipolar_gate():
     assert np.array_equal(m, ref)
     m_rot, n_rot = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, 90.0, 1.0, True, keep2=keep2, F12=F12)
     assert n_rot <= n and ((m_rot == m) | (m_rot == -1)).all()
+
+
+def test_vocabulary_transform_descends_to_nearest_children():
+    """DBoW2 transform on a synthetic 6-ary, 3-level vocabulary against a direct python walk (first minimum wins)."""
+    T, keep, n_words = oracle.make_vocab_tree(oracle.VocabTree, 6, 3, 5)
+    cb, cc, nd, word, weight = keep
+    rng = np.random.default_rng(3)
+    desc = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    desc[:50] = nd[rng.integers(1, len(nd), 50)]                      # exact node descriptors: distance 0 somewhere on the way
+    for levelsup in (1, 2, 3, 5):
+        w, wt, node = oracle.bow_transform(T, desc, levelsup)
+        for i in range(len(desc)):
+            cur, lvl, nid = 0, 0, 0
+            while cc[cur]:
+                lvl += 1
+                ch = np.arange(cb[cur], cb[cur] + cc[cur])
+                d = np.unpackbits(nd[ch] ^ desc[i][None, :], axis=1).sum(1)
+                cur = int(ch[np.argmin(d)])
+                if lvl == 3 - levelsup:
+                    nid = cur
+            assert (w[i], node[i]) == (word[cur], nid) and wt[i] == weight[cur]
+        assert 0 <= w.min() and w.max() < n_words
+    assert (oracle.bow_transform(T, desc, 3)[2] == 0).all() and (oracle.bow_transform(T, desc, 9)[2] == 0).all()     # root when levelsup >= L
