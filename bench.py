@@ -143,6 +143,7 @@ def main():
         dom_bytes = per_stage[dom] * frames_per_launch
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         pair_bytes = 2 * per_frame
+        traffic, traffic_src = measured_traffic(dom, B)
         out = {
             "metric": "stereo frames/sec ORB extract+match, 1920x1080 @2000 feat",
             "value": round(value, 2), "unit": "stereo_pairs/s",
@@ -154,7 +155,7 @@ def main():
                        "pairs_per_step_per_gpu": B, "distinct_pairs": nd, "sharding": "frames round-robin, no collective",
                        "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(stage_ms[dom], 5),
                          "frames_per_launch": frames_per_launch},
             "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
@@ -223,6 +224,23 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel, pairs_per_step):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_d_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled per the gfx950 calibration).  Counters cannot be read from
+    inside this process, so the value is only reported when the profiled batch size matches; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+        k = {"fast_cells": "k_fast_cells", "pyramid": "k_resize_level", "describe": "k_describe", "quadtree": "k_quadtree"}[kernel]
+        if t["pairs_per_step"] != pairs_per_step:
+            return None, None
+        e = t["kernels"][k]
+        mult = 7 if kernel == "pyramid" else 1          # the pyramid stage is 7 launches of k_resize_level; the file holds the per-launch mean
+        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_d_hbm_traffic.json"
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(pairs, budget_s):

@@ -582,6 +582,27 @@ int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark
     return HS_OK;
 }
 
+int hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,
+                                   int32_t* d_match_idx, float* d_match_dist, int32_t* d_n_matches, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!F || !pp || L < 1 || !d_lms || !d_match_idx || !d_match_dist || !d_n_matches || F->n < 1 || F->n > 65535 || !F->kps || !F->desc ||
+        (pp->use_stereo && F->sensor != 0 && !F->uR))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nn = F->n;
+    // scratch is per handle: a second call may only start after the first finished (same stream ordering is enough)
+    const size_t need = pad256(nn * 2) + pad256(nn * 4) + pad256((size_t)L * 4) + 4096;
+    if (need > h->scratch_bytes) { int rc = scratch_begin(h, need); if (rc != HS_OK) return rc; }
+    h->scratch_used = 0;
+    int8_t* d_cell = carve<int8_t>(h, nn * 2); int32_t* d_winner = carve<int32_t>(h, nn); float* d_pangle = carve<float>(h, L);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hs_launch_frame_grid(*F, F->kps, d_cell, s);
+    hs_launch_search_projection(*F, F->kps, F->desc, F->uR, F->kp_lm_obs, d_cell, d_lms, L, *pp, d_match_idx, d_match_dist, d_winner, d_pangle, d_n_matches, s);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
 int hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
                      const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
                      const hs_keypoint* kps2, const uint8_t* desc2, int n2,

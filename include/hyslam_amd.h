@@ -186,6 +186,11 @@ typedef struct hs_proj_params {
 int  hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
                              int32_t* match_idx, float* match_dist, int32_t* n_matches);
 
+/* the same on device-resident data (FeatureViews stay in HBM between extraction and tracking): every pointer inside *F and
+ * d_lms / d_match_idx / d_match_dist / d_n_matches are device pointers (F->kps / F->desc can be the extractor's own outputs).  Asynchronous. */
+int  hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,
+                                    int32_t* d_match_idx, float* d_match_dist, int32_t* d_n_matches, void* stream);
+
 /* the inner loops of SearchByBoW / SearchByBoW2 / _SearchByBoW_ (FeatureMatcher.cc:216-371): for every vocabulary node present in
  * both feature vectors, best / second-best Hamming of each side-1 index over the node's side-2 indices (BestMatchBoWCriterion,
  * MatchCriteria.cpp:601-635: d < threshold and d < ratio*d2, both strict), then RotationConsistencyBoW (:679-726).
