@@ -10,11 +10,14 @@
 //
 // MI355X mapping.  The reference's cell is the unit of work: its tile (interior + apron) is staged in LDS with
 // coalesced dword row loads and the score map lives only in LDS, so the only HBM traffic is one read of each level.
-// The launch is PERSISTENT: 4 workgroups per CU each walk a contiguous range of the (image, level, cell) list;
-// the dwords of the NEXT cell's tile are fetched into registers before the current cell is processed, which takes
-// the ~2 us global-load latency off the per-cell critical path (a one-cell-per-workgroup launch was latency bound:
-// 7.5 us per cell at 5 workgroups/CU).  Ranges are dealt so that workgroups that share an XCD (blockIdx % 8) own
-// neighbouring cells and reuse each other's apron lines in that XCD's L2.  Per cell:
+// The launch is PERSISTENT and every workgroup is ONE wavefront: ~28 of them per CU each walk a contiguous range of the
+// (image, level, cell) list.  One wave per cell means no workgroup barriers at all (LDS hand-offs are ordered by the wave's own
+// in-order LDS queue), list appends are ballot + mbcnt prefix counts in registers instead of LDS atomics, and a wave never idles
+// at a barrier while its partner scores a handful of corners (measured: 1.20 ms one-cell-per-256-thread-workgroup ->
+// 0.60 ms persistent 128-thread -> 0.5 ms single-wave, 32 frames of 1080p).  The dwords of the NEXT cell's tile are fetched into
+// registers before the current cell is processed, which takes the ~2 us global-load latency off the per-cell critical path.
+// Ranges are dealt so that workgroups that share an XCD (blockIdx % 8) own neighbouring cells and reuse each other's apron
+// lines in that XCD's L2 (measured HBM over-fetch 1.15x).  Per cell:
 //   pass 1  every pixel: compass-point quick reject -> "maybe" list in LDS (dense lanes for what follows)
 //   pass 2  maybe pixels: 16-bit darker/brighter ring masks, 9 contiguous cyclic bits -> corner list
 //   pass 3  corners: score into the LDS score tile;  pass 4: strict 3x3 NMS inside the cell
@@ -35,33 +38,40 @@ struct FastLds {
     int32_t tile_pitch;      // >= 3 (dword misalignment) + max cell width + 6, multiple of 4
     int32_t score_pitch;     // max cell width + 2 (1 px zero frame), multiple of 4
     int32_t score_bytes;     // (max cell height + 2) * score_pitch
-    int32_t off_score, off_mlist, off_clist, off_outxy, off_outs, off_ctr, total;
+    int32_t off_score, off_list, total;
 };
-#ifndef FAST_NT
-#define FAST_NT 128                          // threads per workgroup (one cell at a time)
-#endif
-#define NPRE (1536 / FAST_NT)                // prefetched dwords per thread: 1536 >= 70 rows x 19 dwords
+#define FAST_NT 64                           // one wavefront per workgroup (see above)
+#define NPRE (1536 / FAST_NT)                // prefetched dwords per lane: 1536 >= 70 rows x 19 dwords
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would expose the latency of
-// the next cell's prefetch at the first barrier after it is issued; the tile/list hand-offs inside a cell are LDS-only.
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The workgroup is one wave: its LDS operations execute in program order, so a hand-off through LDS only needs the LDS queue
+// drained (no s_barrier, and no vmcnt wait that would expose the latency of the next cell's prefetch).
+#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-__device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t)
+// append: lanes with `flag` get consecutive slots after `base` (wave-uniform); returns the lane's slot, advances base
+__device__ __forceinline__ int wave_append(bool flag, int& base)
 {
-    int lo2[16], lo4[16], lo8[16], hi2[16], hi4[16], hi8[16];
+    const unsigned long long m = __ballot(flag);
+    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    base += (int)__popcll(m);
+    return slot;
+}
+
+// Corner score of a pixel that passed the segment test with polarity `dark` (d[k] = v - ring[k] for dark, ring[k] - v for bright).
+// cv::FAST's cornerScore<16> is max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1; for a corner of one polarity the other
+// polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with d of its own polarity.
+__device__ __forceinline__ int fast_corner_score(const int (&d)[16])
+{
+    int lo2[16], lo4[16], lo8[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; k++) lo2[k] = min(d[k], d[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    for (int k = 0; k < 16; k++) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo8[k] = min(lo4[k], lo4[(k + 4) & 15]); hi8[k] = max(hi4[k], hi4[(k + 4) & 15]); }
-    int a0 = t;
+    for (int k = 0; k < 16; k++) lo8[k] = min(lo4[k], lo4[(k + 4) & 15]);
+    int a0 = min(lo8[0], d[8]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) a0 = max(a0, min(lo8[k], d[(k + 8) & 15]));      // arcs of 9: d[k..k+8]
-    int b0 = -a0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) b0 = min(b0, max(hi8[k], d[(k + 8) & 15]));
-    return -b0 - 1;
+    for (int k = 1; k < 16; k++) a0 = max(a0, min(lo8[k], d[(k + 8) & 15]));      // arcs of 9: d[k..k+8]
+    return a0 - 1;
 }
 
 struct CellGeom {           // wave-uniform description of one work item
@@ -134,13 +144,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const tile = smem;
     uint8_t* const score = smem + lds.off_score;
-    uint16_t* const mlist = reinterpret_cast<uint16_t*>(smem + lds.off_mlist);      // "maybe" pixels (py<<8 | px)
-    uint16_t* const clist = reinterpret_cast<uint16_t*>(smem + lds.off_clist);      // corners
-    uint32_t* const out_xy = reinterpret_cast<uint32_t*>(smem + lds.off_outxy);
-    uint8_t* const out_s = smem + lds.off_outs;
-    int& n_maybe = reinterpret_cast<int*>(smem + lds.off_ctr)[0];
-    int& n_corner = reinterpret_cast<int*>(smem + lds.off_ctr)[1];
-    int& n_out = reinterpret_cast<int*>(smem + lds.off_ctr)[2];
+    uint16_t* const list = reinterpret_cast<uint16_t*>(smem + lds.off_list);   // "maybe" pixels, then (compacted in place) corners
 
     const int tid = threadIdx.x;
     const int t = fast_th;
@@ -157,7 +161,6 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
     if (w_begin >= w_end) return;
 
     for (int i = tid; i < lds.score_bytes / 4; i += FAST_NT) reinterpret_cast<uint32_t*>(score)[i] = 0;
-    if (tid == 0) n_out = 0;
 
     uint32_t pre[NPRE];
     CellGeom g = cell_geom(lv, nlevels, img0, total_cells, w_begin);
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
         const int n = q.th * q.ndw;
 #pragma unroll
         for (int j = 0; j < NPRE; j++) {
-            if (FAST_NT * j >= n) break;                            // uniform: typical cells need 4 of the 12 slots
+            if (FAST_NT * j >= n) break;                            // uniform: typical cells need 7 of the 24 slots
             int i = tid + FAST_NT * j;
             if (i < n) {
                 int r = (int)(((float)i + 0.5f) * rcp), c = i - r * q.ndw;
@@ -207,43 +210,38 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
                 tile[r * TILE_PITCH + off + c] = src[(size_t)r * g.pitch + c];
             }
         }
-        if (tid == 0) { n_maybe = 0; n_corner = 0; }
-        LDS_BARRIER();                                           // S0: tile ready, previous cell fully drained
+        WAVE_LDS_FENCE();                                        // tile ready
         const CellGeom cur = g;
         if (w + 1 < w_end) { cell_next(g, lv, nlevels, img0); prefetch(g); }   // in flight during the passes
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 1
-        if (tid == 0) *cnt = 0;
-        continue;
-#endif
         // ---- pass 1 (every pixel): quick reject on the four compass points.  A 9-arc of the 16-ring always holds two
         //      ADJACENT compass points, i.e. (p0 or p8) and (p4 or p12).
         const int npix = iw * ih;
         const float rcp_iw = __builtin_amdgcn_rcpf((float)iw);  // floor(p/iw) via (p+0.5)*rcp: exact for p < 4096, iw <= 64 even at 1 ulp
-        for (int p = tid; p < npix; p += FAST_NT) {
-            int py = (int)(((float)p + 0.5f) * rcp_iw), px = p - py * iw;
+        int n_maybe = 0;                                         // wave-uniform
+        for (int p0 = 0; p0 < npix; p0 += FAST_NT) {
+            const int p = p0 + tid;
+            const int pc = min(p, npix - 1);
+            int py = (int)(((float)pc + 0.5f) * rcp_iw), px = pc - py * iw;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
             int v = ctr[0];
             int lo = v - t, hi = v + t;
             int r0 = ctr[RO[0]], r8 = ctr[RO[8]], r4 = ctr[RO[4]], r12 = ctr[RO[12]];
             bool dk = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
             bool br = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
-            if (dk || br) {
-                int slot = atomicAdd(&n_maybe, 1);
-                mlist[slot] = (uint16_t)((py << 8) | px);
-            }
+            const bool hit = p < npix && (dk || br);
+            const int slot = wave_append(hit, n_maybe);
+            if (hit) list[slot] = (uint16_t)((py << 8) | px);
         }
-        LDS_BARRIER();                                           // S1
-        if (tid == 0) n_out = 0;                                 // everyone has left the previous cell's emit
+        WAVE_LDS_FENCE();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 2
-        if (tid == 0) *cnt = n_maybe;
-        continue;
-#endif
-        // ---- pass 2 (maybe pixels): 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits
-        const int nm = n_maybe;
-        for (int i = tid; i < nm; i += FAST_NT) {
-            int pos = mlist[i];
+        // ---- pass 2 (maybe pixels): 16-bit darker / brighter ring masks, 9 contiguous (cyclic) set bits.  Corners are compacted
+        //      in place: the slots written in an iteration lie below the entries read in it (reads precede writes in program order)
+        int n_corner = 0;
+        for (int i0 = 0; i0 < n_maybe; i0 += FAST_NT) {
+            const int i = i0 + tid;
+            const bool act = i < n_maybe;
+            int pos = list[act ? i : 0];
             int py = pos >> 8, px = pos & 255;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
             int v = ctr[0];
@@ -261,65 +259,54 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
             uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
             uint32_t m2 = mbright | (mbright << 16);
             uint32_t y = m2 & (m2 >> 1); y &= y >> 2; y &= y >> 4; y &= m2 >> 8;
-            if (((x | y) & 0xFFFFu) != 0) {
-                int slot = atomicAdd(&n_corner, 1);
-                clist[slot] = (uint16_t)pos;
-            }
+            const bool corner = act && ((x | y) & 0xFFFFu) != 0;
+            WAVE_LDS_FENCE();                                    // this iteration's list reads have returned before its slots are overwritten
+            const int slot = wave_append(corner, n_corner);
+            if (corner) list[slot] = (uint16_t)(pos | ((y & 0xFFFFu) ? 0x8000 : 0));       // bit 15: bright corner
         }
-        LDS_BARRIER();                                           // S2
+        WAVE_LDS_FENCE();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 3
-        if (tid == 0) *cnt = n_corner;
-        continue;
-#endif
         // ---- pass 3 (corners): corner score
         const int nc = n_corner;
         for (int i = tid; i < nc; i += FAST_NT) {
-            int pos = clist[i];
-            int py = pos >> 8, px = pos & 255;
+            int pos = list[i];
+            const bool bright = pos & 0x8000;
+            int py = (pos >> 8) & 127, px = pos & 255;
             const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
             int v = ctr[0];
             int d[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = v - (int)ctr[RO[k]];
-            score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)fast_corner_score(d, t);
+            for (int k = 0; k < 16; k++) { int e = v - (int)ctr[RO[k]]; d[k] = bright ? -e : e; }
+            score[(py + 1) * SCORE_PITCH + px + 1] = (uint8_t)fast_corner_score(d);
         }
-        LDS_BARRIER();                                           // S3
+        WAVE_LDS_FENCE();
 
-#if defined(FAST_ABLATE) && FAST_ABLATE == 4
-        if (tid == 0) *cnt = 0;
-        { const int ncc = n_corner; for (int i = tid; i < ncc; i += FAST_NT) { int pos = clist[i]; score[((pos >> 8) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0; } }
-        continue;
-#endif
-        // ---- pass 4: 3x3 strict NMS inside the cell
-        for (int i = tid; i < nc; i += FAST_NT) {
-            int pos = clist[i];
-            int py = pos >> 8, px = pos & 255;
+        // ---- pass 4: 3x3 strict NMS inside the cell; survivors go straight to this cell's slots
+        const size_t slot0 = (size_t)cur.img * cand_img_stride + L.cand_off + (size_t)cur.c * cur.ccap;
+        int n_out = 0;
+        for (int i0 = 0; i0 < nc; i0 += FAST_NT) {
+            const int i = i0 + tid;
+            const bool act = i < nc;
+            int pos = list[act ? i : 0];
+            int py = (pos >> 8) & 127, px = pos & 255;
             const uint8_t* sc = &score[(py + 1) * SCORE_PITCH + px + 1];
             int s = sc[0];
-            bool keep = s > sc[1] && s > sc[-1] &&
-                        s > sc[-SCORE_PITCH - 1] && s > sc[-SCORE_PITCH] && s > sc[-SCORE_PITCH + 1] &&
-                        s > sc[SCORE_PITCH - 1] && s > sc[SCORE_PITCH] && s > sc[SCORE_PITCH + 1];
+            const bool keep = act && s > sc[1] && s > sc[-1] &&
+                              s > sc[-SCORE_PITCH - 1] && s > sc[-SCORE_PITCH] && s > sc[-SCORE_PITCH + 1] &&
+                              s > sc[SCORE_PITCH - 1] && s > sc[SCORE_PITCH] && s > sc[SCORE_PITCH + 1];
+            const int slot = wave_append(keep, n_out);
             if (keep) {
-                int slot = atomicAdd(&n_out, 1);
                 // coordinates relative to (minBorderX, minBorderY): x_local + j*wCell (ORBExtractor.cpp:463-464)
-                out_xy[slot] = ((uint32_t)(py + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff);
-                out_s[slot] = (uint8_t)s;
+                cand_xy[slot0 + slot] = ((uint32_t)(py + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff);
+                cand_sk[slot0 + slot] = ((uint32_t)s << 24) | (uint32_t)cur.c;
             }
         }
-        LDS_BARRIER();                                           // S4: tile, lists and score reads are finished
-
-        // ---- emit into this cell's slots; restore the all-zero score tile
-        const int no = n_out;
-        if (tid == 0) *cnt = no;
-        const size_t slot0 = (size_t)cur.img * cand_img_stride + L.cand_off + (size_t)cur.c * cur.ccap;
-        for (int i = tid; i < no; i += FAST_NT) {
-            cand_xy[slot0 + i] = out_xy[i];
-            cand_sk[slot0 + i] = ((uint32_t)out_s[i] << 24) | (uint32_t)cur.c;
-        }
+        if (tid == 0) *cnt = n_out;
+        WAVE_LDS_FENCE();                                        // NMS reads of the score tile are done
+        // ---- restore the all-zero score tile
         for (int i = tid; i < nc; i += FAST_NT) {
-            int pos = clist[i];
-            score[((pos >> 8) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0;
+            int pos = list[i];
+            score[(((pos >> 8) & 127) + 1) * SCORE_PITCH + (pos & 255) + 1] = 0;
         }
     }
 }
@@ -337,16 +324,11 @@ void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, in
     L.score_bytes = up((max_hcell + 2) * L.score_pitch, 4);
     int o = up((max_hcell + 6) * L.tile_pitch + 16, 16);
     L.off_score = o; o = up(o + L.score_bytes, 16);
-    L.off_mlist = o; o = up(o + 2 * max_wcell * max_hcell, 16);
-    L.off_clist = o; o = up(o + 2 * max_wcell * max_hcell, 16);
-    const int max_out = ((max_wcell + 1) / 2) * ((max_hcell + 1) / 2);
-    L.off_outxy = o; o = up(o + 4 * max_out, 16);
-    L.off_outs = o; o = up(o + max_out, 16);
-    L.off_ctr = o; o += 16;
+    L.off_list = o; o = up(o + 2 * max_wcell * max_hcell, 16);
     L.total = o;
     const int total_work = total_cells * batch;
     int per_cu = std::min(2048 / FAST_NT, std::max(1, (160 * 1024) / L.total));   // wave limit (32 per CU) or LDS
-    int nblk = 256 * per_cu;                               // persistent workgroups
+    int nblk = 256 * per_cu;                               // persistent single-wave workgroups
     while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD dealing)
     if (small)
         hipLaunchKernelGGL((k_fast_cells<48, 40>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,

@@ -87,12 +87,91 @@ __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict_
     *reinterpret_cast<uint32_t*>(drow + dx0) = packed;   // pitch is a multiple of 64: padding bytes may be written
 }
 
+// LDS-staged variant (the fast path): a workgroup produces a 256 x LT_ROWS destination tile.  The source rectangle it needs is
+// fetched once with 16-byte coalesced loads into LDS; every lane then picks its 4 taps per output with LDS byte reads (no
+// per-output global loads, no dword select chains) — ~3x fewer instructions per pixel than k_resize_level and each source row is
+// read from HBM/L2 once per tile instead of once per destination row.  Needs 16-byte aligned source rows.
+#define LT_ROWS 8
+__global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restrict__ lv, int level, HsImg0 img0, int lds_pitch, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
+    const HsLevel& D = lv[level];
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;        // 64 x 4 lanes
+    const int dx_tile = blockIdx.x * 256, dy_tile = blockIdx.y * LT_ROWS;
+
+    const uint8_t* sbase; size_t spitch;
+    if (level == 1) { sbase = hs_img0_ptr(img0, img); spitch = img0.row_stride; }
+    else { const HsLevel& S = lv[level - 1]; sbase = S.base + (size_t)img * S.img_stride; spitch = S.pitch; }
+    const int sw = lv[level - 1].w, sh = lv[level - 1].h;
+    const HsXTab* xt = reinterpret_cast<const HsXTab*>(D.xofs);
+
+    // source rectangle of this tile (wave-uniform)
+    const int dy_last = min(dy_tile + LT_ROWS, D.h) - 1, dx_last = min(dx_tile + 256, D.w) - 1;
+    const int sy_first = min(max((int)D.yofs[dy_tile], 0), sh - 1);
+    const int sy_last = min(max((int)D.yofs[dy_last] + 1, 0), sh - 1);
+    const int col0 = xt[dx_tile].sx & ~15;
+    const int col_last = min(xt[dx_last].sx + 1, sw - 1);
+    const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch, nrow <= lds_rows
+    for (int i = threadIdx.x; i < nvec * nrow; i += 256) {
+        const int r = i / nvec, q = i - r * nvec;
+        const uint4 v = *reinterpret_cast<const uint4*>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
+        *reinterpret_cast<uint4*>(&s_src[r * lds_pitch + 16 * q]) = v;
+    }
+    __syncthreads();
+
+    const int dx0 = dx_tile + 4 * tx;
+    if (dx0 >= D.w) return;
+    HsXTab t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = xt[min(dx0 + i, D.w - 1)];
+#pragma unroll
+    for (int rr = 0; rr < LT_ROWS / 4; rr++) {
+        const int dy = dy_tile + ty + 4 * rr;
+        if (dy >= D.h) break;
+        const int sy = D.yofs[dy];
+        const int b0 = D.ibeta[2 * dy], b1 = D.ibeta[2 * dy + 1];
+        const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
+        const uint8_t* S0 = &s_src[r0 * lds_pitch - col0];
+        const uint8_t* S1 = &s_src[r1 * lds_pitch - col0];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sx = t[i].sx;
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            int h0, h1;
+            if (dx0 + i < D.xmax) { h0 = S0[sx] * t[i].a0 + S0[sx1] * t[i].a1; h1 = S1[sx] * t[i].a0 + S1[sx1] * t[i].a1; }
+            else { h0 = S0[sx] * 2048; h1 = S1[sx] * 2048; }
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xFF) << (8 * i);
+        }
+        uint8_t* drow = D.base + (size_t)img * D.img_stride + (size_t)dy * D.pitch;
+        *reinterpret_cast<uint32_t*>(drow + dx0) = packed;
+    }
+}
+
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s)
 {
     for (int l = 1; l < nlevels; l++) {
+        const HsLevel& D = h_lv[l];
+        const int sw = h_lv[l - 1].w, sh = h_lv[l - 1].h;
+        // 16-byte source vectors: always fine for our own levels (pitch % 64 == 0), checked for the caller's frames;
+        // a vector may run past the last source column only inside the row's own pitch
+        bool vec16 = true;
+        if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((sw + 15) & ~15) <= (int)img0.row_stride;
+        // worst-case source rectangle of a 256 x LT_ROWS tile
+        const double scx = (double)sw / D.w, scy = (double)sh / D.h;
+        const int lds_pitch = (((int)(256 * scx) + 2 + 15 + 15) & ~15) + 16;
+        const int lds_rows = (int)(LT_ROWS * scy) + 4;
+        const size_t lds_bytes = (size_t)lds_pitch * lds_rows;
+        if (vec16 && lds_bytes <= 60 * 1024) {
+            dim3 grid((D.w + 255) / 256, (D.h + LT_ROWS - 1) / LT_ROWS, batch);
+            hipLaunchKernelGGL(k_resize_level_lds, grid, dim3(256), lds_bytes, s, d_lv, l, img0, lds_pitch, lds_rows);
+            continue;
+        }
         dim3 block(64, 4, 1);
-        dim3 grid((h_lv[l].w + 255) / 256, (h_lv[l].h + 3) / 4, batch);
-        // dword source fetches need 4-byte aligned rows: always true for our own levels, checked for the caller's frames
+        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, batch);
+        // dword source fetches need 4-byte aligned rows
         bool aligned = true;
         if (l == 1) aligned = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 3) == 0;
         if (aligned) hipLaunchKernelGGL(k_resize_level<true>, grid, block, 0, s, d_lv, l, img0);
