@@ -41,6 +41,7 @@ struct hs_orb {
     uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
+    int32_t* d_strip_count = nullptr; uint16_t* d_strip_list = nullptr; size_t strip_entries = 0;
     int last_batch = 0; HsImg0 last_img0{};
     // bump-allocated scratch for the host-pointer matcher entry points
     uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
@@ -201,6 +202,18 @@ int ensure_outputs(hs_orb* h, int batch, int cap)
     return HS_OK;
 }
 
+int ensure_stereo_strips(hs_orb* h, int pairs, int cap, int n_rows)
+{
+    const size_t need = (size_t)pairs * hs_stereo_strips(n_rows) * ((size_t)cap + 2);
+    if (need <= h->strip_entries) return HS_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_strip_count); hipFree(h->d_strip_list); h->d_strip_count = nullptr; h->d_strip_list = nullptr;
+    HIP_TRY(h, hipMalloc(&h->d_strip_count, (size_t)pairs * hs_stereo_strips(n_rows) * 4));
+    HIP_TRY(h, hipMalloc(&h->d_strip_list, (size_t)pairs * hs_stereo_strips(n_rows) * cap * 2));
+    h->strip_entries = need;
+    return HS_OK;
+}
+
 int ensure_stereo_scratch(hs_orb* h, size_t entries)
 {
     if (entries <= h->st_entries) return HS_OK;
@@ -259,7 +272,7 @@ void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32
                 const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
 {
     mark(h, 4, s);
-    hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, s);
+    hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
     mark(h, 5, s);
     hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, s);
     mark(h, -1, s);
@@ -354,7 +367,7 @@ void hs_orb_destroy(hs_orb* h)
     free_geometry(h);
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
-    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd); hipFree(h->d_scratch);
+    hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd); hipFree(h->d_scratch); hipFree(h->d_strip_count); hipFree(h->d_strip_list);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -468,6 +481,7 @@ int hs_stereo_match_batch_device(hs_orb* h, const hs_keypoint* d_kpsL, const uin
         return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
+    if (rc == HS_OK) rc = ensure_stereo_strips(h, pairs, cap, sp->n_rows);
     if (rc != HS_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
@@ -491,6 +505,7 @@ int hs_stereo_match(hs_orb* h, const hs_keypoint* kpsL, const uint8_t* descL, in
     HIP_TRY(h, hipMalloc(&dd, (size_t)2 * cap * HS_DESC_BYTES));
     HIP_TRY(h, hipMalloc(&dn, 8));
     int rc = ensure_stereo_scratch(h, (size_t)cap);
+    if (rc == HS_OK) rc = ensure_stereo_strips(h, 1, cap, sp->n_rows);
     int32_t cnt[2] = { nL, nR };
     hipError_t e = hipSuccess;
     if (rc == HS_OK) {
@@ -530,6 +545,7 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     if (rc != HS_OK) return rc;
     if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
     rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
+    if (rc == HS_OK) rc = ensure_stereo_strips(h, pairs, cap, sp->n_rows);
     if (rc != HS_OK) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     HsImg0 img0{ d_left, d_right, pairs, (uint64_t)row_stride, (uint64_t)image_stride };

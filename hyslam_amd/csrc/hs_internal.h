@@ -78,7 +78,9 @@ void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch
 void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
-                      int32_t* best_dist /*[pairs][cap] scratch*/, hipStream_t s);
+                      int32_t* best_dist /*[pairs][cap] scratch*/,
+                      int32_t* strip_count /*[pairs][strips]*/, uint16_t* strip_list /*[pairs][strips][cap]*/, hipStream_t s);
+inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
 void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s);
 
 // kernels_match.hip

@@ -33,8 +33,8 @@ __constant__ int8_t c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 1
 #define RAW_BYTES (RAW_N * RAW_P + 16)
 #define BL_N 37
 #define H_P 38                   // generic path: row-major u16 row sums
-#define HT_P 44                  // fast path: transposed u16 row sums, 43 rows + 1 pad (multiplied by a zero tap)
-#define H_ELEMS (RAW_N * H_P)    // 1634 >= BL_N * HT_P = 1628
+#define HT_P 46                  // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
+#define H_ELEMS (BL_N * HT_P + 2) // 1704 >= RAW_N * H_P = 1634
 #define BL_P 40
 #define KP_PER_BLOCK 4
 
