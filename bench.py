@@ -52,8 +52,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--config", choices=["c2", "c5"], default="c2",
-                    help="c2 = stereo extract+match (the headline metric); c5 = one mono stream per GPU + all-gather + cross-camera 2-NN")
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
+                    help="c2 = stereo extract+match (the headline metric); c3 = batched 64 mono frames, extract only (per-kernel GB/s); "
+                         "c5 = one mono stream per GPU + all-gather + cross-camera 2-NN")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -62,10 +63,10 @@ def main():
 
     import torch
     import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import hyslam_amd as HS
@@ -74,6 +75,8 @@ def main():
 
     if args.config == "c5":
         return run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N)
+    if args.config == "c3":
+        return run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N)
 
     # ---- synthetic input, resident in HBM before the timed region
     B = args.pairs
@@ -166,6 +169,66 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
+    """BASELINE config 3: 64 synthetic 1920x1080 mono frames per step (seeds 100..163, 8 distinct tiled), extract only; per-kernel
+    achieved GB/s of algorithmic bytes (the 'HBM roofline run')."""
+    from hyslam_amd.synth import synth_image
+    B = 64
+    nd = 8
+    imgs = [synth_image(100 + 64 * rank + i, W, H) for i in range(nd)]
+    frames = torch.from_numpy(np.stack([imgs[i % nd] for i in range(B)])).to(dev)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+    cap = ex.max_keypoints()
+    kps = torch.empty(B * cap * N.KP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    desc = torch.empty(B * cap * 32, dtype=torch.uint8, device=dev)
+    n = torch.zeros(B, dtype=torch.int32, device=dev)
+    ex.reserve(W, H, B)
+
+    def step():
+        ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, 0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ex.profile_begin()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ex.profile_end()
+    fence()
+    ex.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    prof = ex.profile_end()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    if rank == 0:
+        per_stage, per_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
+        stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items() if c}
+        gbs = {s: round(per_stage[s] * B / (stage_ms[s] * 1e-3) / 1e9, 1) for s in ("pyramid", "fast_cells", "describe") if s in stage_ms}
+        value = world * B * args.steps / elapsed
+        print(json.dumps({
+            "metric": "mono frames/sec ORB extract, 1920x1080 @2000 feat, batch 64", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C3: 64 x 1920x1080 mono frames per step, 2000 features, extract only", "keypoints_frame0": int(n[0].item())},
+            "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
+            "per_kernel_algorithmic_GBps": gbs,
+            "end_to_end": {"algorithmic_bytes_per_frame": int(per_frame), "achieved_GBps": round(value / world * per_frame / 1e9, 1),
+                           "frac_of_hbm_peak": round(value / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
