@@ -17,7 +17,7 @@
 //            separately rounded fp32 products; bit i of byte j = test 8j+i -> one ballot per 64 tests.
 //
 // Fast path (FT = true: every tap <= 255 and 255*sum(taps) <= 65535, i.e. the row sums cannot saturate — true for the
-// default taps): the patch is fetched as aligned dwords straight into an LDS tile that keeps the source misalignment,
+// default taps): the patch is fetched as (unaligned) dwords straight into an LDS tile aligned to the patch,
 // the row pass is two v_dot4_u32_u8 per output on v_alignbyte'd windows, the row sums are stored TRANSPOSED as u16
 // so that the column pass is four v_dot2_u32_u16 per output (two vertically adjacent outputs share their loads; odd
 // rows use a tap packing shifted by one element instead of shifting data).  Integer sums are exact, so this is
@@ -122,14 +122,15 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     // ---- raw 43x43 neighbourhood.  Interior keypoints: aligned dword rows, the tile keeps the source misalignment `sh`.
     //      Patches that touch the level border: byte loads with BORDER_REFLECT_101.
     const int x0 = cx - 21, y0 = cy - 21;
-    const bool interior = x0 >= 0 && y0 >= 0 && cy + 21 < L.h && cx + 24 < L.w && (((uintptr_t)base | pitch) & 3) == 0;
-    const int sh = (FT && interior) ? (x0 & 3) : 0;
+    const bool interior = x0 >= 0 && y0 >= 0 && cy + 21 < L.h && cx + 24 < L.w;
     if (FT && interior) {
-        const uint8_t* src = base + (size_t)y0 * pitch + (x0 - sh);
-        const int ndw = (sh + RAW_N + 3) >> 2;             // 11 or 12
-        for (int i = lane; i < RAW_N * 12; i += 64) {
-            int r = i / 12, q = i - r * 12;
-            if (q < ndw) *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = *reinterpret_cast<const uint32_t*>(src + (size_t)r * pitch + 4 * q);
+        // 11 dwords per row starting at the patch's own first byte: gfx9 global loads take unaligned dword addresses, so the LDS tile
+        // is aligned to the patch and the row pass below needs no per-keypoint byte shifts
+        struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
+        const uint8_t* src = base + (size_t)y0 * pitch + x0;
+        for (int i = lane; i < RAW_N * 11; i += 64) {
+            int r = i / 11, q = i - r * 11;
+            *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = reinterpret_cast<const U32*>(src + (size_t)r * pitch + 4 * q)->v;
         }
     } else {
         for (int i = lane; i < RAW_N * RAW_N; i += 64) {
@@ -146,16 +147,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         const uint32_t t456 = tp[4] | (tp[5] << 8) | (tp[6] << 16);
         for (int i = lane; i < RAW_N * 10; i += 64) {
             const int r = i / 10, gq = i - r * 10;
-            const int b0 = sh + 4 * gq;                        // first byte of the first window of this group
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(&raw[r * RAW_P + (b0 & ~3)]);
-            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];   // bytes beyond the row only meet the zero tap
-            const int s = b0 & 3;
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(&raw[r * RAW_P + 4 * gq]);
+            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int c = 4 * gq + j;
-                const int t = s + j;                            // 0..6
-                const uint32_t lo = t < 4 ? __builtin_amdgcn_alignbyte(d1, d0, t) : __builtin_amdgcn_alignbyte(d2, d1, t - 4);
-                const uint32_t hi = t < 4 ? __builtin_amdgcn_alignbyte(d2, d1, t) : __builtin_amdgcn_alignbyte(d3, d2, t - 4);
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, j);
+                const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, j);
                 const uint32_t hsum = __builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
                 if (c < BL_N) hb[c * HT_P + r] = (uint16_t)hsum;
             }
