@@ -84,7 +84,6 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][H_ELEMS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bl[KP_PER_BLOCK][BL_N * BL_P];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int img = blockIdx.y;
@@ -114,7 +113,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     if (level == 0) { base = hs_img0_ptr(img0, img); pitch = img0.row_stride; }
     else { base = L.base + (size_t)img * L.img_stride; pitch = L.pitch; }
 
-    uint8_t* raw = s_raw[wv]; uint16_t* hb = s_h[wv]; uint8_t* bl = s_bl[wv];
+    uint8_t* raw = s_raw[wv]; uint16_t* hb = s_h[wv];
+    uint8_t* bl = s_raw[wv];      // the blurred 37x37 tile reuses the raw tile's LDS: the raw bytes are dead once the row pass has run
     uint32_t tp[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) tp[k] = taps7[k];

@@ -29,6 +29,7 @@
 // Bound: integer VALU + LDS byte reads; HBM bytes = P per frame.
 #include "hs_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 // LDS layout, sized on the host from the largest cell of the configured geometry (a 1080p frame needs ~9 KB per workgroup,
 // so the wave limit, not LDS, decides how many cells a CU has in flight)
@@ -41,7 +42,9 @@ struct FastLds {
     int32_t off_score, off_list, total;
 };
 #define FAST_NT 64                           // one wavefront per workgroup (see above)
-#define NPRE (1536 / FAST_NT)                // prefetched dwords per lane: 1536 >= 70 rows x 19 dwords
+#ifndef FAST_WAVES_PER_SIMD
+#define FAST_WAVES_PER_SIMD 6                // register budget: 80 VGPRs (the kernel is latency bound: resident waves are what it needs)
+#endif
 
 // The workgroup is one wave: its LDS operations execute in program order, so a hand-off through LDS only needs the LDS queue
 // drained (no s_barrier, and no vmcnt wait that would expose the latency of the next cell's prefetch).
@@ -135,8 +138,9 @@ __device__ __forceinline__ void cell_next(CellGeom& g, const HsLevel* __restrict
     cell_fill(g, lv, img0);
 }
 
-template <int TILE_PITCH, int SCORE_PITCH>
-__global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0, int fast_th,
+// NPRE = prefetched dwords per lane (64 * NPRE >= rows * dwords of the largest tile)
+template <int TILE_PITCH, int SCORE_PITCH, int NPRE>
+__global__ __launch_bounds__(FAST_NT, FAST_WAVES_PER_SIMD) void k_fast_cells(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0, int fast_th,
                                                     uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
                                                     int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                     int total_cells, int total_work, FastLds lds)
@@ -216,22 +220,40 @@ __global__ __launch_bounds__(FAST_NT) void k_fast_cells(const HsLevel* __restric
 
         // ---- pass 1 (every pixel): quick reject on the four compass points.  A 9-arc of the 16-ring always holds two
         //      ADJACENT compass points, i.e. (p0 or p8) and (p4 or p12).
-        const int npix = iw * ih;
-        const float rcp_iw = __builtin_amdgcn_rcpf((float)iw);  // floor(p/iw) via (p+0.5)*rcp: exact for p < 4096, iw <= 64 even at 1 ulp
         int n_maybe = 0;                                         // wave-uniform
-        for (int p0 = 0; p0 < npix; p0 += FAST_NT) {
-            const int p = p0 + tid;
-            const int pc = min(p, npix - 1);
-            int py = (int)(((float)pc + 0.5f) * rcp_iw), px = pc - py * iw;
-            const uint8_t* ctr = &tile[(py + 3) * TILE_PITCH + off + px + 3];
-            int v = ctr[0];
-            int lo = v - t, hi = v + t;
-            int r0 = ctr[RO[0]], r8 = ctr[RO[8]], r4 = ctr[RO[4]], r12 = ctr[RO[12]];
-            bool dk = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
-            bool br = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
-            const bool hit = p < npix && (dk || br);
-            const int slot = wave_append(hit, n_maybe);
-            if (hit) list[slot] = (uint16_t)((py << 8) | px);
+        {
+            // Four horizontally adjacent pixels per lane: the tile row is read as aligned dwords (centre dword, its two neighbours,
+            // the dwords 3 rows above and below) and every operand is a byte lane of those registers (SDWA), so a pixel costs
+            // ~12 VALU ops and 1.25 LDS loads instead of 5 byte loads + address math.
+            const int c_first = off + 3, c_end = off + 3 + iw;   // tile columns of the interior
+            const int g0 = c_first >> 2, ng = ((c_end + 3) >> 2) - g0;
+            const int ntask = ih * ng;
+            const float rcp_ng = __builtin_amdgcn_rcpf((float)ng);
+            for (int q0 = 0; q0 < ntask; q0 += FAST_NT) {
+                const int q = q0 + tid;
+                const int qc = min(q, ntask - 1);
+                const int py = (int)(((float)qc + 0.5f) * rcp_ng), gi = qc - py * ng;
+                const int tc = (g0 + gi) << 2;
+                const uint32_t* rowc = reinterpret_cast<const uint32_t*>(&tile[(py + 3) * TILE_PITCH + tc]);
+                const uint32_t Cm = rowc[-1], Cc = rowc[0], Cp = rowc[1];
+                const uint32_t Tt = *reinterpret_cast<const uint32_t*>(&tile[(py + 0) * TILE_PITCH + tc]);     // ring 8: (0,-3)
+                const uint32_t Bb = *reinterpret_cast<const uint32_t*>(&tile[(py + 6) * TILE_PITCH + tc]);     // ring 0: (0,+3)
+                const uint32_t Lw = __builtin_amdgcn_alignbyte(Cc, Cm, 1);    // bytes tc-3 .. tc   -> ring 12 of pixels 0..3
+                const uint32_t Rw = __builtin_amdgcn_alignbyte(Cp, Cc, 3);    // bytes tc+3 .. tc+6 -> ring 4 of pixels 0..3
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int v = (Cc >> (8 * j)) & 0xFF;
+                    const int r0 = (Bb >> (8 * j)) & 0xFF, r8 = (Tt >> (8 * j)) & 0xFF;
+                    const int r4 = (Rw >> (8 * j)) & 0xFF, r12 = (Lw >> (8 * j)) & 0xFF;
+                    const int lo = v - t, hi = v + t;
+                    const bool dk = (r0 < lo || r8 < lo) && (r4 < lo || r12 < lo);
+                    const bool br = (r0 > hi || r8 > hi) && (r4 > hi || r12 > hi);
+                    const int px = tc + j - c_first;
+                    const bool hit = q < ntask && px >= 0 && px < iw && (dk || br);
+                    const int slot = wave_append(hit, n_maybe);
+                    if (hit) list[slot] = (uint16_t)((py << 8) | px);
+                }
+            }
         }
         WAVE_LDS_FENCE();
 
@@ -327,13 +349,18 @@ void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, in
     L.off_list = o; o = up(o + 2 * max_wcell * max_hcell, 16);
     L.total = o;
     const int total_work = total_cells * batch;
-    int per_cu = std::min(2048 / FAST_NT, std::max(1, (160 * 1024) / L.total));   // wave limit (32 per CU) or LDS
+    int per_cu = std::min(4 * FAST_WAVES_PER_SIMD, std::max(1, (160 * 1024) / L.total));   // resident waves per CU (register budget) or LDS
+    if (const char* e = getenv("HS_FAST_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));   // tuning knob
     int nblk = 256 * per_cu;                               // persistent single-wave workgroups
     while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD dealing)
-    if (small)
-        hipLaunchKernelGGL((k_fast_cells<48, 40>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+    const int tile_dwords = (max_hcell + 6) * ((3 + max_wcell + 6 + 3) / 4);
+    if (small && tile_dwords <= 64 * 8)
+        hipLaunchKernelGGL((k_fast_cells<48, 40, 8>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+                           cand_img_stride, total_cells, total_work, L);
+    else if (small)
+        hipLaunchKernelGGL((k_fast_cells<48, 40, 16>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
                            cand_img_stride, total_cells, total_work, L);
     else
-        hipLaunchKernelGGL((k_fast_cells<80, HS_MAX_CELL + 4>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
+        hipLaunchKernelGGL((k_fast_cells<80, HS_MAX_CELL + 4, 24>), dim3(nblk), dim3(FAST_NT), L.total, s, d_lv, nlevels, img0, fast_th, cand_xy, cand_sk, cell_count,
                            cand_img_stride, total_cells, total_work, L);
 }
