@@ -124,6 +124,30 @@ def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
     stage_parity(synth_image(40 + w, w, h), nfeat, scale)
 
 
+def test_custom_blur_taps_and_large_cells(gpu):
+    """non-default parameters: a 256-sum tap set and taps that overflow a byte (generic blur path), and N_CELLS = 40
+    (cells wider than 37 px: the general FAST tile variant)."""
+    img = synth_image(77, 640, 480)
+    for taps in ([16, 34, 50, 56, 50, 34, 16], [300, 20, 10, 5, 10, 20, 300]):
+        p = oracle.default_params(800)
+        for i, t in enumerate(taps):
+            p.blur_taps[i] = t
+        ok, od = oracle.extract(p, img)
+        ex = HS.ORBExtractor(settings(800), blur_taps=taps)
+        gk, gd = ex(img)
+        assert_same_features(gk, gd, ok, od)
+    p = oracle.default_params(800)
+    p.cell_px = 40
+    ok, od = oracle.extract(p, img)
+    s = settings(800)
+    s.N_CELLS = 40
+    gk, gd = HS.ORBExtractor(s)(img)
+    assert_same_features(gk, gd, ok, od)
+    s.N_CELLS = 300                                           # one cell wider than 64 px: rejected, never mis-computed
+    with pytest.raises(HS.HsError):
+        HS.ORBExtractor(s)(img)
+
+
 def test_empty_flat_and_noise_frames(gpu):
     ex = HS.ORBExtractor(settings(500))
     k, d = ex(np.zeros((0, 0), np.uint8))
