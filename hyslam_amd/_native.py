@@ -69,7 +69,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
-    "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
+    "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
@@ -118,6 +118,7 @@ def lib():
                                    vp, f32, f32, C.c_int, vp, vp]
     L.hs_search_by_bow_ex.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                       vp, vp, vp, f32, f32, f32, f32, C.c_int, vp, vp]
+    L.hs_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FrameView), vp, C.c_int, f32, f32, vp, vp]
     L.hs_bow_transform.argtypes = [vp, C.POINTER(VocabTree), vp, C.c_int, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]

@@ -690,6 +690,48 @@ int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1
     return HS_OK;
 }
 
+int hs_search_for_initialization(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1, const hs_frame_view* F2,
+                                 float* prev_matched_xy, int window, float th_low, float nnratio, int32_t* matches12, int32_t* n_matches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!F2 || n1 < 0 || !n_matches || F2->n < 0 || F2->n > 65535 || (n1 > 0 && (!kps1 || !desc1 || !prev_matched_xy || !matches12)) ||
+        (F2->n > 0 && (!F2->kps || !F2->desc)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_matches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || F2->n == 0) return HS_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n2 = F2->n;
+    int rc = scratch_begin(h, pad256((size_t)n1 * sizeof(hs_keypoint)) + pad256((size_t)n2 * sizeof(hs_keypoint)) + pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) +
+                              pad256((size_t)n2 * 2) + pad256((size_t)n1 * 8) + 4 * pad256((size_t)n2 * 4) + 256);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    hs_keypoint* d_k1 = carve<hs_keypoint>(h, n1); hs_keypoint* d_k2 = carve<hs_keypoint>(h, n2);
+    uint8_t* d_d1 = carve<uint8_t>(h, (size_t)n1 * 32); uint8_t* d_d2 = carve<uint8_t>(h, (size_t)n2 * 32);
+    int8_t* d_cell = carve<int8_t>(h, (size_t)n2 * 2); float* d_prev = carve<float>(h, (size_t)n1 * 2);
+    int32_t* d_owner = carve<int32_t>(h, n2); int32_t* d_odist = carve<int32_t>(h, n2); float* d_ang = carve<float>(h, n2); int32_t* d_self = carve<int32_t>(h, n2);
+    int32_t* d_nm = carve<int32_t>(h, 1);
+    HIP_TRY(h, hipMemcpyAsync(d_k1, kps1, (size_t)n1 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_k2, F2->kps, (size_t)n2 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_d2, F2->desc, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_prev, prev_matched_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
+    hs_launch_frame_grid(*F2, d_k2, d_cell, s);
+    hs_launch_search_init(*F2, d_k2, d_d2, d_cell, d_k1, d_d1, n1, d_prev, (float)window, th_low, nnratio, d_owner, d_odist, d_ang, d_self, d_nm, s);
+    HIP_TRY(h, hipGetLastError());
+    std::vector<int32_t> owner(n2);
+    HIP_TRY(h, hipMemcpyAsync(owner.data(), d_owner, (size_t)n2 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int i2 = 0; i2 < n2; i2++) {                          // matches_inverse + vbPrevMatched update (:446-458)
+        const int i1 = owner[i2];
+        if (i1 < 0) continue;
+        matches12[i1] = i2;
+        prev_matched_xy[2 * i1] = F2->kps[i2].x; prev_matched_xy[2 * i1 + 1] = F2->kps[i2].y;
+    }
+    return HS_OK;
+}
+
 int hs_bow_transform(hs_orb* h, const hs_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id)
 {
     if (!h) return HS_ERR_INVALID;

@@ -99,3 +99,6 @@ void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int3
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);
 void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, const int32_t* d_cc, const uint8_t* d_ndesc, const int32_t* d_word,
                              const float* d_weight, int levels, int levelsup, int32_t* d_out_word, float* d_out_weight, int32_t* d_out_node, hipStream_t s);
+void hs_launch_search_init(const hs_frame_view& F2, const hs_keypoint* d_kps2, const uint8_t* d_desc2, const int8_t* d_cell2,
+                           const hs_keypoint* d_kps1, const uint8_t* d_desc1, int n1, const float* d_prev_xy, float window, float th_low, float nnratio,
+                           int32_t* d_owner, int32_t* d_odist, float* d_angle_scratch, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);

@@ -458,3 +458,73 @@ void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, 
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, s, n, d_desc, d_cb, d_cc, d_ndesc, d_word, d_weight, levels, levelsup,
                        d_out_word, d_out_weight, d_out_node);
 }
+
+// SearchForInitialization: ONE workgroup, sequential over frame-1 keypoints, parallel inside each step.
+// owner[i2] = frame-1 index currently matched to frame-2 keypoint i2 (-1 none), odist[i2] = its distance (global scratch, L2-resident).
+__global__ __launch_bounds__(1024) void k_search_init(HsFrameDev F2, const uint8_t* __restrict__ desc1, int n1, const float* __restrict__ prev_xy,
+                                                      float window, float th_low, float nnratio, int32_t* __restrict__ owner, int32_t* __restrict__ odist)
+{
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_second[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < F2.n; i += 1024) { owner[i] = -1; odist[i] = -1; }
+    __syncthreads();
+    const float invW = (float)GRID_COLS / (F2.max_x - F2.min_x), invH = (float)GRID_ROWS / (F2.max_y - F2.min_y);
+    const float r = window;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const float x = prev_xy[2 * i1], y = prev_xy[2 * i1 + 1];
+        const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, F2.min_x), r), invW)));
+        const int maxCX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, F2.min_x), r), invW)));
+        const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, F2.min_y), r), invH)));
+        const int maxCY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, F2.min_y), r), invH)));
+        unsigned long long best = NO_KEY; int second = NO_DIST;
+        if (!(minCX >= GRID_COLS || maxCX < 0 || minCY >= GRID_ROWS || maxCY < 0)) {
+            const unsigned long long* d1 = reinterpret_cast<const unsigned long long*>(desc1 + (size_t)i1 * 32);
+            const unsigned long long a0 = d1[0], a1 = d1[1], a2 = d1[2], a3 = d1[3];
+            for (int i2 = tid; i2 < F2.n; i2 += 1024) {
+                const int cx = F2.cell[2 * i2], cy = F2.cell[2 * i2 + 1];
+                if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;
+                const hs_keypoint kp = F2.kps[i2];
+                if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;
+                const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F2.desc + (size_t)i2 * 32);
+                const int d = __popcll(a0 ^ dk[0]) + __popcll(a1 ^ dk[1]) + __popcll(a2 ^ dk[2]) + __popcll(a3 ^ dk[3]);
+                const int dp = odist[i2];
+                if (dp >= 0 && !(d < dp)) continue;                         // MonoInitScoreExceedsPrevious
+                const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned)i2;
+                if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+                else second = min(second, d);
+            }
+        }
+        wave_best2(best, second);
+        if (lane == 0) { s_best[wv] = best; s_second[wv] = second; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = NO_KEY; int s2 = NO_DIST;
+            for (int w = 0; w < 16; w++) {
+                const unsigned long long ob = s_best[w]; const int os = s_second[w];
+                const int worse = max((int)(b >> 32), (int)(ob >> 32));
+                b = min(b, ob); s2 = min(min(s2, os), worse);
+            }
+            if (b != NO_KEY) {                                               // MonoInitBestScore accept rule
+                const float bd = (float)(int)(b >> 32), bd2 = s2 == NO_DIST ? FLT_MAX : (float)s2;
+                if (bd <= th_low && bd < __fmul_rn(bd2, nnratio)) { const int i2 = (int)(b & 0xFFFF); owner[i2] = i1; odist[i2] = (int)(b >> 32); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void hs_launch_search_init(const hs_frame_view& F2, const hs_keypoint* d_kps2, const uint8_t* d_desc2, const int8_t* d_cell2,
+                           const hs_keypoint* d_kps1, const uint8_t* d_desc1, int n1, const float* d_prev_xy, float window, float th_low, float nnratio,
+                           int32_t* d_owner, int32_t* d_odist, float* d_angle_scratch, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s)
+{
+    HsFrameDev D{}; D.min_x = F2.min_x; D.max_x = F2.max_x; D.min_y = F2.min_y; D.max_y = F2.max_y; D.n = F2.n;
+    D.kps = d_kps2; D.desc = d_desc2; D.cell = d_cell2;
+    hipLaunchKernelGGL(k_search_init, dim3(1), dim3(1024), 0, s, D, d_desc1, n1, d_prev_xy, window, th_low, nnratio, d_owner, d_odist);
+    // RotationConsistency(matches, views2, views1): entries keyed by the frame-2 index, rot = angle1[owner] - angle2[i2]
+    const int g = (F2.n + 255) / 256;
+    hipLaunchKernelGGL(k_gather_angle, dim3(g), dim3(256), 0, s, F2.n, d_owner, d_kps1, d_angle_scratch);
+    hipLaunchKernelGGL(k_iota_where, dim3(g), dim3(256), 0, s, F2.n, d_owner, d_self_scratch);
+    hipLaunchKernelGGL(k_rotation_filter, dim3(1), dim3(1024), 0, s, F2.n, d_self_scratch, d_angle_scratch, d_kps2, (int32_t*)nullptr, 0, 0, d_n_matches);
+    hipLaunchKernelGGL(k_mask_by, dim3(g), dim3(256), 0, s, F2.n, d_self_scratch, d_owner);
+}

@@ -254,6 +254,19 @@ class FeatureMatcher:
         landmarks = pKF's map points minus sAlreadyFound.  Its rotation criterion is a no-op in the reference (no previous frame)."""
         return self._project(frame, landmarks, N.ProjParams(th, float(ORBdist), 1.0, 0.5, 1.5, 1, 0, 0))
 
+    def SearchForInitialization(self, kps1, desc1, frame2, vbPrevMatched, windowSize=10):
+        """SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (FeatureMatcher.cc:404-462).  frame2 is a FrameView (grid
+        bounds + keypoints + descriptors).  Returns (vnMatches12, updated vbPrevMatched, number of matches)."""
+        ex = self._ex
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        m = np.full(len(k1), -1, np.int32)
+        n = C.c_int32()
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_for_initialization(ex._h, p(k1), p(d1), len(k1), C.byref(frame2), p(prev), int(windowSize),
+                                                            self.TH_LOW, self.mfNNratio, p(m), C.byref(n)))
+        return m, prev, n.value
+
     def Fuse(self, keyframe, landmarks, th=3.0, reprojection_err=5.99):
         """Fuse(pKF, vpMapPoints, fuse_matches, th, reprojection_err) (FeatureMatcher.cc:464-521).  The caller sets skip = 1 on landmarks
         that are bad, already observed in pKF or protected (:480-485).  Returns per-landmark keypoint indices (first landmark per keypoint)."""

@@ -213,6 +213,15 @@ int  hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc
                          float score_threshold, float second_best_ratio, int check_rotation,
                          int32_t* match12, int32_t* n_matches);
 
+/* FeatureMatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (FeatureMatcher.cc:404-462; monocular map
+ * initialisation, MonoInitializer.cpp:83).  Inherently sequential over F1's keypoints — a later keypoint takes over an F2 keypoint only
+ * with a strictly smaller distance (MatchCriteria.cpp:525-549) — so one workgroup walks F1 in order and parallelises the window search
+ * and the best / second-best reduction of each step.  F2 supplies the grid bounds, keypoints and descriptors (pose fields unused).
+ * prev_matched_xy [n1][2] is vbPrevMatched (in/out), matches12 [n1] is vnMatches12.  Host pointers; synchronous. */
+int  hs_search_for_initialization(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1, const hs_frame_view* F2,
+                                  float* prev_matched_xy, int window, float th_low, float nnratio,
+                                  int32_t* matches12, int32_t* n_matches);
+
 /* Vocabulary transform: what Frame::ComputeBoW / KeyFrame::ComputeBoW obtain from ORBVocabulary::transform -> DBoW2::TemplatedVocabulary<FORB>
  * ::transform(features, bow, fv, levelsup=4) (src/core/Frame.cc:472-479, src/features/low_level/ORBVocabulary.cpp:31-42).  DBoW2 and the
  * ORBvoc data are not part of the reference tree; the tree descent follows DBoW2's published algorithm (first minimum wins at every level).

@@ -211,6 +211,12 @@ typedef struct hso_vocab_tree {
 } hso_vocab_tree;
 void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id);
 
+/* FeatureMatcher::SearchForInitialization (FeatureMatcher.cc:404-462) with MonoInitScoreExceedsPrevious / MonoInitBestScore
+ * (MatchCriteria.cpp:486-549): sequential over frame-1 keypoints (a later keypoint can steal a frame-2 keypoint only with a strictly
+ * smaller distance).  F2 = frame 2 (grid bounds, keypoints, descriptors); prev_matched_xy[n1][2] in/out; matches12[n1] = frame-2 index or -1. */
+int hso_search_for_initialization(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const hso_frame_view* F2,
+                                  float* prev_matched_xy, int window, float th_low, float nnratio, int32_t* matches12);
+
 /* brute-force Hamming 2-NN of every query against every train descriptor: best index, best and second-best distance
  * (first minimum wins, like every best/second-best loop of the reference, e.g. MatchCriteria.cpp:248-280) */
 void hso_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);

@@ -347,6 +347,48 @@ int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1,
     return (int)matches_internal.size();
 }
 
+int hso_search_for_initialization(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const hso_frame_view* F2v,
+                                  float* prev_matched_xy, int window, float th_low, float nnratio, int32_t* matches12)
+{
+    Frame F2(*F2v);
+    MatchesIdx matches;                        // idx in frame 2 -> idx in frame 1
+    std::map<size_t, float> distances;         // MonoCriteriaData::distances
+    for (int i1 = 0; i1 < n1; i1++) {
+        std::vector<size_t> cand = F2.GetFeaturesInAreaNEW(prev_matched_xy[2 * i1], prev_matched_xy[2 * i1 + 1], (float)window);   // no level check (:415)
+        if (cand.empty()) continue;
+        const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+        {   // MonoInitScoreExceedsPrevious :525-549
+            std::vector<size_t> passed;
+            for (size_t i2 : cand) {
+                auto it = distances.find(i2);
+                float dist_prev = it != distances.end() ? it->second : -1;
+                if (dist_prev < 0) passed.push_back(i2);
+                else { int dist = (int)ORBDistance(d1, F2v->desc + i2 * 32); if (dist < dist_prev) passed.push_back(i2); }
+            }
+            cand.swap(passed);
+        }
+        // MonoInitBestScore :486-523
+        float bestDist = std::numeric_limits<float>::max(), bestDist2 = std::numeric_limits<float>::max();
+        int bestIdx = -1;
+        for (size_t i2 : cand) {
+            float dist = ORBDistance(d1, F2v->desc + i2 * 32);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= th_low && bestDist < (float)bestDist2 * nnratio) {
+            matches[bestIdx] = i1;                                            // overwrites any old match (:433)
+            distances[bestIdx] = ORBDistance(d1, F2v->desc + (size_t)bestIdx * 32);
+        }
+    }
+    matches = RotationConsistency(matches, [&](size_t i2) { return F2v->kps[i2].angle; }, [&](size_t i1) { return kps1[i1].angle; });   // (matches, views2, views1) :443
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (auto& m : matches) {
+        matches12[m.second] = (int32_t)m.first;
+        prev_matched_xy[2 * m.second] = F2v->kps[m.first].x; prev_matched_xy[2 * m.second + 1] = F2v->kps[m.first].y;          // :456
+    }
+    return (int)matches.size();
+}
+
 void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id)
 {
     const int nid_level = T->levels - levelsup;

@@ -362,3 +362,12 @@ def bow_transform(T, desc, levelsup):
     lib().hso_bow_transform(C.byref(T), desc.ctypes.data_as(C.c_void_p), n, levelsup, w.ctypes.data_as(C.c_void_p),
                             wt.ctypes.data_as(C.c_void_p), nd.ctypes.data_as(C.c_void_p))
     return w, wt, nd
+
+
+def search_for_initialization(k1, d1, F2, prev_xy, window, th_low, nnratio):
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); d1 = np.ascontiguousarray(d1, np.uint8)
+    prev = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2).copy()
+    m = np.full(len(k1), -1, np.int32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    n = lib().hso_search_for_initialization(p(k1), p(d1), len(k1), C.byref(F2), p(prev), int(window), C.c_float(th_low), C.c_float(nnratio), p(m))
+    return m, prev, n

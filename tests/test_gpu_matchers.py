@@ -149,6 +149,17 @@ def test_vocabulary_transform_and_bow_pipeline(matcher):
     assert gn > 300                                                     # levelsup 4 = root node: one big group, most points re-found
 
 
+def test_search_for_initialization(matcher):
+    from test_oracle_matchers import mono_init_scene
+    for seed, window in ((51, 100), (52, 20)):
+        k1, d1, fa, prev = mono_init_scene(seed, 1000)
+        Fo, ko = oracle.make_frame_view(oracle.FrameView, **fa)
+        Fg, kg = oracle.make_frame_view(N.FrameView, **fa)
+        gm, gprev, gn = matcher.SearchForInitialization(k1, d1, Fg, prev, window)
+        om, oprev, on = oracle.search_for_initialization(k1, d1, Fo, prev, window, 50.0, 0.8)
+        assert on > 100 and gn == on and np.array_equal(gm, om) and np.array_equal(gprev, oprev), (seed, window)
+
+
 def test_knn2(matcher):
     rng = np.random.default_rng(6)
     q = rng.integers(0, 256, (2000, 32), dtype=np.uint8)

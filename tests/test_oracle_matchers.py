@@ -266,3 +266,56 @@ def test_vocabulary_transform_descends_to_nearest_children():
             assert (w[i], node[i]) == (word[cur], nid) and wt[i] == weight[cur]
         assert 0 <= w.min() and w.max() < n_words
     assert (oracle.bow_transform(T, desc, 3)[2] == 0).all() and (oracle.bow_transform(T, desc, 9)[2] == 0).all()     # root when levelsup >= L
+
+
+def mono_init_scene(seed, n_keep=400):
+    """Two mono frames of the same points: frame 2 = frame 1 moved by a few pixels, descriptors with some flipped bits, shuffled."""
+    sc = scenes.projection_scene(seed, 320, 240, nfeat=n_keep, copies=1, fx=260.0)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(len(k1))
+    k2, d2 = k1[perm].copy(), d1[perm].copy()
+    k2["x"] += rng.normal(6, 3, len(k2)).astype(np.float32); k2["y"] += rng.normal(-4, 3, len(k2)).astype(np.float32)
+    k2["angle"] = (k2["angle"] + rng.normal(0, 5, len(k2)) + (rng.random(len(k2)) < 0.1) * 150) % 360
+    for i in range(len(d2)):
+        for b in rng.integers(0, 256, rng.integers(0, 25)):
+            d2[i, b >> 3] ^= 1 << (b & 7)
+    fa = dict(sc["frame_args"]); fa.update(kps=k2, desc=d2, uR=None, kp_lm_obs=None, sensor=0)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    return k1, d1, fa, prev
+
+
+def test_search_for_initialization_against_python_restatement():
+    k1, d1, fa, prev = mono_init_scene(26)
+    F2, keep = oracle.make_frame_view(oracle.FrameView, **fa)
+    m, prev_out, n = oracle.search_for_initialization(k1, d1, F2, prev, 30, 50.0, 0.9)
+    # python restatement: sequential loop, brute-force window (grid cell range of the query + |dx|,|dy| < r), steal-only-if-better
+    k2, d2 = fa["kps"], fa["desc"]
+    f32 = np.float32
+    invW, invH = f32(64) / f32(320), f32(48) / f32(240)
+    gx = np.floor((k2["x"] * invW) + f32(0.5)).astype(int); gy = np.floor((k2["y"] * invH) + f32(0.5)).astype(int)
+    ingrid = (gx >= 0) & (gx < 64) & (gy >= 0) & (gy < 48)
+    owner, odist = {}, {}
+    r = f32(30)
+    for i1 in range(len(k1)):
+        x, y = prev[i1]
+        x0 = max(0, int(np.floor(f32(f32(x - r) * invW)))); x1 = min(63, int(np.ceil(f32(f32(x + r) * invW))))
+        y0 = max(0, int(np.floor(f32(f32(y - r) * invH)))); y1 = min(47, int(np.ceil(f32(f32(y + r) * invH))))
+        c = np.nonzero(ingrid & (gx >= x0) & (gx <= x1) & (gy >= y0) & (gy <= y1) & (np.abs(k2["x"] - x) < r) & (np.abs(k2["y"] - y) < r))[0]
+        if len(c) == 0:
+            continue
+        c = c[np.lexsort((c, gy[c], gx[c]))]
+        d = np.unpackbits(d2[c] ^ d1[i1][None, :], axis=1).sum(1)
+        ok = np.array([(i2 not in odist) or (dd < odist[i2]) for i2, dd in zip(c.tolist(), d.tolist())], bool)
+        c, d = c[ok], d[ok]
+        if len(c) == 0:
+            continue
+        b = int(np.argmin(d)); second = np.sort(d)[1] if len(d) > 1 else np.finfo(np.float32).max
+        if d[b] <= 50 and f32(d[b]) < f32(second) * f32(0.9):
+            owner[int(c[b])] = i1; odist[int(c[b])] = int(d[b])
+    idx2 = np.array(sorted(owner)); i1s = np.array([owner[i] for i in idx2])
+    keepm = oracle.rotation_consistency(k2["angle"][idx2], k1["angle"][i1s])           # rot = prev(views1) - curr(views2)
+    ref = np.full(len(k1), -1, np.int32); ref[i1s[keepm]] = idx2[keepm]
+    assert np.array_equal(m, ref) and n == keepm.sum() > 100
+    moved = m >= 0
+    assert np.array_equal(prev_out[moved], np.stack([k2["x"][m[moved]], k2["y"][m[moved]]], 1)) and np.array_equal(prev_out[~moved], prev[~moved])
