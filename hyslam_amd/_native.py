@@ -68,7 +68,7 @@ EXPORTS = [
     "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
-    "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_synchronize",
+    "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
     "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
@@ -111,6 +111,7 @@ def lib():
     L.hs_stereo_match_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
     L.hs_stereo_frontend_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, sz, sz,
                                                   vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
+    L.hs_orb_set_lanes.argtypes = [vp, C.c_int]
     L.hs_orb_synchronize.argtypes = [vp, vp]
     L.hs_search_by_projection.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
     L.hs_search_by_projection_device.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp, vp]

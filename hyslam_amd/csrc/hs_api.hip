@@ -45,6 +45,8 @@ struct hs_orb {
     int last_batch = 0; HsImg0 last_img0{};
     // bump-allocated scratch for the host-pointer matcher entry points
     uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
+    // second lane (hs_orb_set_lanes): a child handle with its own workspace and stream, fenced against the caller's stream by two events
+    hs_orb* lane2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling: events[i] marks the start of stage prof_stage[i]; the event after the last stage has stage -1
     bool prof = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -363,6 +365,9 @@ void hs_orb_destroy(hs_orb* h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->lane2) { hs_orb_destroy(h->lane2); h->lane2 = nullptr; }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_geometry(h);
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
@@ -415,6 +420,24 @@ int hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, int
     if (!d_imgs || !d_kps || !d_desc || !d_n || batch < 1 || row_stride < (size_t)w || cap < 1 || cap > 65535)
         return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->lane2 && batch >= 2) {      // two lanes: the second half runs on the child handle's stream, fenced by fork / join events
+        hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+        const int b0 = batch / 2, b1 = batch - b0;
+        h->lane2->prof = h->prof;
+        HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->lane2->stream, h->ev_fork, 0));
+        hs_orb* child = h->lane2; h->lane2 = nullptr;          // the recursive calls below must not split again
+        int rc = hs_orb_extract_batch_device(h, d_imgs, b0, w, h_px, row_stride, image_stride, d_kps, d_desc, d_n, cap, s);
+        if (rc == HS_OK) {
+            rc = hs_orb_extract_batch_device(child, d_imgs + (size_t)b0 * image_stride, b1, w, h_px, row_stride, image_stride,
+                                             d_kps + (size_t)b0 * cap, d_desc + (size_t)b0 * cap * HS_DESC_BYTES, d_n + b0, cap, child->stream);
+            if (rc != HS_OK) h->err = child->err;
+        }
+        h->lane2 = child;
+        HIP_TRY(h, hipEventRecord(h->ev_join, child->stream));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join, 0));
+        return rc;
+    }
     int rc = configure(h, w, h_px, batch);
     if (rc != HS_OK) return rc;
     if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
@@ -541,6 +564,27 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
         pairs < 1 || 2 * pairs > 65535 || row_stride < (size_t)w || cap < 1 || cap > 65535)
         return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->lane2 && pairs >= 2) {      // two lanes: each handles half of the pairs end to end (extract L+R, match) on its own stream
+        hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+        const int p0 = pairs / 2, p1 = pairs - p0;
+        h->lane2->prof = h->prof;
+        HIP_TRY(h, hipEventRecord(h->ev_fork, s));
+        HIP_TRY(h, hipStreamWaitEvent(h->lane2->stream, h->ev_fork, 0));
+        hs_orb* child = h->lane2; h->lane2 = nullptr;
+        int rc = hs_stereo_frontend_batch_device(h, d_left, d_right, p0, w, h_px, row_stride, image_stride, d_kpsL, d_descL, d_nL,
+                                                 d_kpsR, d_descR, d_nR, cap, sp, d_uRight, d_depth, s);
+        if (rc == HS_OK) {
+            const size_t io = (size_t)p0 * image_stride, ko = (size_t)p0 * cap;
+            rc = hs_stereo_frontend_batch_device(child, d_left + io, d_right + io, p1, w, h_px, row_stride, image_stride,
+                                                 d_kpsL + ko, d_descL + ko * HS_DESC_BYTES, d_nL + p0, d_kpsR + ko, d_descR + ko * HS_DESC_BYTES, d_nR + p0,
+                                                 cap, sp, d_uRight + ko, d_depth + ko, child->stream);
+            if (rc != HS_OK) h->err = child->err;
+        }
+        h->lane2 = child;
+        HIP_TRY(h, hipEventRecord(h->ev_join, child->stream));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_join, 0));
+        return rc;
+    }
     int rc = configure(h, w, h_px, 2 * pairs);
     if (rc != HS_OK) return rc;
     if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
@@ -815,6 +859,7 @@ int hs_orb_profile_begin(hs_orb* h)
 {
     if (!h) return HS_ERR_INVALID;
     h->prof = true; h->ev_used = 0; h->prof_stage.clear();
+    if (h->lane2) { h->lane2->prof = true; h->lane2->ev_used = 0; h->lane2->prof_stage.clear(); }
     return HS_OK;
 }
 
@@ -834,6 +879,21 @@ int hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches)
         ms[st] += t; launches[st]++;
     }
     h->ev_used = 0; h->prof_stage.clear();
+    return HS_OK;
+}
+
+int hs_orb_set_lanes(hs_orb* h, int lanes)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (lanes < 1 || lanes > 2) return fail(h, HS_ERR_INVALID, "lanes must be 1 or 2");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (lanes == 1) { if (h->lane2) { hs_orb_destroy(h->lane2); h->lane2 = nullptr; } return HS_OK; }
+    if (!h->lane2) {
+        int rc = hs_orb_create(&h->p, h->device, &h->lane2);
+        if (rc != HS_OK) return fail(h, rc, "could not create the second lane");
+        if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        if (!h->ev_join) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     return HS_OK;
 }
 

@@ -152,6 +152,10 @@ class ORBExtractor:
                                                                    d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
                                                                    C.byref(sp), d_uRight, d_depth, stream or None))
 
+    def set_lanes(self, lanes):
+        """1 or 2 internal launch sequences for the batched device entry points (hs_orb_set_lanes)."""
+        N.check(self._h, self._lib.hs_orb_set_lanes(self._h, int(lanes)))
+
     def synchronize(self, stream=0):
         N.check(self._h, self._lib.hs_orb_synchronize(self._h, stream or None))
 

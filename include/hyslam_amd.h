@@ -124,6 +124,13 @@ int  hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uin
                                      hs_keypoint* d_kpsR, uint8_t* d_descR, int32_t* d_nR, int cap,
                                      const hs_stereo_params* sp, float* d_uRight, float* d_depth, void* stream);
 
+/* Concurrency inside one handle: with lanes = 2 the batched device entry points (hs_orb_extract_batch_device,
+ * hs_stereo_frontend_batch_device) split their batch in two halves that run on two streams with separate workspaces (the second lane
+ * is an internal child handle).  The kernels of this path are latency-bound rather than bandwidth-bound, so two interleaved launch
+ * sequences fill each other's stalls (+15 % pairs/s measured).  Ordering towards the caller is unchanged: all work is complete when the
+ * caller's stream reaches the point after the call.  Default 1. */
+int  hs_orb_set_lanes(hs_orb* h, int lanes);
+
 /* block until everything enqueued on the handle's own stream (or `stream`) has finished */
 int  hs_orb_synchronize(hs_orb* h, void* stream);
 

@@ -51,4 +51,25 @@ ex.extract_batch_device(left.data_ptr(), B, W, H, W, W * H, kL.data_ptr(), dL.da
 torch.cuda.synchronize()
 okL, odL = oracle.extract(p, pairs[1][0])
 assert kL.view(B, cap * kb)[1].cpu().numpy().view(N.KP_DTYPE)[:int(nL[1])].tobytes() == okL.tobytes()
+# two lanes: the batch is split over two streams inside the handle; results must not change
+ex.set_lanes(2)
+kL.zero_(); kR.zero_(); dL.zero_(); dR.zero_(); nL.zero_(); nR.zero_(); uR.zero_(); depth.zero_()
+ex.stereo_frontend_batch_device(left.data_ptr(), right.data_ptr(), B, W, H, W, W * H, kL.data_ptr(), dL.data_ptr(), nL.data_ptr(),
+                                kR.data_ptr(), dR.data_ptr(), nR.data_ptr(), cap, sp, uR.data_ptr(), depth.data_ptr(), s.cuda_stream)
+s.synchronize()
+for i in range(B):
+    okL, odL = oracle.extract(p, pairs[i][0])
+    okR, odR = oracle.extract(p, pairs[i][1])
+    ouR, odepth, _, _ = oracle.stereo_match(okL, odL, okR, odR, osp)
+    n_l = int(nL[i])
+    assert n_l == len(okL) and int(nR[i]) == len(okR), i
+    assert kL.view(B, cap * kb)[i].cpu().numpy().view(N.KP_DTYPE)[:n_l].tobytes() == okL.tobytes(), i
+    assert np.array_equal(dR.view(B, cap, 32)[i, :len(okR)].cpu().numpy(), odR), i
+    assert np.array_equal(uR.view(B, cap)[i, :n_l].cpu().numpy(), ouR) and np.array_equal(depth.view(B, cap)[i, :n_l].cpu().numpy(), odepth), i
+kL.zero_(); nL.zero_()
+ex.extract_batch_device(left.data_ptr(), B, W, H, W, W * H, kL.data_ptr(), dL.data_ptr(), nL.data_ptr(), cap, s.cuda_stream)
+s.synchronize()
+for i in range(B):
+    okL, odL = oracle.extract(p, pairs[i][0])
+    assert kL.view(B, cap * kb)[i].cpu().numpy().view(N.KP_DTYPE)[:int(nL[i])].tobytes() == okL.tobytes(), i
 print("device api ok")

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GIB = 1 << 30
 PAIRS = 16
+LANES = 2            # like bench.py's default: every kernel is launched once per lane over half of the pairs
 
 
 def run():
@@ -28,6 +29,7 @@ def run():
     from hyslam_amd.synth import synth_stereo_pair
     dev = torch.device("cuda", 0)
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000))
+    ex.set_lanes(LANES)
     src = torch.randint(0, 255, (GIB,), dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
@@ -75,7 +77,7 @@ def report(dfetch, dwrite):
             continue
         f = F[(k, "FETCH_SIZE")]; w = Wr[(k, "WRITE_SIZE")]
         fa, wa = sum(f) / len(f), sum(w) / len(w)
-        print("%s,%d,%.1f,%.1f,%.2f,%.2f,%d" % (k.replace(",", ";"), len(f), fa, wa, fa * 1024 / cal[wd][0] / 1e6, wa * 1024 / cal[wd][1] / 1e6, 2 * PAIRS))
+        print("%s,%d,%.1f,%.1f,%.2f,%.2f,%d" % (k.replace(",", ";"), len(f), fa, wa, fa * 1024 / cal[wd][0] / 1e6, wa * 1024 / cal[wd][1] / 1e6, 2 * PAIRS // LANES))
 
 
 if __name__ == "__main__":
