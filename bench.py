@@ -52,8 +52,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
-                    help="launch sequences inside the handle: 2 = the batch is split in two halves on two streams (hs_orb_set_lanes)")
+    ap.add_argument("--handles", type=int, default=2,
+                    help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
+                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  The path's kernels are latency-bound, so two "
+                         "independent launch sequences fill each other's stalls")
+    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
+                    help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
                     help="c2 = stereo extract+match (the headline metric); c3 = batched 64 mono frames, extract only (per-kernel GB/s); "
                          "c5 = one mono stream per GPU + all-gather + cross-camera 2-NN")
@@ -87,7 +91,9 @@ def main():
     left = torch.from_numpy(np.stack([pairs[i % nd][0] for i in range(B)])).to(dev)
     right = torch.from_numpy(np.stack([pairs[i % nd][1] for i in range(B)])).to(dev)
 
-    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+    nh = max(1, min(args.handles, B))
+    exs = [HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank) for _ in range(nh)]
+    ex = exs[0]
     cap = ex.max_keypoints()
     sp = HS.stereo_params(HS.Camera(fx=1050.0, mbf=1050.0 * 0.12, mnMaxY=float(H)))
     kp_bytes = N.KP_DTYPE.itemsize
@@ -99,14 +105,32 @@ def main():
     nR = torch.zeros(B, dtype=torch.int32, device=dev)
     uR = torch.empty(B * cap, dtype=torch.float32, device=dev)
     depth = torch.empty_like(uR)
-    lanes = args.lanes if B >= 2 else 1
-    ex.set_lanes(lanes)
-    stream = torch.cuda.current_stream().cuda_stream
+    from hyslam_amd.distributed import shard_range
+    parts = [shard_range(B, i, nh) for i in range(nh)]          # contiguous blocks of pairs per handle
+    lanes = args.lanes if min(b - a for a, b in parts) >= 2 else 1
+    for e, (a, b) in zip(exs, parts):
+        e.set_lanes(lanes)
+        e.reserve(W, H, 2 * (b - a))
 
     def step():
-        ex.stereo_frontend_batch_device(left.data_ptr(), right.data_ptr(), B, W, H, W, W * H,
-                                        kL.data_ptr(), dL.data_ptr(), nL.data_ptr(), kR.data_ptr(), dR.data_ptr(), nR.data_ptr(),
-                                        cap, sp, uR.data_ptr(), depth.data_ptr(), stream)
+        # every handle enqueues on its own stream (stream argument 0); nothing synchronises between handles or between steps
+        for e, (a, b) in zip(exs, parts):
+            e.stereo_frontend_batch_device(left.data_ptr() + a * W * H, right.data_ptr() + a * W * H, b - a, W, H, W, W * H,
+                                           kL.data_ptr() + a * cap * kp_bytes, dL.data_ptr() + a * cap * 32, nL.data_ptr() + 4 * a,
+                                           kR.data_ptr() + a * cap * kp_bytes, dR.data_ptr() + a * cap * 32, nR.data_ptr() + 4 * a,
+                                           cap, sp, uR.data_ptr() + 4 * a * cap, depth.data_ptr() + 4 * a * cap, 0)
+
+    def profile_begin():
+        for e in exs:
+            e.profile_begin()
+
+    def profile_end():
+        tot = {}
+        for e in exs:
+            for k, (ms, c) in e.profile_end().items():
+                m0, c0 = tot.get(k, (0.0, 0))
+                tot[k] = (m0 + ms, c0 + c)
+        return tot
 
     def fence():
         torch.cuda.synchronize()
@@ -114,20 +138,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ex.profile_begin()          # warm-up also pre-creates part of the event pool
+    profile_begin()             # warm-up also pre-creates part of the event pool
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ex.profile_end()
+    profile_end()
 
     fence()
-    ex.profile_begin()
+    profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     t1 = time.perf_counter()
-    prof = ex.profile_end()
+    prof = profile_end()
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -143,7 +167,7 @@ def main():
     if rank == 0:
         px = pyramid_pixels(ex, W, H)
         per_stage, per_frame = algorithmic_bytes(px, NFEAT)
-        frames_per_launch = 2 * B // lanes if lanes == 2 else 2 * B      # a lane launches every kernel over its half of the pairs
+        frames_per_launch = 2 * max(b - a for a, b in parts) // lanes     # every launch sequence covers its own share of the pairs
         stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items()}
         # dominant kernel among those with an HBM-byte model (the quadtree is a latency-bound LDS kernel: a host stage in the reference,
         # no compulsory HBM bytes in SURVEY.md's accounting; its time is still listed in stage_ms_per_step)
@@ -160,7 +184,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "C2: 1920x1080 stereo pair, 2000 features/frame, 8 levels @1.2, extract L+R + stereo match",
-                       "pairs_per_step_per_gpu": B, "lanes": lanes, "distinct_pairs": nd, "sharding": "frames round-robin, no collective",
+                       "pairs_per_step_per_gpu": B, "handles": nh, "lanes_per_handle": lanes, "distinct_pairs": nd, "sharding": "frames round-robin, no collective",
                        "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
