@@ -71,10 +71,10 @@ def report(dfetch, dwrite):
         cal[width] = (f, w)
         print("# calibration %-11s (1 GiB read + 1 GiB written, %2d B/lane): FETCH_SIZE reports %.3f x, WRITE_SIZE reports %.3f x of the true bytes" % (name, width, f, w))
     print("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,read_MB_per_launch_corrected,written_MB_per_launch_corrected,frames_per_launch")
-    width_of = {"k_resize_level<true>": 4, "k_fast_cells<48, 40>": 4, "k_quadtree": 4, "k_describe<true>": 4, "k_stereo_match": 4, "k_stereo_median": 4}
-    for k, wd in width_of.items():
-        if (k, "FETCH_SIZE") not in F:
-            continue
+    # every kernel of the path reads and writes 4 B/lane (dword tile rows, dword pixel groups); k_resize_level_lds reads 16 B/lane
+    kernels = sorted({k for (k, c) in F if k.startswith("k_") and not k.startswith("k_copy")})
+    for k in kernels:
+        wd = 16 if k.startswith("k_resize_level_lds") else 4
         f = F[(k, "FETCH_SIZE")]; w = Wr[(k, "WRITE_SIZE")]
         fa, wa = sum(f) / len(f), sum(w) / len(w)
         print("%s,%d,%.1f,%.1f,%.2f,%.2f,%d" % (k.replace(",", ";"), len(f), fa, wa, fa * 1024 / cal[wd][0] / 1e6, wa * 1024 / cal[wd][1] / 1e6, 2 * PAIRS // LANES))
