@@ -26,11 +26,13 @@ struct hs_orb {
     int w = 0, h = 0, batch_cap = 0;
     std::vector<HsLevel> lv;
     int total_cells = 0, max_wcell = 1, max_hcell = 1;
+    int fast_items = 0;                // FAST work items per image (HsLevel::item_begin)
     uint64_t cand_img_stride = 0;      // candidate entries per image
     int sel_img_stride = 0;            // selection entries per image
     int max_kp = 0;
     // device memory
     HsLevel* d_lv = nullptr;
+    HsFastItem* d_fast_items = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
     uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr, *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
@@ -77,6 +79,7 @@ void free_geometry(hs_orb* h)
 {
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
+    hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
     h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
@@ -95,7 +98,7 @@ int configure(hs_orb* h, int w, int hh, int batch)
     h->lv.assign(L, HsLevel{});
     std::vector<int16_t> tables;
     std::vector<size_t> tab_off(L * 4, 0);
-    size_t pyr_per_img = 0; uint64_t cand = 0; int sel = 0, cells = 0;
+    size_t pyr_per_img = 0; uint64_t cand = 0; int sel = 0, cells = 0, items = 0;
     std::vector<size_t> pyr_off(L, 0);
     for (int l = 0; l < L; l++) {
         HsLevel& V = h->lv[l];
@@ -114,6 +117,11 @@ int configure(hs_orb* h, int w, int hh, int batch)
         else { V.wcell = (int)ceilf(width / V.ncols); V.hcell = (int)ceilf(height / V.nrows); }
         if (V.wcell > HS_MAX_CELL || V.hcell > HS_MAX_CELL) return fail(h, HS_ERR_INVALID, "FAST cell larger than 64 px is not supported");
         V.cell_begin = cells; cells += V.ncols * V.nrows;
+        V.grp_cells = hs_fast_group_cells(V.wcell, V.ncols);
+        V.ngroups = V.grp_cells > 0 ? (V.ncols + V.grp_cells - 1) / V.grp_cells : 0;
+        V.item_begin = items; items += V.ngroups * V.nrows;
+        V.inv_wcell = V.wcell > 0 ? (65536 + V.wcell - 1) / V.wcell : 0;
+        V.inv_wcell1 = V.wcell > 0 ? (65536 + V.wcell) / (V.wcell + 1) : 0;
         // quadtree, ORBExtractor.cpp:183-185
         V.qt_w = maxBX - minB; V.qt_h = maxBY - minB;
         V.n_ini = (V.qt_w > 0 && V.qt_h > 0) ? (int)roundf((float)V.qt_w / (float)V.qt_h) : 0;
@@ -121,7 +129,7 @@ int configure(hs_orb* h, int w, int hh, int batch)
         if (V.n_ini > HS_QT_MAX_NODES / 4) return fail(h, HS_ERR_INVALID, "aspect ratio too wide");
         V.hx = V.n_ini > 0 ? (float)V.qt_w / V.n_ini : 1.f;
         V.quota = h->quota[l];
-        V.cand_cap = V.ncols * V.nrows * ((V.wcell + 1) / 2) * ((V.hcell + 1) / 2);
+        V.cand_cap = V.ncols * V.nrows * hs_cell_cap(V.wcell, V.hcell);
         V.cand_off = cand; cand += (uint64_t)((V.cand_cap + 3) & ~3);
         V.sel_cap = std::max(V.quota + 4, 4 * V.n_ini + 4);
         V.sel_off = sel; sel += V.sel_cap;
@@ -161,7 +169,7 @@ int configure(hs_orb* h, int w, int hh, int batch)
     pyr_per_img = (pyr_per_img + 255) & ~(size_t)255;
     h->max_wcell = h->max_hcell = 1;
     for (int l = 0; l < L; l++) { h->max_wcell = std::max(h->max_wcell, h->lv[l].wcell); h->max_hcell = std::max(h->max_hcell, h->lv[l].hcell); }
-    h->total_cells = cells; h->cand_img_stride = cand; h->sel_img_stride = sel; h->max_kp = sel;
+    h->total_cells = cells; h->fast_items = items; h->cand_img_stride = cand; h->sel_img_stride = sel; h->max_kp = sel;
 
     HIP_TRY(h, hipMalloc(&h->d_pyr, std::max<size_t>(pyr_per_img * batch, 256)));
     HIP_TRY(h, hipMalloc(&h->d_tables, std::max<size_t>(tables.size() * sizeof(int16_t), 256)));
@@ -186,6 +194,12 @@ int configure(hs_orb* h, int w, int hh, int batch)
         }
     }
     HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
+    {
+        std::vector<HsFastItem> fi(std::max(items, 1));
+        hs_fast_build_items(h->lv.data(), L, fi.data());
+        HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
+        HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
+    }
     h->w = w; h->h = hh; h->batch_cap = batch;
     return HS_OK;
 }
@@ -235,7 +249,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     mark(h, 0, s);
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
-    hs_launch_fast(h->d_lv, L, img0, batch, h->total_cells, h->p.fast_threshold,
+    hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
                    h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,

@@ -24,6 +24,10 @@ struct HsLevel {
     // FAST cell grid (ORBExtractor.cpp:413-428)
     int32_t ncols, nrows, wcell, hcell;
     int32_t cell_begin;            // first block index of this level in the all-levels cell launch
+    // FAST work items (kernels_fast.hip): one item = `grp_cells` horizontally adjacent cells of one cell row
+    int32_t grp_cells, ngroups;    // cells per item (the last item of a row may hold fewer), items per cell row
+    int32_t item_begin;            // first item of this level within one image's item list
+    int32_t inv_wcell, inv_wcell1; // ceil(65536 / wcell), ceil(65536 / (wcell + 1)): x / wcell == (x * inv) >> 16 for x < 256
     // DistributeOctTree inputs (ORBExtractor.cpp:179-203,475-476)
     int32_t qt_w, qt_h;            // maxBorderX-minBorderX, maxBorderY-minBorderY
     int32_t n_ini;                 // round(qt_w / qt_h)
@@ -44,6 +48,29 @@ struct HsLevel {
     float kp_size;                 // (int)(31*scale)
 };
 
+// One work item of the FAST kernel (kernels_fast.hip): `ncell` horizontally adjacent cells of one cell row.  Everything that does not
+// depend on the image index is precomputed on the host, so a wave fetches an item's geometry with a single 64-byte scalar load.
+struct HsFastItem {
+    const uint8_t* base;           // level buffer; nullptr = level 0 (the caller's frame, HsImg0)
+    uint64_t img_stride;           // bytes between images of the level buffer
+    int32_t pitch;                 // row pitch of the level buffer (level 0: HsImg0::row_stride)
+    int32_t gcell0;                // HsLevel::cell_begin + c0: first entry of the item in cell_count
+    int32_t c0;                    // cell index (row-major within the level) of the item's first cell
+    uint32_t slot0;                // HsLevel::cand_off + c0 * ccap: the first cell's slots in the candidate arrays
+    int32_t ccap;                  // slots per cell
+    int32_t inv_w, inv_w1;         // ceil(65536 / wcell), ceil(65536 / (wcell + 1))
+    uint16_t iniY, a0;             // first tile row; first tile column rounded down to a dword
+    uint16_t th, iw;               // tile rows (0: the item yields nothing), interior width
+    uint8_t off, ndw, ncell, level;// tile column of x is off + (x - iniX); dwords per tile row
+    uint16_t xoff, yoff;           // j0 * wCell, i * hCell (ORBExtractor.cpp:463-464)
+    uint32_t _pad;
+};
+static_assert(sizeof(HsFastItem) == 64, "HsFastItem is fetched as one 64-byte record");
+
+// candidate slots per FAST cell: 3x3 NMS leaves at most one survivor per 2x2 block; rounded to 4 so that a cell's records start on
+// a 16-byte boundary (cand_off is a multiple of 4 entries)
+__host__ __device__ inline int hs_cell_cap(int wcell, int hcell) { return ((((wcell + 1) >> 1) * ((hcell + 1) >> 1)) + 3) & ~3; }
+
 struct HsImg0 {                    // level 0 = the caller's frames; images [0,split) from base, the rest from base2
     const uint8_t* base;           // (left / right frames of a stereo batch go through one launch sequence)
     const uint8_t* base2;
@@ -56,6 +83,24 @@ __host__ __device__ inline const uint8_t* hs_img0_ptr(const HsImg0& I, int img)
     return img < I.split ? I.base + (size_t)img * I.img_stride : I.base2 + (size_t)(img - I.split) * I.img_stride;
 }
 
+// Pointers that reach a kernel through a struct in memory (HsLevel::base, the tables) have no provable address space and compile to
+// FLAT loads, which count on lgkmcnt as well as vmcnt: every LDS wait then also waits for them.  These helpers assert "global".
+#define HS_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t hs_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T hs_gload(const void* p) { return *(const HS_GLOBAL T*)(uintptr_t)p; }
+// a pointer the compiler must keep in SGPRs (so that `uniform base + 32-bit lane offset` becomes the saddr form of global_load)
+__device__ __forceinline__ const uint8_t* hs_uniform_ptr(const uint8_t* p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const uint8_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T hs_gload_off(const uint8_t* uniform_base, uint32_t lane_off)
+{
+    return *(const HS_GLOBAL T*)((const HS_GLOBAL uint8_t*)(uintptr_t)uniform_base + lane_off);
+}
+template <typename T> __device__ __forceinline__ void hs_gstore(void* p, T v) { *(HS_GLOBAL T*)(uintptr_t)p = v; }
+
 struct HsOut {                     // extractor outputs, split the same way
     hs_keypoint* kps; uint8_t* desc; int32_t* n;
     hs_keypoint* kps2; uint8_t* desc2; int32_t* n2;
@@ -65,7 +110,9 @@ struct HsOut {                     // extractor outputs, split the same way
 
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
-void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
+int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
+void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
+void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, hipStream_t s);
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,

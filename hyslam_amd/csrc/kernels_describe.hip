@@ -127,16 +127,17 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         // 11 dwords per row starting at the patch's own first byte: gfx9 global loads take unaligned dword addresses, so the LDS tile
         // is aligned to the patch and the row pass below needs no per-keypoint byte shifts
         struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
+        typedef const HS_GLOBAL U32* gu32;
         const uint8_t* src = base + (size_t)y0 * pitch + x0;
         for (int i = lane; i < RAW_N * 11; i += 64) {
             int r = i / 11, q = i - r * 11;
-            *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = reinterpret_cast<const U32*>(src + (size_t)r * pitch + 4 * q)->v;
+            *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = ((gu32)(uintptr_t)(src + (size_t)r * pitch + 4 * q))->v;
         }
     } else {
         for (int i = lane; i < RAW_N * RAW_N; i += 64) {
             int r = i / RAW_N, q = i - r * RAW_N;
             int y = reflect101(y0 + r, L.h), x = reflect101(x0 + q, L.w);
-            raw[r * RAW_P + q] = base[(size_t)y * pitch + x];
+            raw[r * RAW_P + q] = hs_gload<uint8_t>(base + (size_t)y * pitch + x);
         }
     }
     WAVE_LDS_SYNC();

@@ -30,6 +30,7 @@
 #include "hs_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 // LDS layout, sized on the host from the largest cell of the configured geometry (a 1080p frame needs ~9 KB per workgroup,
 // so the wave limit, not LDS, decides how many cells a CU has in flight)
@@ -99,7 +100,7 @@ __device__ __forceinline__ void cell_fill(CellGeom& g, const HsLevel* __restrict
     const int maxX = min(g.iniX + L.wcell + 6, L.w - HS_BORDER), maxY = min(g.iniY + L.hcell + 6, L.h - HS_BORDER);
     g.tw = maxX - g.iniX; g.th = maxY - g.iniY;
     g.valid = g.tw >= 7 && g.th >= 7;                 // reference skip rules (:435,444) / cv::FAST on < 7 rows or columns
-    g.ccap = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+    g.ccap = hs_cell_cap(L.wcell, L.hcell);
     const uint8_t* base;
     if (g.level == 0) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
     else { base = L.base + (size_t)g.img * L.img_stride; g.pitch = L.pitch; }
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(FAST_NT, FAST_WAVES_PER_SIMD) void k_fast_cells(con
             int i = tid + FAST_NT * j;
             if (i < n) {
                 int r = (int)(((float)i + 0.5f) * rcp), c = i - r * q.ndw;
-                pre[j] = *reinterpret_cast<const uint32_t*>(q.rows + (size_t)r * q.pitch + 4 * c);
+                pre[j] = hs_gload<uint32_t>(q.rows + (size_t)r * q.pitch + 4 * c);
             }
         }
     };
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(FAST_NT, FAST_WAVES_PER_SIMD) void k_fast_cells(con
             const uint8_t* src = g.rows + off;                  // (iniX, iniY)
             for (int i = tid; i < g.th * g.tw; i += FAST_NT) {
                 int r = i / g.tw, c = i - r * g.tw;
-                tile[r * TILE_PITCH + off + c] = src[(size_t)r * g.pitch + c];
+                tile[r * TILE_PITCH + off + c] = hs_gload<uint8_t>(src + (size_t)r * g.pitch + c);
             }
         }
         WAVE_LDS_FENCE();                                        // tile ready
@@ -333,11 +334,496 @@ __global__ __launch_bounds__(FAST_NT, FAST_WAVES_PER_SIMD) void k_fast_cells(con
     }
 }
 
-void hs_launch_fast(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch, int total_cells, int fast_th,
+
+// =====================================================================================================================
+// k_fast_rows — the same per-cell semantics, but the unit of work is a ROW GROUP: up to 8 horizontally adjacent cells of one
+// cell row (<= 247 px of interior), one wavefront per item, one pixel DWORD per lane.
+//
+// Why: with ~1 % corners a single 31x31 cell leaves the wave's lanes mostly idle after the first pass (32 "maybe" pixels, 11
+// corners on 64 lanes) and pays the per-cell bookkeeping 6342 times per frame.  A row group shares the aprons between its
+// cells, fills the lanes of every pass and turns the quick-reject pass into packed arithmetic on whole dwords:
+//   stage   tile rows arrive as one dword per lane (prefetched into registers during the previous item) -> LDS tile
+//   scan A  per tile row, 4 pixels per lane: compass-point quick reject with v_pk_*_u16 on the row dwords (the horizontal
+//           ring pixels come from the neighbouring lanes by DPP wave shifts); lanes with a hit append ONE group entry
+//   expand  group entries -> pixel list (4 ballots + mbcnt prefix), then the segment test and the corner score as before;
+//           scores go to a dense LDS score tile in which every cell owns its columns plus one zero separator column, so
+//           the 3x3 NMS needs no cell-boundary logic
+//   scan B  per score row: lanes with a non-zero dword append a group entry; expand; strict 3x3 NMS; survivors are ranked
+//           per cell in row-major order (one ballot per cell of the group) and written to the cell's slots.
+// All LDS lists have fixed capacities; a scan flushes (runs the later passes on what it has) whenever the next step could
+// overflow, so saturated images stay correct and merely lose batching efficiency.
+// Template: LC = log2(dword columns per tile row): 6 -> 256 px wide tiles, 1 row per step; 5 -> 128 px, two rows per step.
+//           NR = prefetch registers per lane (NR * rows-per-step >= tile rows).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t lane_from_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }  // wave_shr:1
+__device__ __forceinline__ uint32_t lane_from_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }  // wave_shl:1
+
+// Quick reject of 2 pixels held in the HIGH bytes of the two 16-bit fields (low bytes: anything).  Exact condition:
+// (r0 or r8 darker than v-t) and (r4 or r12 darker), or the same for brighter.  Garbage in the low bytes can only add
+// false positives: a true difference >= t+1 is >= 256t+1 in field units.  Returns non-zero fields for pixels that may be corners.
+__device__ __forceinline__ us2 fr_pretest(us2 T, us2 C, us2 B, us2 L, us2 R, us2 t16)
+{
+    const us2 dk = __builtin_elementwise_max(__builtin_elementwise_min(T, B), __builtin_elementwise_min(L, R));
+    const us2 br = __builtin_elementwise_min(__builtin_elementwise_max(T, B), __builtin_elementwise_max(L, R));
+    const us2 z = __builtin_elementwise_max(__builtin_elementwise_sub_sat(C, dk), __builtin_elementwise_sub_sat(br, C));
+    return __builtin_elementwise_sub_sat(z, t16);
+}
+// 1 in every 16-bit field that is non-zero (v_pk_min_u16; written as asm so that it is not turned back into compares)
+__device__ __forceinline__ uint32_t fr_field_flags(us2 s, uint32_t ones)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(as_u32(s)), "v"(ones));
+    return r;
+}
+
+struct FastRowsLds { int32_t off_score, off_plist, score_bytes, pcap, total; };
+
+struct RowGeom {            // wave-uniform description of one work item in one image
+    int img;
+    int ncell, c0, gcell0;  // cells in this item, cell index of its first cell (within the level / within the image)
+    uint32_t slot0; int ccap;
+    int inv_w, inv_w1;
+    int xoff, yoff;         // j0*wCell, i*hCell
+    int th, ih, iw;         // tile rows, interior rows, interior width
+    int off, ndw;           // tile column of level x is off + (x - iniX); dwords per tile row
+    const uint8_t* rows;    // address of (a0, iniY): first dword of the first tile row
+    size_t pitch;
+    bool valid, aligned;
+};
+
+__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, int w)
+{
+    RowGeom g;
+    g.img = w / items_per_img;
+    const HsFastItem it = items[w - g.img * items_per_img];     // one s_load_dwordx16
+    g.ncell = it.ncell; g.c0 = it.c0; g.gcell0 = it.gcell0; g.slot0 = it.slot0; g.ccap = it.ccap;
+    g.inv_w = it.inv_w; g.inv_w1 = it.inv_w1;
+    g.xoff = it.xoff; g.yoff = it.yoff;
+    g.th = it.th; g.ih = g.th - 6; g.iw = it.iw;
+    g.off = it.off; g.ndw = it.ndw;
+    g.valid = it.th != 0;
+    const uint8_t* base;
+    if (it.base == nullptr) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
+    else { base = it.base + (size_t)g.img * it.img_stride; g.pitch = (size_t)it.pitch; }
+    g.aligned = (((uintptr_t)base | g.pitch) & 3) == 0;
+    g.rows = base + (size_t)it.iniY * g.pitch + it.a0;
+    return g;
+}
+
+#define FR_MAXG 8            // cells per item (one per-cell counter each)
+
+#ifdef HS_FAST_PROFILE       // make EXTRA=-DHS_FAST_PROFILE: per-phase cycle totals over all waves (tools/fast_phase_profile.py)
+__device__ unsigned long long g_fr_prof[16];
+#define FR_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define FR_ACC(i, a, b) fr_acc[i] += (b) - (a)
+extern "C" void hs_debug_fast_profile(unsigned long long* out16)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fr_prof), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fr_prof), z, sizeof(z));
+}
+#else
+#define FR_T(var)
+#define FR_ACC(i, a, b)
+#endif
+
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, no LDS)
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8   -> inclusive within each row of 16
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// TR = tile rows held in LDS (6 + 8*RS*blocks); the item's tile (th <= TR rows) is fetched with 16-byte loads, 64/LPR rows per load
+template <int LC, int TR>
+__global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
+                                                  uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
+                                                  int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
+                                                  int total_cells, int items_per_img, int total_work, FastRowsLds lds, int dbg)
+{
+    constexpr int COLS = 1 << LC;            // dwords per tile row
+    constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
+    constexpr int PITCH = 4 * COLS;          // bytes per row of the pixel tile and of the score tile
+    constexpr int LPR = COLS / 4;            // lanes per tile row in the 16-byte staging loads
+    constexpr int RPL = 64 / LPR;            // tile rows per staging load
+    constexpr int NL = (TR + RPL - 1) / RPL; // staging loads per lane
+    constexpr int BR = 8;                    // rows per lane and scan block
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const tile = smem;
+    uint8_t* const score = smem + lds.off_score;
+    uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
+    uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(score + lds.score_bytes - 4 * FR_MAXG);   // last bytes of the (zeroed) score area
+    const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
+    const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
+
+    const int tid = threadIdx.x;
+    const int col = tid & (COLS - 1), sub = tid >> LC;
+    const int ld_row = tid / LPR, ld_c16 = tid % LPR;
+    const int t = min(max(fast_th, 0), 255);
+    const us2 t16 = as_us2((uint32_t)(t << 8) * 0x00010001u);
+    const uint32_t ones = 0x00010001u;
+    constexpr int RO[16] = { 3 * PITCH + 0, 3 * PITCH + 1, 2 * PITCH + 2, 1 * PITCH + 3, 0 * PITCH + 3, -1 * PITCH + 3, -2 * PITCH + 2, -3 * PITCH + 1,
+                             -3 * PITCH + 0, -3 * PITCH - 1, -2 * PITCH - 2, -1 * PITCH - 3, 0 * PITCH - 3, 1 * PITCH - 3, 2 * PITCH - 2, 3 * PITCH - 1 };
+
+    // Work distribution: the item list is cut into 8 contiguous ranges, one per XCD (blockIdx % 8); the waves of an XCD walk their
+    // range in lock-step strides, so at any time an XCD works on ~nblk/8 neighbouring items (shared apron lines hit in its L2) while
+    // every wave's items are spread over all levels and image regions.  Corner-rich regions cost several times more than flat ones:
+    // contiguous per-wave ranges left the average wave idle for ~40 % of the kernel (and one atomic work counter per XCD serialises).
+    const int per_x = (total_work + 7) >> 3, wpx = gridDim.x >> 3;
+    const int x_end = min(total_work, ((int)(blockIdx.x & 7) + 1) * per_x);
+    int w = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
+    if (w >= x_end) return;
+
+    auto zero_score = [&]() {
+        for (int i = tid * 16; i < lds.score_bytes; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
+    };
+    zero_score();
+
+#ifdef HS_FAST_PROFILE
+    unsigned long long fr_acc[10] = {};
+    FR_T(t_kernel0);
+#endif
+    hs_u32x4 pre[NL];
+    RowGeom g = row_geom(items, img0, items_per_img, w);
+    // All NL loads are issued unconditionally (rows beyond the tile re-read its last row, columns beyond it the last needed
+    // 16 bytes): predicating them makes the compiler copy the whole register array at every merge point.
+    auto prefetch = [&](const RowGeom& q) {
+        const int rlast = max(q.th - 1, 0);
+        const uint32_t coff = 16u * (uint32_t)min(ld_c16, (q.ndw - 1) >> 2);
+        const uint8_t* base = hs_uniform_ptr(q.rows);
+        if (q.aligned) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                pre[k] = hs_gload_off<hs_u32x4>(base, (uint32_t)min(RPL * k + ld_row, rlast) * (uint32_t)q.pitch + coff);
+        } else {                                                 // caller's frame with an odd base or stride: unaligned dword loads
+            struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const HS_GLOBAL U32* p = (const HS_GLOBAL U32*)((const HS_GLOBAL uint8_t*)(uintptr_t)base + ((uint32_t)min(RPL * k + ld_row, rlast) * (uint32_t)q.pitch + coff));
+                pre[k] = hs_u32x4{p[0].v, p[1].v, p[2].v, p[3].v};
+            }
+        }
+    };
+    prefetch(g);
+
+    for (; w < x_end; w += wpx) {
+        const int w_next = w + wpx < x_end ? w + wpx : -1;
+        int32_t* const cnt_out = &cell_count[(size_t)g.img * total_cells + g.gcell0];
+        if (!g.valid) {
+            if (tid < g.ncell) cnt_out[tid] = 0;
+            if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); }
+            continue;
+        }
+        // ---- stage the tile
+        FR_T(t0);
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (RPL * (k + 1) <= TR || RPL * k + ld_row < TR)
+                *reinterpret_cast<hs_u32x4*>(&tile[(RPL * k + ld_row) * PITCH + 16 * ld_c16]) = pre[k];
+        WAVE_LDS_FENCE();
+        FR_T(t1);
+        FR_ACC(0, t0, t1);
+        const RowGeom cur = g;
+        const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1, ccap = cur.ccap;
+        const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
+        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); }   // in flight during the passes
+        FR_T(t2);
+        FR_ACC(1, t1, t2);
+
+        const int c_first = cur.off + 3;                         // tile column of the first interior pixel
+        uint32_t vmask = 0;                                      // this lane's pixels that are interior columns: bits 0,1,16,17 = pixel 0,1,2,3
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int px = 4 * col + j - c_first;
+            if (px >= 0 && px < cur.iw) vmask |= 1u << ((j & 1) + 16 * (j >> 1));
+        }
+        const uint32_t vmask8 = vmask * 0x5555u;                 // the same for the 8 rows of a scan block (row r at << 2r)
+        int npx = 0;                                             // wave-uniform list length
+        int cs_runs = 0, n_last_corner = 0;                      // how often corners_and_scores ran for this item; corners of its last run
+
+        // ---- pixel list -> corners -> scores
+        auto corners_and_scores = [&]() {
+            WAVE_LDS_FENCE();
+            FR_T(tc0);
+            int n_corner = 0;
+            for (int i0 = 0; i0 < npx; i0 += 64) {
+                const int i = i0 + tid;
+                const bool act = i < npx;
+                const int pos = plist[act ? i : 0];
+                const int py = pos >> 8, px = pos & 255;
+                const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
+                const int v = ctr[0];
+                const int lo = v - t, hi = v + t;
+                // one subtract + one v_alignbit per ring pixel and polarity: the sign bit of (r - lo) / (hi - r) is shifted into the mask
+                // (bit order comes out reversed, which a cyclic run test does not care about)
+                uint32_t mdark = 0, mbright = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int r = ctr[RO[k]];
+                    mdark = __builtin_amdgcn_alignbit(mdark, (uint32_t)(r - lo), 31);
+                    mbright = __builtin_amdgcn_alignbit(mbright, (uint32_t)(hi - r), 31);
+                }
+                uint32_t m = mdark | (mdark << 16);
+                uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
+                uint32_t m2 = mbright | (mbright << 16);
+                uint32_t y = m2 & (m2 >> 1); y &= y >> 2; y &= y >> 4; y &= m2 >> 8;
+                const bool corner = act && ((x | y) & 0xFFFFu) != 0;
+                WAVE_LDS_FENCE();                                // this iteration's reads precede the in-place compaction writes
+                const int slot = wave_append(corner, n_corner);
+                if (corner) plist[slot] = (uint16_t)(pos | ((y & 0xFFFFu) ? 0x8000 : 0));
+            }
+            WAVE_LDS_FENCE();
+            FR_T(tc1);
+            FR_ACC(4, tc0, tc1);
+            for (int i = tid; i < n_corner; i += 64) {
+                const int pos = plist[i];
+                const bool bright = pos & 0x8000;
+                const int py = (pos >> 8) & 127, px = pos & 255;
+                const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
+                const int v = ctr[0];
+                int d[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { int e = v - (int)ctr[RO[k]]; d[k] = bright ? -e : e; }
+                const int gc = (px * inv_w) >> 16;               // cell of the item; its columns start at 1 + gc*(wcell+1)
+                score[(py + 1) * PITCH + 1 + px + gc] = (uint8_t)fast_corner_score(d);
+                plist[i] = (uint16_t)(((py + 1) << 8) | (1 + px + gc));   // score tile coordinates: what nms_and_emit reads
+            }
+            npx = 0; cs_runs++; n_last_corner = n_corner;
+            WAVE_LDS_FENCE();
+            FR_T(tc2);
+            FR_ACC(5, tc1, tc2);
+        };
+
+        // ---- pixel list (score tile coordinates) -> strict 3x3 NMS -> the cells' slots, in no particular order (the quadtree kernel
+        //      orders a cell's records by (y, x) when it gathers them)
+        auto nms_and_emit = [&]() {
+            WAVE_LDS_FENCE();
+            for (int i0 = 0; i0 < npx; i0 += 64) {
+                const int i = i0 + tid;
+                const bool act = i < npx;
+                const int pos = plist[act ? i : 0];
+                const int r = pos >> 8, sc = pos & 255;
+                const uint8_t* p = &score[r * PITCH + sc];
+                const int s = p[0];
+                // all eight neighbours are read before any is compared (&&-chains compile to eight dependent LDS round trips)
+                const int n0 = p[-PITCH - 1], n1 = p[-PITCH], n2 = p[-PITCH + 1], n3 = p[-1], n4 = p[1], n5 = p[PITCH - 1], n6 = p[PITCH], n7 = p[PITCH + 1];
+                const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+                if (act & (s > nmax)) {
+                    const int gc = ((sc - 1) * inv_w1) >> 16;
+                    const int px = sc - 1 - gc;                  // interior column within the item
+                    const uint32_t slot = atomicAdd(&cellcnt[gc], 1u);
+                    const size_t o = slot_base + (size_t)gc * ccap + slot;
+                    cand_xy[o] = ((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff);
+                    cand_sk[o] = ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc);
+                }
+            }
+            npx = 0;
+        };
+
+        // ---- the set bits of M (one per pixel of this lane's scan block) -> pixel list.  SCORES: bit 4r+j, entries in score tile
+        //      coordinates; otherwise bit 2r + (j&1) + 16*(j>>1), entries relative to the interior.  `row0`: tile/score row of r = 0.
+        auto emit_mask = [&](uint32_t M, int row0, bool scores) {
+            const int incl = wave_scan_incl((int)__popc(M));
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) return;
+            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(); }
+            if (total <= lds.pcap) {
+                int pos = npx + incl - (int)__popc(M);
+                while (M) {
+                    const int b = __ffs((int)M) - 1;
+                    M &= M - 1;
+                    const int r = scores ? (b >> 2) : ((b >> 1) & 7), j = scores ? (b & 3) : ((b & 1) | ((b >> 4) << 1));
+                    plist[pos++] = scores ? (uint16_t)(((row0 + r) << 8) | (4 * col + j)) : (uint16_t)(((row0 + r - 3) << 8) + (4 * col + j - c_first));
+                }
+                npx += total;
+            } else {                                             // a block alone overflows the list (saturated image): one row at a time
+                for (int r = 0; r < BR; r++) {
+                    uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x00030003u << (2 * r)));
+                    const int incl_r = wave_scan_incl((int)__popc(Mr));
+                    const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 4*COLS <= pcap
+                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(); }
+                    int pos = npx + incl_r - (int)__popc(Mr);
+                    while (Mr) {
+                        const int b = __ffs((int)Mr) - 1;
+                        Mr &= Mr - 1;
+                        const int j = scores ? (b & 3) : ((b & 1) | ((b >> 4) << 1));
+                        plist[pos++] = scores ? (uint16_t)(((row0 + r) << 8) | (4 * col + j)) : (uint16_t)(((row0 + r - 3) << 8) + (4 * col + j - c_first));
+                    }
+                    npx += total_r;
+                }
+            }
+        };
+
+        // ---- scan A: quick reject.  A lane takes 4 pixel columns x 8 rows per block: 14 tile rows in registers, the horizontal ring
+        //      pixels from the neighbouring lanes (DPP wave shifts), all compares as v_pk_*_u16 on two pixels at a time.
+        FR_T(t3);
+        {
+            const int yend = 3 + cur.ih;
+            for (int y0 = 3 + BR * sub; y0 - BR * sub < yend; y0 += BR * RS) {
+                uint32_t M = 0;
+                if (!(dbg & 1)) {
+                    const uint32_t* tp = tile32 + (y0 - 3) * COLS + col;
+                    uint32_t R[BR + 6]; us2 E[BR + 6];
+#pragma unroll
+                    for (int k = 0; k < BR + 6; k++) { R[k] = tp[k * COLS]; E[k] = as_us2(R[k]) << 8; }
+#pragma unroll
+                    for (int r = 0; r < BR; r++) {
+                        const uint32_t C = R[r + 3];
+                        const uint32_t Cm = lane_from_below(C), Cp = lane_from_above(C);
+                        // even pixels (bytes 0,2): T, C, B shifted into the high bytes; ring 12 = bytes 1,3 of the lane below
+                        const us2 se = fr_pretest(E[r], E[r + 3], E[r + 6], as_us2(Cm), as_us2(__builtin_amdgcn_alignbyte(Cp, C, 2)), t16);
+                        // odd pixels (bytes 1,3) already sit in the high bytes
+                        const us2 so = fr_pretest(as_us2(R[r]), as_us2(C), as_us2(R[r + 6]),
+                                                  as_us2(__builtin_amdgcn_alignbyte(C, Cm, 1)), as_us2(__builtin_amdgcn_alignbyte(Cp, C, 3)), t16);
+                        M |= (fr_field_flags(se, ones) | (fr_field_flags(so, ones) << 1)) << (2 * r);
+                    }
+                    const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior
+                    M &= vmask8 & (((1u << (2 * nrow)) - 1u) * 0x00010001u);
+                }
+                if (!(dbg & 2)) emit_mask(M, y0, false);
+            }
+            if (npx > 0) corners_and_scores();
+        }
+        FR_T(t4);
+        FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
+        // ---- NMS.  Usual case: every corner of the item is still in the list (score coordinates).
+        if (cs_runs <= 1 && !(dbg & 8)) {
+            npx = n_last_corner;
+            if (!(dbg & 4)) nms_and_emit();
+        } else if (!(dbg & 4)) {
+            // ---- scan B (the list overflowed and was flushed): find the corners again as the non-zero bytes of the score tile
+            WAVE_LDS_FENCE();
+            for (int r0 = 1 + BR * sub; r0 - BR * sub <= cur.ih; r0 += BR * RS) {
+                uint32_t M = 0;
+#pragma unroll
+                for (int r = 0; r < BR; r++) {
+                    const uint32_t S = (r0 + r <= cur.ih) ? score32[(r0 + r) * COLS + col] : 0u;
+                    const uint32_t nib = ((S & 0xFFu) ? 1u : 0u) | ((S & 0xFF00u) ? 2u : 0u) | ((S & 0xFF0000u) ? 4u : 0u) | ((S & 0xFF000000u) ? 8u : 0u);
+                    M |= nib << (4 * r);
+                }
+                emit_mask(M, r0, true);
+            }
+            if (npx > 0) nms_and_emit();
+        }
+        WAVE_LDS_FENCE();
+        FR_T(t5);
+        FR_ACC(6, t4, t5);
+        // ---- per-cell counts; restore the all-zero score tile (and counters)
+        if (tid < cur.ncell) cnt_out[tid] = (int32_t)cellcnt[tid];
+        WAVE_LDS_FENCE();
+        zero_score();
+#ifdef HS_FAST_PROFILE
+        WAVE_LDS_FENCE();
+        FR_T(t6);
+        FR_ACC(7, t5, t6);
+        fr_acc[8] += 1;
+#endif
+    }
+#ifdef HS_FAST_PROFILE
+    FR_T(t_kernel1);
+    fr_acc[9] = t_kernel1 - t_kernel0;
+    if (tid == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_fr_prof[i], fr_acc[i]);
+    if (tid == 0) atomicAdd(&g_fr_prof[10], 1ull);
+#endif
+}
+
+// cells per work item for a level: as many as fit the tile (interior <= 4*COLS - 9 px, <= FR_MAXG), spread evenly over the row
+static int fast_rows_lc()
+{
+    static int lc = [] { const char* e = getenv("HS_FAST_COLS"); return (e && atoi(e) == 32) ? 5 : 6; }();
+    return lc;
+}
+int hs_fast_group_cells(int wcell, int ncols)
+{
+    if (wcell <= 0 || ncols <= 0) return 0;
+    const int iw_max = 4 * (1 << fast_rows_lc()) - 9;
+    int gmax = std::min(FR_MAXG, iw_max / wcell);
+    if (gmax < 1) gmax = 1;                                   // cannot happen: wcell <= HS_MAX_CELL = 64 < 119
+    const int ngroups = (ncols + gmax - 1) / gmax;
+    return (ncols + ngroups - 1) / ngroups;
+}
+
+void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
+{
+    for (int l = 0; l < nlevels; l++) {
+        const HsLevel& L = h_lv[l];
+        for (int ci = 0; ci < L.nrows; ci++)
+            for (int gj = 0; gj < L.ngroups; gj++) {
+                HsFastItem& it = out[L.item_begin + ci * L.ngroups + gj];
+                memset(&it, 0, sizeof(it));
+                const int j0 = gj * L.grp_cells, ncell = std::min(L.grp_cells, L.ncols - j0);
+                const int xoff = j0 * L.wcell, yoff = ci * L.hcell;
+                const int iniX = HS_BORDER + xoff, iniY = HS_BORDER + yoff;
+                const int maxX = std::min(iniX + ncell * L.wcell + 6, L.w - HS_BORDER), maxY = std::min(iniY + L.hcell + 6, L.h - HS_BORDER);
+                const int tw = maxX - iniX, th = maxY - iniY;
+                const bool valid = tw >= 7 && th >= 7;            // reference skip rules (:435,444) / cv::FAST on < 7 rows or columns
+                const int a0 = iniX & ~3;
+                it.base = l == 0 ? nullptr : L.base; it.img_stride = L.img_stride; it.pitch = L.pitch;
+                it.c0 = ci * L.ncols + j0; it.gcell0 = L.cell_begin + it.c0;
+                it.ccap = hs_cell_cap(L.wcell, L.hcell);
+                it.slot0 = (uint32_t)(L.cand_off + (uint64_t)it.c0 * it.ccap);
+                it.inv_w = L.inv_wcell; it.inv_w1 = L.inv_wcell1;
+                it.iniY = valid ? (uint16_t)iniY : 0; it.a0 = valid ? (uint16_t)a0 : 0;   // invalid items still prefetch (harmlessly) from (0,0)
+                it.th = valid ? (uint16_t)th : 0; it.iw = valid ? (uint16_t)(tw - 6) : 0;
+                it.off = (uint8_t)(iniX - a0); it.ndw = valid ? (uint8_t)((iniX - a0 + tw + 3) >> 2) : 1;
+                it.ncell = (uint8_t)ncell; it.level = (uint8_t)l;
+                it.xoff = (uint16_t)xoff; it.yoff = (uint16_t)yoff;
+            }
+    }
+}
+
+static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
+                             uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                             int max_wcell, int max_hcell, hipStream_t s)
+{
+    auto up = [](int v, int a) { return (v + a - 1) / a * a; };
+    const int lc = fast_rows_lc(), cols = 1 << lc, pitch = 4 * cols;
+    // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
+    // LDS (score tile / list follow) and those rows are masked out.  Template instances below.
+    const int th_max = max_hcell + 6;
+    const int tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : 70;
+    FastRowsLds L;
+    L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
+    if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the flush paths
+    int o = tr * pitch;
+    L.off_score = o;
+    L.score_bytes = (max_hcell + 3) * pitch;                  // rows 0..ih+1 are read; the per-cell counters sit at the end of one more row
+    o += L.score_bytes;
+    L.off_plist = o; o += L.pcap * 2;
+    o = std::max(o, (tr + 8) * pitch);                        // the over-read of the last scan block stays inside the allocation
+    L.total = o;
+    const int total_work = items_per_img * batch;
+    if (total_work <= 0) return;
+    int per_cu = std::max(1, std::min(16, (160 * 1024) / L.total));
+    if (const char* e = getenv("HS_FAST_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    int nblk = 256 * per_cu;
+    while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;
+    int dbg = 0; if (const char* e = getenv("HS_FAST_DBG")) dbg = atoi(e);
+#define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, dbg)
+    if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else FR_LAUNCH(6, 70); }
+    else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else FR_LAUNCH(5, 70); }
+#undef FR_LAUNCH
+}
+
+void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, hipStream_t s)
 {
     if (total_cells <= 0) return;
+    static const bool use_cells = [] { const char* e = getenv("HS_FAST_IMPL"); return e && !strcmp(e, "cells"); }();
+    if (!use_cells) {
+        launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, s);
+        return;
+    }
     auto up = [](int v, int a) { return (v + a - 1) / a * a; };
     FastLds L;
     const bool small = max_wcell <= 37;

@@ -108,15 +108,15 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
 
     // source rectangle of this tile (wave-uniform)
     const int dy_last = min(dy_tile + LT_ROWS, D.h) - 1, dx_last = min(dx_tile + 256, D.w) - 1;
-    const int sy_first = min(max((int)D.yofs[dy_tile], 0), sh - 1);
-    const int sy_last = min(max((int)D.yofs[dy_last] + 1, 0), sh - 1);
-    const int col0 = xt[dx_tile].sx & ~15;
-    const int col_last = min(xt[dx_last].sx + 1, sw - 1);
+    const int sy_first = min(max((int)hs_gload<int16_t>(D.yofs + dy_tile), 0), sh - 1);
+    const int sy_last = min(max((int)hs_gload<int16_t>(D.yofs + dy_last) + 1, 0), sh - 1);
+    const int col0 = hs_gload<int16_t>(&xt[dx_tile].sx) & ~15;
+    const int col_last = min(hs_gload<int16_t>(&xt[dx_last].sx) + 1, sw - 1);
     const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch, nrow <= lds_rows
     for (int i = threadIdx.x; i < nvec * nrow; i += 256) {
         const int r = i / nvec, q = i - r * nvec;
-        const uint4 v = *reinterpret_cast<const uint4*>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
-        *reinterpret_cast<uint4*>(&s_src[r * lds_pitch + 16 * q]) = v;
+        const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
+        *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
     }
     __syncthreads();
 
@@ -124,13 +124,13 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     if (dx0 >= D.w) return;
     HsXTab t[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = xt[min(dx0 + i, D.w - 1)];
+    for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, hs_gload<uint64_t>(&xt[min(dx0 + i, D.w - 1)]));
 #pragma unroll
     for (int rr = 0; rr < LT_ROWS / 4; rr++) {
         const int dy = dy_tile + ty + 4 * rr;
         if (dy >= D.h) break;
-        const int sy = D.yofs[dy];
-        const int b0 = D.ibeta[2 * dy], b1 = D.ibeta[2 * dy + 1];
+        const int sy = hs_gload<int16_t>(D.yofs + dy);
+        const int b0 = hs_gload<int16_t>(D.ibeta + 2 * dy), b1 = hs_gload<int16_t>(D.ibeta + 2 * dy + 1);
         const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
         const uint8_t* S0 = &s_src[r0 * lds_pitch - col0];
         const uint8_t* S1 = &s_src[r1 * lds_pitch - col0];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
             packed |= (uint32_t)(v & 0xFF) << (8 * i);
         }
         uint8_t* drow = D.base + (size_t)img * D.img_stride + (size_t)dy * D.pitch;
-        *reinterpret_cast<uint32_t*>(drow + dx0) = packed;
+        hs_gstore<uint32_t>(drow + dx0, packed);
     }
 }
 

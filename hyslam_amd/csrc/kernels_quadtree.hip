@@ -59,6 +59,19 @@ __device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
     return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4
 }
 
+// rank the first k of N register-held keys (unused ones are 0xFFFFFFFF) by counting and scatter the records in ascending key order
+template <int N>
+__device__ __forceinline__ void qt_rank_store(const uint32_t (&key)[16], const uint32_t (&sk)[16], int k, uint32_t* pxy, uint32_t* psk)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) rank += key[j] < key[i];
+        if (i < k) { pxy[rank] = key[i]; psk[rank] = sk[i]; }
+    }
+}
+
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
@@ -85,12 +98,12 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
     int32_t* out_n = &sel_count[img * nlevels + level];
 
-    // ---- gather this level's candidates from the per-cell slots k_fast_cells filled into one dense list
-    //      (block-wide prefix sum over the cell counts, one thread copies one cell: a few records each)
+    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list
+    //      (block-wide prefix sum over the cell counts, one thread copies and orders one cell: a few records each)
     int n = 0;
     {
         const int ncell = L.ncols * L.nrows;
-        const int ccap = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+        const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
         const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
@@ -98,8 +111,33 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             const int c = c0 + tid;
             const int k = c < ncell ? min(ccnt[c], ccap) : 0;
             int tot; int pre = n + block_scan_excl(k, s_wave, tot);
-            const size_t src = (size_t)c * ccap;
-            for (int i = 0; i < k; i++) { pxy[pre + i] = sxy[src + i]; psk[pre + i] = ssk[src + i]; }
+            const size_t src = (size_t)min(c, ncell - 1) * ccap;      // (threads past the last cell have k = 0 but still issue the loads below)
+            // The FAST kernel fills a cell's slots in no particular order; the reference's list order inside a cell is cv::FAST's
+            // row-major scan, i.e. ascending (y<<16 | x) = ascending cand_xy.  Cells hold a handful of records: rank by counting.
+            if (k <= 16) {                                     // the usual case: the cell's records fit in registers
+                // 16-byte loads (a cell's slots start on a 16-byte boundary); only the first quarter is fetched unconditionally:
+                // most cells hold <= 4 records, and every further distinct cache line costs the wave a TA pass
+                uint32_t key[16], sk[16];
+                const hs_u32x4* kx = reinterpret_cast<const hs_u32x4*>(sxy + src);
+                const hs_u32x4* ks = reinterpret_cast<const hs_u32x4*>(ssk + src);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    hs_u32x4 a = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, b = {0, 0, 0, 0};
+                    if (q == 0 || k > 4 * q) { a = kx[q]; b = ks[q]; }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { key[4 * q + e] = (4 * q + e < k) ? a[e] : 0xFFFFFFFFu; sk[4 * q + e] = b[e]; }
+                }
+                if (k <= 4) qt_rank_store<4>(key, sk, k, pxy + pre, psk + pre);
+                else if (k <= 8) qt_rank_store<8>(key, sk, k, pxy + pre, psk + pre);
+                else qt_rank_store<16>(key, sk, k, pxy + pre, psk + pre);
+            } else {
+                for (int i = 0; i < k; i++) {
+                    const uint32_t key = sxy[src + i];
+                    int rank = 0;
+                    for (int j = 0; j < k; j++) rank += sxy[src + j] < key;
+                    pxy[pre + rank] = key; psk[pre + rank] = ssk[src + i];
+                }
+            }
             n += tot;
         }
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)

@@ -161,6 +161,17 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
+@pytest.mark.parametrize("env", [{}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32"},
+                                 {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}])
+def test_fast_kernel_variants_in_subprocess(gpu, env):
+    """the FAST kernel's tile-width variants, and its list-overflow (flush) paths forced by tiny LDS lists: same bits as the oracle"""
+    e = dict(os.environ)
+    e.update(env)
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fast_variant_check.py")], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_batch_equals_singles_and_is_deterministic(gpu):
     imgs = [synth_image(60 + i, 640, 480) for i in range(5)]
     ex = HS.ORBExtractor(settings(1000))
