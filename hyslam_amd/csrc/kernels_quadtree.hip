@@ -25,6 +25,7 @@
 // Inputs are the per-cell candidate slots written by k_fast_cells (gathered into a dense list first).  Outputs per (image, level):
 // selected (x,y,score) in final list order + count.  Bound: LDS atomics / VALU; HBM traffic negligible.
 #include "hs_internal.h"
+#include <cstdlib>
 
 #define QT_T HS_QT_THREADS
 #define QT_M HS_QT_MAX_NODES
@@ -59,25 +60,12 @@ __device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
     return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4
 }
 
-// rank the first k of N register-held keys (unused ones are 0xFFFFFFFF) by counting and scatter the records in ascending key order
-template <int N>
-__device__ __forceinline__ void qt_rank_store(const uint32_t (&key)[16], const uint32_t (&sk)[16], int k, uint32_t* pxy, uint32_t* psk)
-{
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < N; j++) rank += key[j] < key[i];
-        if (i < k) { pxy[rank] = key[i]; psk[rank] = sk[i]; }
-    }
-}
-
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
-                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride)
+                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride, int dbg)
 {
     __shared__ QtNodes nodes[2];
     __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
@@ -98,44 +86,56 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
     int32_t* out_n = &sel_count[img * nlevels + level];
 
-    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list
-    //      (block-wide prefix sum over the cell counts, one thread copies and orders one cell: a few records each)
+    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list.
+    // The FAST kernel fills a cell's slots in no particular order; the reference's list order (vToDistributeKeys) is cell by cell and,
+    // inside a cell, cv::FAST's row-major scan = ascending (y<<16 | x) = ascending cand_xy.  Up to QT_T cells per round:
+    //   A  one thread per cell: count, block-wide exclusive scan, and the cell id of each of its records into LDS
+    //   B  one thread per RECORD: key -> LDS;  then rank inside its cell by counting smaller keys (LDS reads), scatter to the dense list.
+    // Record-parallel because the high pyramid levels have few cells with many records each (mean 20, up to 34 at level 7 of a 1080p
+    // frame): a per-cell thread loop was k dependent global round trips long.  The node arrays are not live yet: their LDS is the scratch.
     int n = 0;
     {
+        uint32_t* const s_key = reinterpret_cast<uint32_t*>(&nodes[0]);          // [QT_GKEYS]
+        uint16_t* const s_cell = reinterpret_cast<uint16_t*>(ccount);            // [QT_GKEYS]
+        uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [QT_T] exclusive offset of the round's cell
+        constexpr int QT_GKEYS = (int)(sizeof(nodes) / 4) < (int)(sizeof(ccount) / 2) ? (int)(sizeof(nodes) / 4) : (int)(sizeof(ccount) / 2);
+        static_assert(sizeof(child_index) >= QT_T * 4, "s_pre scratch");
         const int ncell = L.ncols * L.nrows;
         const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
         const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
-        for (int c0 = 0; c0 < ncell; c0 += QT_T) {
+        for (int c0 = (dbg & 2) ? ncell : 0; c0 < ncell; c0 += QT_T) {
             const int c = c0 + tid;
             const int k = c < ncell ? min(ccnt[c], ccap) : 0;
-            int tot; int pre = n + block_scan_excl(k, s_wave, tot);
-            const size_t src = (size_t)min(c, ncell - 1) * ccap;      // (threads past the last cell have k = 0 but still issue the loads below)
-            // The FAST kernel fills a cell's slots in no particular order; the reference's list order inside a cell is cv::FAST's
-            // row-major scan, i.e. ascending (y<<16 | x) = ascending cand_xy.  Cells hold a handful of records: rank by counting.
-            if (k <= 16) {                                     // the usual case: the cell's records fit in registers
-                // 16-byte loads (a cell's slots start on a 16-byte boundary); only the first quarter is fetched unconditionally:
-                // most cells hold <= 4 records, and every further distinct cache line costs the wave a TA pass
-                uint32_t key[16], sk[16];
-                const hs_u32x4* kx = reinterpret_cast<const hs_u32x4*>(sxy + src);
-                const hs_u32x4* ks = reinterpret_cast<const hs_u32x4*>(ssk + src);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    hs_u32x4 a = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, b = {0, 0, 0, 0};
-                    if (q == 0 || k > 4 * q) { a = kx[q]; b = ks[q]; }
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { key[4 * q + e] = (4 * q + e < k) ? a[e] : 0xFFFFFFFFu; sk[4 * q + e] = b[e]; }
+            int tot; const int pre = block_scan_excl(k, s_wave, tot);
+            if (tot <= QT_GKEYS) {
+                s_pre[tid] = (uint32_t)pre;
+                for (int i = 0; i < k; i++) s_cell[pre + i] = (uint16_t)tid;
+                __syncthreads();
+                for (int e = tid; e < tot; e += QT_T) {
+                    const int lc = s_cell[e];
+                    s_key[e] = sxy[(size_t)(c0 + lc) * ccap + (e - (int)s_pre[lc])];
                 }
-                if (k <= 4) qt_rank_store<4>(key, sk, k, pxy + pre, psk + pre);
-                else if (k <= 8) qt_rank_store<8>(key, sk, k, pxy + pre, psk + pre);
-                else qt_rank_store<16>(key, sk, k, pxy + pre, psk + pre);
-            } else {
+                __syncthreads();
+                for (int e = tid; e < tot; e += QT_T) {
+                    const int lc = s_cell[e];
+                    const int first = (int)s_pre[lc], i = e - first;
+                    const uint32_t sk = ssk[(size_t)(c0 + lc) * ccap + i];           // in flight during the rank loop
+                    const int last = (lc + 1 < QT_T) ? (int)s_pre[lc + 1] : tot;     // cells past the last one have k = 0: s_pre = tot
+                    const uint32_t key = s_key[e];
+                    int rank = 0;
+                    for (int j = first; j < last; j++) rank += s_key[j] < key;
+                    pxy[n + first + rank] = key; psk[n + first + rank] = sk;
+                }
+                __syncthreads();                                   // the scratch is reused by the next round
+            } else {                                               // saturated image: more records than the scratch holds; one thread per cell
+                const size_t src = (size_t)min(c, ncell - 1) * ccap;
                 for (int i = 0; i < k; i++) {
                     const uint32_t key = sxy[src + i];
                     int rank = 0;
                     for (int j = 0; j < k; j++) rank += sxy[src + j] < key;
-                    pxy[pre + rank] = key; psk[pre + rank] = ssk[src + i];
+                    pxy[n + pre + rank] = key; psk[n + pre + rank] = ssk[src + i];
                 }
             }
             n += tot;
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
+    if (dbg & 1) { if (tid == 0) *out_n = 0; return; }
 
     const int nIni = L.n_ini;
     const float hX = L.hx;
@@ -383,5 +384,5 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
 {
     dim3 grid(nlevels, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, getenv("HS_QT_DBG") ? atoi(getenv("HS_QT_DBG")) : 0);
 }
