@@ -413,6 +413,9 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
 }
 
 #define FR_MAXG 8            // cells per item (one per-cell counter each)
+#ifndef FR_PAD
+#define FR_PAD 16            // row padding of the LDS tiles, bytes (multiple of 16)
+#endif
 
 #ifdef HS_FAST_PROFILE       // make EXTRA=-DHS_FAST_PROFILE: per-phase cycle totals over all waves (tools/fast_phase_profile.py)
 __device__ unsigned long long g_fr_prof[16];
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
-    constexpr int PITCH = 4 * COLS;          // bytes per row of the pixel tile and of the score tile
+    constexpr int PITCH = 4 * COLS + FR_PAD; // bytes per row of the pixel tile and of the score tile (padded: vertical neighbours in different banks)
+    constexpr int PD = PITCH / 4;
     constexpr int LPR = COLS / 4;            // lanes per tile row in the 16-byte staging loads
     constexpr int RPL = 64 / LPR;            // tile rows per staging load
     constexpr int NL = (TR + RPL - 1) / RPL; // staging loads per lane
@@ -667,13 +671,15 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_T(t3);
         {
             const int yend = 3 + cur.ih;
-            for (int y0 = 3 + BR * sub; y0 - BR * sub < yend; y0 += BR * RS) {
+            const int nblock = (cur.ih + BR * RS - 1) / (BR * RS);               // uniform trip count (the half-waves take different rows)
+            for (int b = 0; b < nblock; b++) {
+                const int y0 = 3 + BR * (RS * b + sub);
                 uint32_t M = 0;
                 if (!(dbg & 1)) {
-                    const uint32_t* tp = tile32 + (y0 - 3) * COLS + col;
+                    const uint32_t* tp = tile32 + (y0 - 3) * PD + col;
                     uint32_t R[BR + 6]; us2 E[BR + 6];
 #pragma unroll
-                    for (int k = 0; k < BR + 6; k++) { R[k] = tp[k * COLS]; E[k] = as_us2(R[k]) << 8; }
+                    for (int k = 0; k < BR + 6; k++) { R[k] = tp[k * PD]; E[k] = as_us2(R[k]) << 8; }
 #pragma unroll
                     for (int r = 0; r < BR; r++) {
                         const uint32_t C = R[r + 3];
@@ -701,11 +707,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         } else if (!(dbg & 4)) {
             // ---- scan B (the list overflowed and was flushed): find the corners again as the non-zero bytes of the score tile
             WAVE_LDS_FENCE();
-            for (int r0 = 1 + BR * sub; r0 - BR * sub <= cur.ih; r0 += BR * RS) {
+            const int nblock = (cur.ih + BR * RS - 1) / (BR * RS);
+            for (int b = 0; b < nblock; b++) {
+                const int r0 = 1 + BR * (RS * b + sub);
                 uint32_t M = 0;
 #pragma unroll
                 for (int r = 0; r < BR; r++) {
-                    const uint32_t S = (r0 + r <= cur.ih) ? score32[(r0 + r) * COLS + col] : 0u;
+                    const uint32_t S = (r0 + r <= cur.ih) ? score32[(r0 + r) * PD + col] : 0u;
                     const uint32_t nib = ((S & 0xFFu) ? 1u : 0u) | ((S & 0xFF00u) ? 2u : 0u) | ((S & 0xFF0000u) ? 4u : 0u) | ((S & 0xFF000000u) ? 8u : 0u);
                     M |= nib << (4 * r);
                 }
@@ -785,7 +793,7 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
                              int max_wcell, int max_hcell, hipStream_t s)
 {
     auto up = [](int v, int a) { return (v + a - 1) / a * a; };
-    const int lc = fast_rows_lc(), cols = 1 << lc, pitch = 4 * cols;
+    const int lc = fast_rows_lc(), cols = 1 << lc, pitch = 4 * cols + FR_PAD;
     // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
     // LDS (score tile / list follow) and those rows are masked out.  Template instances below.
     const int th_max = max_hcell + 6;
