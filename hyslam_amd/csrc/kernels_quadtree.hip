@@ -22,7 +22,7 @@
 //     a 64-bit LDS atomicMax on score<<56 | ~order, where order = (cell, y, x) reproduces the reference's
 //     candidate order (cells row-major, cv::FAST's row-major scan inside a cell).
 //
-// Inputs are the per-cell candidate slots written by k_fast_cells (gathered into a dense list first).  Outputs per (image, level):
+// Inputs are the per-cell candidate slots written by k_fast_rows (gathered into a dense list first).  Outputs per (image, level):
 // selected (x,y,score) in final list order + count.  Bound: LDS atomics / VALU; HBM traffic negligible.
 #include "hs_internal.h"
 #include <cstdlib>
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
-                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride, int dbg)
+                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride)
 {
     __shared__ QtNodes nodes[2];
     __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
         const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
-        for (int c0 = (dbg & 2) ? ncell : 0; c0 < ncell; c0 += QT_T) {
+        for (int c0 = 0; c0 < ncell; c0 += QT_T) {
             const int c = c0 + tid;
             const int k = c < ncell ? min(ccnt[c], ccap) : 0;
             int tot; const int pre = block_scan_excl(k, s_wave, tot);
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
-    if (dbg & 1) { if (tid == 0) *out_n = 0; return; }
 
     const int nIni = L.n_ini;
     const float hX = L.hx;
@@ -384,5 +383,5 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
 {
     dim3 grid(nlevels, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, getenv("HS_QT_DBG") ? atoi(getenv("HS_QT_DBG")) : 0);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride);
 }

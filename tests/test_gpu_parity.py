@@ -161,10 +161,11 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
-@pytest.mark.parametrize("env", [{}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32"},
-                                 {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}])
+@pytest.mark.parametrize("env", [{}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
+                                 {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
-    """the FAST kernel's tile-width variants, and its list-overflow (flush) paths forced by tiny LDS lists: same bits as the oracle"""
+    """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, and NMS driven from the score
+    tile instead of the corner list: same bits as the oracle"""
     e = dict(os.environ)
     e.update(env)
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
