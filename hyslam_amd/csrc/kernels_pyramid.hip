@@ -87,14 +87,22 @@ __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict_
     *reinterpret_cast<uint32_t*>(drow + dx0) = packed;   // pitch is a multiple of 64: padding bytes may be written
 }
 
-// LDS-staged variant (the fast path): a workgroup produces a 256 x LT_ROWS destination tile.  The source rectangle it needs is
-// fetched once with 16-byte coalesced loads into LDS; every lane then picks its 4 taps per output with LDS byte reads (no
-// per-output global loads, no dword select chains) — ~3x fewer instructions per pixel than k_resize_level and each source row is
-// read from HBM/L2 once per tile instead of once per destination row.  Needs 16-byte aligned source rows.
-#define LT_ROWS 8
+// LDS-staged variant (the fast path): a workgroup produces a 256 x LT_ROWS destination tile in three steps.
+//   A  the source rectangle it needs is fetched once with 16-byte coalesced loads into LDS (each source row is read from HBM/L2 once
+//      per tile instead of once per destination row)
+//   B  horizontal pass, once per SOURCE row: H = S[sx]*a0 + S[sx+1]*a1 for the tile's 256 columns, stored as (H >> 4) in 16 bits
+//      (the only form the vertical pass uses).  A lane makes 4 adjacent columns from an 8-byte window of the source row: one
+//      v_perm_b32 (byte pair -> two 16-bit fields, selectors precomputed per lane) + one v_dot2_u32_u16 per value.  Vertically adjacent
+//      destination rows share their source rows, so this pass runs ~1.4x per destination pixel instead of 2x.
+//   C  vertical pass: ((b0*H0)>>16) + ((b1*H1)>>16) + 2) >> 2 from two 8-byte LDS reads per 4 pixels.
+// ~14 VALU instructions per destination pixel instead of ~43 for the direct form (the kernel is VALU-issue bound, not HBM bound).
+// Needs 16-byte aligned source rows and a scale <= 2 (the 4 columns of a lane then span <= 8 source bytes).
+#define LT_ROWS 16
+typedef unsigned short hs_us2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restrict__ lv, int level, HsImg0 img0, int lds_pitch, int lds_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
+    uint16_t* const s_h = reinterpret_cast<uint16_t*>(s_src + (size_t)lds_pitch * lds_rows);      // [lds_rows][256] (H >> 4)
     const HsLevel& D = lv[level];
     const int img = blockIdx.z;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;        // 64 x 4 lanes
@@ -112,41 +120,57 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     const int sy_last = min(max((int)hs_gload<int16_t>(D.yofs + dy_last) + 1, 0), sh - 1);
     const int col0 = hs_gload<int16_t>(&xt[dx_tile].sx) & ~15;
     const int col_last = min(hs_gload<int16_t>(&xt[dx_last].sx) + 1, sw - 1);
-    const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch, nrow <= lds_rows
+    const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch - 16, nrow <= lds_rows
+    // ---- A
     for (int i = threadIdx.x; i < nvec * nrow; i += 256) {
         const int r = i / nvec, q = i - r * nvec;
         const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
         *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
     }
-    __syncthreads();
-
+    // per-lane column data (independent of the row): 8-byte window position, byte-pair selectors, coefficient pairs
     const int dx0 = dx_tile + 4 * tx;
-    if (dx0 >= D.w) return;
     HsXTab t[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, hs_gload<uint64_t>(&xt[min(dx0 + i, D.w - 1)]));
+    const int o0 = t[0].sx - col0;                              // byte offset of the window in a staged row
+    const int wbase = o0 & ~3, wshift = o0 & 3;
+    uint32_t sel[4], coef[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t q = (uint32_t)(t[i].sx - t[0].sx);       // 0..6: bytes q, q+1 of the window (a1 == 0 wherever sx+1 is past the row)
+        sel[i] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
+        coef[i] = (uint32_t)(uint16_t)t[i].a0 | ((uint32_t)(uint16_t)t[i].a1 << 16);
+    }
+    __syncthreads();
+    // ---- B
+    for (int r = ty; r < nrow; r += 4) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_src[r * lds_pitch + wbase]);
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, wshift);
+        uint32_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, sel[i])), __builtin_bit_cast(hs_us2, coef[i]), 0u, false) >> 4;
+        *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    __syncthreads();
+    // ---- C
+    if (dx0 >= D.w) return;
 #pragma unroll
     for (int rr = 0; rr < LT_ROWS / 4; rr++) {
         const int dy = dy_tile + ty + 4 * rr;
         if (dy >= D.h) break;
         const int sy = hs_gload<int16_t>(D.yofs + dy);
-        const int b0 = hs_gload<int16_t>(D.ibeta + 2 * dy), b1 = hs_gload<int16_t>(D.ibeta + 2 * dy + 1);
+        const uint32_t b0 = (uint32_t)hs_gload<int16_t>(D.ibeta + 2 * dy), b1 = (uint32_t)hs_gload<int16_t>(D.ibeta + 2 * dy + 1);
         const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
-        const uint8_t* S0 = &s_src[r0 * lds_pitch - col0];
-        const uint8_t* S1 = &s_src[r1 * lds_pitch - col0];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int sx = t[i].sx;
-            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
-            int h0, h1;
-            if (dx0 + i < D.xmax) { h0 = S0[sx] * t[i].a0 + S0[sx1] * t[i].a1; h1 = S1[sx] * t[i].a0 + S1[sx1] * t[i].a1; }
-            else { h0 = S0[sx] * 2048; h1 = S1[sx] * 2048; }
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 0xFF) << (8 * i);
-        }
+        const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
+        const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
+        const uint32_t v0 = (((b0 * (H0.x & 0xFFFFu)) >> 16) + ((b1 * (H1.x & 0xFFFFu)) >> 16) + 2) >> 2;
+        const uint32_t v1 = (((b0 * (H0.x >> 16)) >> 16) + ((b1 * (H1.x >> 16)) >> 16) + 2) >> 2;
+        const uint32_t v2 = (((b0 * (H0.y & 0xFFFFu)) >> 16) + ((b1 * (H1.y & 0xFFFFu)) >> 16) + 2) >> 2;
+        const uint32_t v3 = (((b0 * (H0.y >> 16)) >> 16) + ((b1 * (H1.y >> 16)) >> 16) + 2) >> 2;
         uint8_t* drow = D.base + (size_t)img * D.img_stride + (size_t)dy * D.pitch;
-        hs_gstore<uint32_t>(drow + dx0, packed);
+        hs_gstore<uint32_t>(drow + dx0, (v0 & 0xFF) | ((v1 & 0xFF) << 8) | ((v2 & 0xFF) << 16) | (v3 << 24));   // pitch is a multiple of 64: padding bytes may be written
     }
 }
 
@@ -163,8 +187,8 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
         const double scx = (double)sw / D.w, scy = (double)sh / D.h;
         const int lds_pitch = (((int)(256 * scx) + 2 + 15 + 15) & ~15) + 16;
         const int lds_rows = (int)(LT_ROWS * scy) + 4;
-        const size_t lds_bytes = (size_t)lds_pitch * lds_rows;
-        if (vec16 && lds_bytes <= 60 * 1024) {
+        const size_t lds_bytes = (size_t)lds_pitch * lds_rows + (size_t)lds_rows * 256 * 2;      // source rectangle + 16-bit horizontal sums
+        if (vec16 && lds_bytes <= 60 * 1024 && scx <= 2.0) {
             dim3 grid((D.w + 255) / 256, (D.h + LT_ROWS - 1) / LT_ROWS, batch);
             hipLaunchKernelGGL(k_resize_level_lds, grid, dim3(256), lds_bytes, s, d_lv, l, img0, lds_pitch, lds_rows);
             continue;
