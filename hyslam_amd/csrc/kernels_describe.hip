@@ -84,6 +84,21 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][H_ELEMS];
+    __shared__ uint2 s_momw[31 * 10];        // intensity-centroid weights per aligned dword of the blurred tile: .x bytes = u + 15, .y bytes = 1 (0 outside the disc)
+
+    // weights of the 749-pixel disc (ORBFinder.cpp:131-149): rows v = -15..15 of the tile (row 18 + v), dwords q = 0..9 (columns 4q..4q+3, u = column - 18)
+    for (int i = threadIdx.x; i < 31 * 10; i += 64 * KP_PER_BLOCK) {
+        const int r = i / 10, q = i - r * 10;
+        const int av = r < 15 ? 15 - r : r - 15, d = c_umax[av];
+        uint32_t wu = 0, w1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int uu = 4 * q + j - 18;
+            if ((uu < 0 ? -uu : uu) <= d) { wu |= (uint32_t)(uu + 15) << (8 * j); w1 |= 1u << (8 * j); }
+        }
+        s_momw[i] = make_uint2(wu, w1);
+    }
+    __syncthreads();
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int img = blockIdx.y;
@@ -122,16 +137,16 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     // ---- raw 43x43 neighbourhood.  Interior keypoints: aligned dword rows, the tile keeps the source misalignment `sh`.
     //      Patches that touch the level border: byte loads with BORDER_REFLECT_101.
     const int x0 = cx - 21, y0 = cy - 21;
-    const bool interior = x0 >= 0 && y0 >= 0 && cy + 21 < L.h && cx + 24 < L.w;
+    const bool interior = x0 >= 0 && y0 >= 0 && cy + 21 < L.h && cx + 27 < L.w;     // 48 bytes are fetched per row: x0 + 47 stays inside it
     if (FT && interior) {
-        // 11 dwords per row starting at the patch's own first byte: gfx9 global loads take unaligned dword addresses, so the LDS tile
+        // three 16-byte loads per row starting at the patch's own first byte: gfx9 global loads take unaligned addresses, so the LDS tile
         // is aligned to the patch and the row pass below needs no per-keypoint byte shifts
-        struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
-        typedef const HS_GLOBAL U32* gu32;
+        struct __attribute__((packed, aligned(1))) U128 { hs_u32x4 v; };
+        typedef const HS_GLOBAL U128* gu128;
         const uint8_t* src = base + (size_t)y0 * pitch + x0;
-        for (int i = lane; i < RAW_N * 11; i += 64) {
-            int r = i / 11, q = i - r * 11;
-            *reinterpret_cast<uint32_t*>(&raw[r * RAW_P + 4 * q]) = ((gu32)(uintptr_t)(src + (size_t)r * pitch + 4 * q))->v;
+        for (int i = lane; i < RAW_N * 3; i += 64) {
+            int r = i / 3, q = i - r * 3;
+            *reinterpret_cast<hs_u32x4*>(&raw[r * RAW_P + 16 * q]) = ((gu128)(uintptr_t)(src + (size_t)r * pitch + 16 * q))->v;
         }
     } else {
         for (int i = lane; i < RAW_N * RAW_N; i += 64) {
@@ -206,13 +221,16 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     WAVE_LDS_SYNC();
 
     // ---- intensity centroid (ORBFinder.cpp:16-43): integer moments over the umax disc
+    //      m10 = sum u*I, m01 = sum v*I as v_dot4_u32_u8 over aligned dwords: sum (u+15)*I - 15*sum I, and v * (row sum)
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        int vv = i / 31 - 15, uu = i - (i / 31) * 31 - 15;
-        int av = vv < 0 ? -vv : vv, au = uu < 0 ? -uu : uu;
-        if (au <= c_umax[av]) {
-            int I = bl[(18 + vv) * BL_P + 18 + uu];
-            m10 += uu * I; m01 += vv * I;
+    {
+        const uint32_t* bl32 = reinterpret_cast<const uint32_t*>(bl);
+        for (int i = lane; i < 31 * 10; i += 64) {
+            const int r = i / 10, q = i - r * 10;
+            const uint32_t W = bl32[(3 + r) * (BL_P / 4) + q];
+            const uint2 wt = s_momw[i];
+            const int s1 = (int)__builtin_amdgcn_udot4(W, wt.y, 0u, false), su = (int)__builtin_amdgcn_udot4(W, wt.x, 0u, false);
+            m10 += su - 15 * s1; m01 += (r - 15) * s1;
         }
     }
 #pragma unroll
@@ -222,7 +240,9 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     // ---- rBRIEF (ORBFinder.cpp:89-129)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float theta = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)theta), b = (float)sin((double)theta);
+    double sin_t, cos_t;
+    sincos((double)theta, &sin_t, &cos_t);                      // one argument reduction; same values as sin() and cos()
+    const float a = (float)cos_t, b = (float)sin_t;
     uint8_t* dout = desc + ((size_t)oimg * cap + g) * HS_DESC_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
