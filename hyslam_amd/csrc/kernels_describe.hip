@@ -180,17 +180,20 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         //      the odd row r+1 uses (0,t0)(t1,t2)(t3,t4)(t5,t6) on the SAME dwords
         const uint32_t e0 = tp[0] | (tp[1] << 16), e1 = tp[2] | (tp[3] << 16), e2 = tp[4] | (tp[5] << 16), e3 = tp[6];
         const uint32_t o0 = tp[0] << 16, o1 = tp[1] | (tp[2] << 16), o2 = tp[3] | (tp[4] << 16), o3 = tp[5] | (tp[6] << 16);
-        for (int i = lane; i < BL_N * 19; i += 64) {
-            const int c = i / 19, rp = i - c * 19;              // rows 2rp, 2rp+1 (row 37 does not exist)
-            const int r = 2 * rp;
+        // a lane makes 4 vertically adjacent outputs (rows r..r+3, r = 4*rq) from the five dwords H[r..r+9] of its column
+        for (int i = lane; i < BL_N * 10; i += 64) {
+            const int c = i / 10, rq = i - c * 10;
+            const int r = 4 * rq;
             const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
-            const uint32_t a0 = col[0], a1 = col[1], a2 = col[2], a3 = col[3];
-            const uint32_t ve = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0u))));
-            bl[r * BL_P + c] = (uint8_t)min((ve + 0x8000u) >> 16, 255u);
-            if (r + 1 < BL_N) {
-                const uint32_t vo = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0u))));
-                bl[(r + 1) * BL_P + c] = (uint8_t)min((vo + 0x8000u) >> 16, 255u);
-            }
+            const uint32_t a0 = col[0], a1 = col[1], a2 = col[2], a3 = col[3], a4 = col[4];   // rows >= 43 (last group): pad / next column, only the discarded outputs see them
+            const uint32_t v0 = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0u))));
+            const uint32_t v1 = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0u))));
+            const uint32_t v2 = udot2(a4, e3, udot2(a3, e2, udot2(a2, e1, udot2(a1, e0, 0u))));
+            const uint32_t v3 = udot2(a4, o3, udot2(a3, o2, udot2(a2, o1, udot2(a1, o0, 0u))));
+            bl[r * BL_P + c] = (uint8_t)min((v0 + 0x8000u) >> 16, 255u);
+            if (r + 1 < BL_N) bl[(r + 1) * BL_P + c] = (uint8_t)min((v1 + 0x8000u) >> 16, 255u);
+            if (r + 2 < BL_N) bl[(r + 2) * BL_P + c] = (uint8_t)min((v2 + 0x8000u) >> 16, 255u);
+            if (r + 3 < BL_N) bl[(r + 3) * BL_P + c] = (uint8_t)min((v3 + 0x8000u) >> 16, 255u);
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
