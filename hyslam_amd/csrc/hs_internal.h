@@ -88,6 +88,9 @@ __host__ __device__ inline const uint8_t* hs_img0_ptr(const HsImg0& I, int img)
 #define HS_GLOBAL __attribute__((address_space(1)))
 typedef uint32_t hs_u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ T hs_gload(const void* p) { return *(const HS_GLOBAL T*)(uintptr_t)p; }
+// read-only tables at a wave-uniform address: the constant address space lets the compiler use scalar loads (SGPR result, no VALU/VMEM slot)
+#define HS_CONSTANT __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ T hs_cload(const void* p) { return *(const HS_CONSTANT T*)(uintptr_t)p; }
 // a pointer the compiler must keep in SGPRs (so that `uniform base + 32-bit lane offset` becomes the saddr form of global_load)
 __device__ __forceinline__ const uint8_t* hs_uniform_ptr(const uint8_t* p)
 {

@@ -121,11 +121,17 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     const int col0 = hs_gload<int16_t>(&xt[dx_tile].sx) & ~15;
     const int col_last = min(hs_gload<int16_t>(&xt[dx_last].sx) + 1, sw - 1);
     const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch - 16, nrow <= lds_rows
-    // ---- A
-    for (int i = threadIdx.x; i < nvec * nrow; i += 256) {
-        const int r = i / nvec, q = i - r * nvec;
-        const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
-        *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
+    // ---- A: a wave takes whole source rows, floor(64 / nvec) at a time (no per-lane division by the runtime nvec)
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));          // rows per wave step
+        const int rl = (lane >= nvec) + (lane >= 2 * nvec) + (lane >= 3 * nvec), q = lane - rl * nvec;
+        if (lane < rpw * nvec) {
+            for (int r = wave * rpw + rl; r < nrow; r += 4 * rpw) {
+                const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
+                *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
+            }
+        }
     }
     // per-lane column data (independent of the row): 8-byte window position, byte-pair selectors, coefficient pairs
     const int dx0 = dx_tile + 4 * tx;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     }
     __syncthreads();
     // ---- B
-    for (int r = ty; r < nrow; r += 4) {
+    for (int r = __builtin_amdgcn_readfirstlane(ty); r < nrow; r += 4) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_src[r * lds_pitch + wbase]);
         const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
         const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, wshift);
@@ -154,14 +160,17 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
         *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     }
     __syncthreads();
-    // ---- C
+    // ---- C: the destination row of a wave is uniform, so its source rows and weights come from scalar loads
     if (dx0 >= D.w) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t* const dimg = D.base + (size_t)img * D.img_stride;
 #pragma unroll
     for (int rr = 0; rr < LT_ROWS / 4; rr++) {
-        const int dy = dy_tile + ty + 4 * rr;
+        const int dy = dy_tile + wave + 4 * rr;
         if (dy >= D.h) break;
-        const int sy = hs_gload<int16_t>(D.yofs + dy);
-        const uint32_t b0 = (uint32_t)hs_gload<int16_t>(D.ibeta + 2 * dy), b1 = (uint32_t)hs_gload<int16_t>(D.ibeta + 2 * dy + 1);
+        const int sy = hs_cload<int16_t>(D.yofs + dy);
+        const uint32_t b01 = hs_cload<uint32_t>(D.ibeta + 2 * dy);
+        const uint32_t b0 = b01 & 0xFFFFu, b1 = b01 >> 16;
         const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
         const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
         const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
@@ -169,8 +178,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
         const uint32_t v1 = (((b0 * (H0.x >> 16)) >> 16) + ((b1 * (H1.x >> 16)) >> 16) + 2) >> 2;
         const uint32_t v2 = (((b0 * (H0.y & 0xFFFFu)) >> 16) + ((b1 * (H1.y & 0xFFFFu)) >> 16) + 2) >> 2;
         const uint32_t v3 = (((b0 * (H0.y >> 16)) >> 16) + ((b1 * (H1.y >> 16)) >> 16) + 2) >> 2;
-        uint8_t* drow = D.base + (size_t)img * D.img_stride + (size_t)dy * D.pitch;
-        hs_gstore<uint32_t>(drow + dx0, (v0 & 0xFF) | ((v1 & 0xFF) << 8) | ((v2 & 0xFF) << 16) | (v3 << 24));   // pitch is a multiple of 64: padding bytes may be written
+        hs_gstore<uint32_t>(dimg + (size_t)dy * D.pitch + dx0, v0 | (v1 << 8) | (v2 << 16) | (v3 << 24));   // every v <= 255; pitch is a multiple of 64: padding bytes may be written
     }
 }
 
