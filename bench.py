@@ -52,10 +52,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--handles", type=int, default=2,
+    ap.add_argument("--handles", type=int, default=1,
                     help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
-                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  The path's kernels are latency-bound, so two "
-                         "independent launch sequences fill each other's stalls")
+                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  While the kernels were latency-bound two "
+                         "independent launch sequences filled each other's stalls (+19 %); now that they are issue-bound one handle is as fast")
     ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
                     help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
@@ -319,18 +319,18 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
 
 
 def measured_traffic(kernel, pairs_per_step, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_e_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_f_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled per the gfx950 calibration).  Counters cannot be read from
     inside this process, so the value is only reported when the profiled batch size matches; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_f_hbm_traffic.json")
     try:
         t = json.load(open(path))
-        k = {"fast_cells": "k_fast_cells", "pyramid": "k_resize_level", "describe": "k_describe", "quadtree": "k_quadtree"}[kernel]
+        k = {"fast_cells": "k_fast_rows", "pyramid": "k_resize_level_lds", "describe": "k_describe", "quadtree": "k_quadtree"}[kernel]
         e = t["kernels"][k]
         if t["pairs_per_step"] != pairs_per_step or e["frames_per_launch"] != frames_per_launch:
             return None, None
         mult = 7 if kernel == "pyramid" else 1          # the pyramid stage is 7 launches of k_resize_level; the file holds the per-launch mean
-        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_e_hbm_traffic.json"
+        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_f_hbm_traffic.json"
     except Exception:
         return None, None
 

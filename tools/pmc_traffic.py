@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GIB = 1 << 30
 PAIRS = 16
-LANES = 2            # two launch sequences of 8 pairs each per step, the same launch shapes as bench.py's default (2 handles x 8 pairs)
+LANES = 1            # one launch sequence of 16 pairs per step, the same launch shapes as bench.py's default (1 handle)
 
 
 def run():
@@ -71,10 +71,10 @@ def report(dfetch, dwrite):
         cal[width] = (f, w)
         print("# calibration %-11s (1 GiB read + 1 GiB written, %2d B/lane): FETCH_SIZE reports %.3f x, WRITE_SIZE reports %.3f x of the true bytes" % (name, width, f, w))
     print("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,read_MB_per_launch_corrected,written_MB_per_launch_corrected,frames_per_launch")
-    # every kernel of the path reads and writes 4 B/lane (dword tile rows, dword pixel groups); k_resize_level_lds reads 16 B/lane
+    # the streaming kernels (pyramid, FAST, describe) read 16 B/lane; the rest reads and writes 4 B/lane
     kernels = sorted({k for (k, c) in F if k.startswith("k_") and not k.startswith("k_copy")})
     for k in kernels:
-        wd = 16 if k.startswith("k_resize_level_lds") else 4
+        wd = 16 if k.startswith(("k_resize_level_lds", "k_fast_rows", "k_describe")) else 4
         f = F[(k, "FETCH_SIZE")]; w = Wr[(k, "WRITE_SIZE")]
         fa, wa = sum(f) / len(f), sum(w) / len(w)
         print("%s,%d,%.1f,%.1f,%.2f,%.2f,%d" % (k.replace(",", ";"), len(f), fa, wa, fa * 1024 / cal[wd][0] / 1e6, wa * 1024 / cal[wd][1] / 1e6, 2 * PAIRS // LANES))
