@@ -33,6 +33,7 @@ struct hs_orb {
     // device memory
     HsLevel* d_lv = nullptr;
     HsFastItem* d_fast_items = nullptr;
+    uint32_t* d_fast_ovf = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
     uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr, *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
@@ -80,6 +81,7 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
+    hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
     hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
     h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
@@ -199,6 +201,7 @@ int configure(hs_orb* h, int w, int hh, int batch)
         hs_fast_build_items(h->lv.data(), L, fi.data());
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell), 256)));
     }
     h->w = w; h->h = hh; h->batch_cap = batch;
     return HS_OK;
@@ -250,7 +253,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
     hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, s);
+                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, s);

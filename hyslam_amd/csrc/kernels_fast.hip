@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t fr_field_flags(us2 s, uint32_t ones)
     return r;
 }
 
-struct FastRowsLds { int32_t off_score, off_plist, score_bytes, pcap, total; };
+struct FastRowsLds { int32_t off_plist, off_pscore, off_cnt, pcap, total; };
 
 struct RowGeom {            // wave-uniform description of one work item in one image
     int img;
@@ -167,7 +167,8 @@ template <int LC, int TR>
 __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
                                                   uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
-                                                  int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b)
+                                                  int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -179,9 +180,11 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     constexpr int BR = 8;                    // rows per lane and scan block
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const tile = smem;
-    uint8_t* const score = smem + lds.off_score;
+    uint8_t* const score = smem;                                                 // the score tile REUSES the pixel tile once every corner is scored
     uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
-    uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(score + lds.score_bytes - 4 * FR_MAXG);   // last bytes of the (zeroed) score area
+    uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
+    uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
+    uint32_t* const ovf = overflow + (size_t)blockIdx.x * overflow_stride;       // this wave's spill area for scored corners (list overflow only)
     const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
     const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
 
@@ -203,10 +206,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     int w = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
     if (w >= x_end) return;
 
-    auto zero_score = [&]() {
-        for (int i = tid * 16; i < lds.score_bytes; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
-    };
-    zero_score();
+    if (tid < FR_MAXG) cellcnt[tid] = 0;
 
 #ifdef HS_FAST_PROFILE
     unsigned long long fr_acc[10] = {};
@@ -268,10 +268,10 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         const uint32_t vmask8 = vmask * 0x5555u;                 // the same for the 8 rows of a scan block (row r at << 2r)
         int npx = 0;                                             // wave-uniform list length
-        int cs_runs = 0, n_last_corner = 0;                      // how often corners_and_scores ran for this item; corners of its last run
+        int n_last_corner = 0, n_ovf = 0;                        // corners of the final corners_and_scores run (in the list); corners spilled by earlier runs
 
         // ---- pixel list -> corners -> scores
-        auto corners_and_scores = [&]() {
+        auto corners_and_scores = [&](bool final) {
             FR_FENCE();
             FR_T(tc0);
             int n_corner = 0;
@@ -314,10 +314,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #pragma unroll
                 for (int k = 0; k < 16; k++) { int e = v - (int)ctr[RO[k]]; d[k] = bright ? -e : e; }
                 const int gc = (px * inv_w) >> 16;               // cell of the item; its columns start at 1 + gc*(wcell+1)
-                score[(py + 1) * PITCH + 1 + px + gc] = (uint8_t)fast_corner_score(d);
-                plist[i] = (uint16_t)(((py + 1) << 8) | (1 + px + gc));   // score tile coordinates: what nms_and_emit reads
+                const uint32_t sc_pos = (uint32_t)(((py + 1) << 8) | (1 + px + gc)), sc_val = (uint32_t)fast_corner_score(d) & 0xFFu;
+                plist[i] = (uint16_t)sc_pos;                     // score tile coordinates: what nms_and_emit reads
+                pscore[i] = (uint8_t)sc_val;
+                if (!final) ovf[n_ovf + i] = (sc_pos << 8) | sc_val;   // the list is about to be reused: spill (row, column, score)
             }
-            npx = 0; cs_runs++; n_last_corner = n_corner;
+            npx = 0;
+            if (final) n_last_corner = n_corner; else n_ovf += n_corner;
             FR_FENCE();
             FR_T(tc2);
             FR_ACC(5, tc1, tc2);
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             const int incl = wave_scan_incl((int)__popc(M));
             const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0) return;
-            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(); }
+            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(false); }
             if (total <= lds.pcap) {
                 int pos = npx + incl - (int)__popc(M);
                 while (M) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x00030003u << (2 * r)));
                     const int incl_r = wave_scan_incl((int)__popc(Mr));
                     const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 4*COLS <= pcap
-                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(); }
+                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(false); }
                     int pos = npx + incl_r - (int)__popc(Mr);
                     while (Mr) {
                         const int b = __ffs((int)Mr) - 1;
@@ -413,16 +416,29 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 }
                 emit_mask(M, y0, false);
             }
-            if (npx > 0) corners_and_scores();
+            corners_and_scores(true);
         }
         FR_T(t4);
         FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
+        // ---- the pixel tile is dead: its LDS becomes the dense score tile (rows 0..ih+1, zero except at the corners)
+        for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < n_last_corner; i += 64) {
+            const int pos = plist[i];
+            score[(pos >> 8) * PITCH + (pos & 255)] = pscore[i];
+        }
+        if (n_ovf > 0) {                                         // spilled corners come back through L2 (the wave's own stores: wait, then bypass L1)
+            __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
+            for (int i = tid; i < n_ovf; i += 64) {
+                const uint32_t rec = __hip_atomic_load(&ovf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                score[(rec >> 16) * PITCH + ((rec >> 8) & 255)] = (uint8_t)rec;
+            }
+        }
         // ---- NMS.  Usual case: every corner of the item is still in the list (score coordinates).
-        if (cs_runs <= 1 && !force_scan_b) {
+        if (n_ovf == 0 && !force_scan_b) {
             npx = n_last_corner;
             nms_and_emit();
         } else {
-            // ---- scan B (the list overflowed and was flushed): find the corners again as the non-zero bytes of the score tile
+            // ---- scan B (the list overflowed and corners were spilled): find the corners again as the non-zero bytes of the score tile
             FR_FENCE();
             const int nblock = (cur.ih + BR * RS - 1) / (BR * RS);
             for (int b = 0; b < nblock; b++) {
@@ -441,10 +457,10 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_FENCE();
         FR_T(t5);
         FR_ACC(6, t4, t5);
-        // ---- per-cell counts; restore the all-zero score tile (and counters)
+        // ---- per-cell counts; reset the counters
         if (tid < cur.ncell) cnt_out[tid] = (int32_t)cellcnt[tid];
         FR_FENCE();
-        zero_score();
+        if (tid < FR_MAXG) cellcnt[tid] = 0;
 #ifdef HS_FAST_PROFILE
         FR_FENCE();
         FR_T(t6);
@@ -505,34 +521,52 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
     }
 }
 
+// launch configuration shared by the launcher and by hs_fast_overflow_bytes()
+struct FastRowsCfg { int lc, tr, per_cu; uint32_t ovf_stride; FastRowsLds lds; };
+static FastRowsCfg fast_rows_cfg(int max_hcell)
+{
+    FastRowsCfg c;
+    c.lc = fast_rows_lc();
+    const int cols = 1 << c.lc, pitch = 4 * cols + FR_PAD;
+    // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
+    // LDS (the lists follow) and those rows are masked out.  Template instances below.
+    const int th_max = max_hcell + 6;
+    c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : 70;
+    FastRowsLds& L = c.lds;
+    L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
+    if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the spill paths
+    int o = c.tr * pitch;                                     // pixel tile, later the score tile (rows 0..ih+1 <= th-4)
+    L.off_plist = o; o += L.pcap * 2;
+    L.off_pscore = o; o += L.pcap;
+    L.off_cnt = o; o += 4 * FR_MAXG;
+    o = std::max(o, (c.tr + 8) * pitch);                      // the over-read of the last scan block stays inside the allocation
+    L.total = (o + 15) & ~15;
+    c.per_cu = std::max(1, std::min(16, (160 * 1024) / L.total));
+    if (const char* e = getenv("HS_FAST_WG_PER_CU")) c.per_cu = std::max(1, std::min(c.per_cu, atoi(e)));
+    c.ovf_stride = (uint32_t)((4 * cols - 9) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
+    return c;
+}
+size_t hs_fast_overflow_bytes(int max_hcell)
+{
+    const FastRowsCfg c = fast_rows_cfg(max_hcell);
+    return (size_t)256 * c.per_cu * c.ovf_stride * 4;
+}
+
 static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, hipStream_t s)
 {
-    const int lc = fast_rows_lc(), cols = 1 << lc, pitch = 4 * cols + FR_PAD;
-    // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
-    // LDS (score tile / list follow) and those rows are masked out.  Template instances below.
-    const int th_max = max_hcell + 6;
-    const int tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : 70;
-    FastRowsLds L;
-    L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
-    if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the flush paths
-    int o = tr * pitch;
-    L.off_score = o;
-    L.score_bytes = (max_hcell + 3) * pitch;                  // rows 0..ih+1 are read; the per-cell counters sit at the end of one more row
-    o += L.score_bytes;
-    L.off_plist = o; o += L.pcap * 2;
-    o = std::max(o, (tr + 8) * pitch);                        // the over-read of the last scan block stays inside the allocation
-    L.total = o;
+    (void)max_wcell;
+    const FastRowsCfg c = fast_rows_cfg(max_hcell);
+    const FastRowsLds& L = c.lds;
+    const int lc = c.lc, tr = c.tr;
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return;
-    int per_cu = std::max(1, std::min(16, (160 * 1024) / L.total));
-    if (const char* e = getenv("HS_FAST_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
-    int nblk = 256 * per_cu;
+    int nblk = 256 * c.per_cu;
     while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;
     int force_scan_b = 0; if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) force_scan_b = atoi(e) != 0;   // parity tests: NMS from the score tile
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else FR_LAUNCH(6, 70); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else FR_LAUNCH(5, 70); }
 #undef FR_LAUNCH
@@ -540,9 +574,9 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0) return;
-    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, s);
+    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, s);
 }

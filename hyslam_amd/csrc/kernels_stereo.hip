@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict_
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int pair = blockIdx.y;
     const int iL = blockIdx.x * 4 + wv;
-    const int nL = min(nLs[pair], cap), nR = min(nRs[pair], cap);
+    const int nL = min(nLs[pair], cap);
     if (iL >= cap) return;
     const size_t o = (size_t)pair * cap;
     if (iL >= nL) { if (lane == 0) { uRight[o + iL] = -1.0f; depth[o + iL] = -1.0f; best_dist[o + iL] = -1; } return; }
