@@ -52,10 +52,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--handles", type=int, default=1,
+    ap.add_argument("--handles", type=int, default=2,
                     help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
-                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  While the kernels were latency-bound two "
-                         "independent launch sequences filled each other's stalls (+19 %); now that they are issue-bound one handle is as fast")
+                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  Two independent launch sequences overlap one "
+                         "sequence's latency-bound kernels (quadtree, stereo, small pyramid levels) with the other's issue-bound ones: +10 %")
     ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
                     help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",

@@ -419,7 +419,7 @@ int hs_orb_max_keypoints(const hs_orb* h)
     // 4*nIni nodes of the unconditional first pass.  nIni depends on the frame; assume the widest supported.
     int n = 0;
     for (int l = 0; l < h->p.nlevels; l++) n += std::max(h->quota[l] + 4, 4 * 8 + 4);
-    return n;
+    return std::max(n, h->max_kp);          // a configured geometry (hs_orb_reserve / a previous extract) with more than 8 root nodes per level needs more
 }
 
 int hs_orb_reserve(hs_orb* h, int w, int h_px, int batch)

@@ -124,6 +124,7 @@ class ORBExtractor:
                 raise ValueError("batched frames must have equal size")
         b = len(imgs)
         h, w = imgs[0].shape
+        self.reserve(w, h, b)                                   # max_keypoints() depends on the frame's aspect ratio (root nodes per level)
         cap = self.max_keypoints()
         kps = np.zeros((b, cap), KP_DTYPE)
         desc = np.zeros((b, cap, 32), np.uint8)

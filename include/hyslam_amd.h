@@ -85,7 +85,8 @@ int  hs_orb_get_levels(const hs_orb* h);
 float hs_orb_get_scale_factor(const hs_orb* h);
 int  hs_orb_get_scale_tables(const hs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                              int32_t* features_per_level);
-/* smallest `cap` that can never overflow: nfeatures + per-level overshoot of DistributeOctTree */
+/* smallest `cap` that can never overflow: nfeatures + per-level overshoot of DistributeOctTree.  Frames wider than 8:1 start the
+ * quadtree with more than 8 root nodes per level and need more: call hs_orb_reserve() for the frame size first, the value then covers it. */
 int  hs_orb_max_keypoints(const hs_orb* h);
 /* optional: size the device workspace up front for `batch` images of w x h (grows lazily otherwise) */
 int  hs_orb_reserve(hs_orb* h, int w, int h_px, int batch);
