@@ -278,8 +278,11 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             for (int i0 = 0; i0 < npx; i0 += 64) {
                 const int i = i0 + tid;
                 const bool act = i < npx;
-                const int pos = plist[act ? i : 0];
-                const int py = pos >> 8, px = pos & 255;
+                const int code = plist[act ? i : 0];
+                const int eb = code & 31, el = (code >> 5) & 63;                 // bit of the scan mask, lane that found it
+                const int py = BR * (RS * (code >> 11) + (el >> LC)) + ((eb >> 1) & 7);
+                const int px = 4 * (el & (COLS - 1)) + ((eb & 1) | ((eb >> 4) << 1)) - c_first;
+                const int pos = (py << 8) | px;
                 const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
                 const int v = ctr[0];
                 const int lo = v - t, hi = v + t;
@@ -354,7 +357,10 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 
         // ---- the set bits of M (one per pixel of this lane's scan block) -> pixel list.  SCORES: bit 4r+j, entries in score tile
         //      coordinates; otherwise bit 2r + (j&1) + 16*(j>>1), entries relative to the interior.  `row0`: tile/score row of r = 0.
-        auto emit_mask = [&](uint32_t M, int row0, bool scores) {
+        // Scan A entries are CODES (block<<11 | lane<<5 | bit of M), decoded on dense lanes by corners_and_scores: the per-lane bit loop
+        // below runs for as many rounds as the busiest lane has hits, so every instruction in it counts ~10x.
+        auto emit_mask = [&](uint32_t M, int row0, bool scores, int blk) {
+            const uint32_t code0 = ((uint32_t)blk << 11) | ((uint32_t)tid << 5);
             const int incl = wave_scan_incl((int)__popc(M));
             const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0) return;
@@ -364,8 +370,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 while (M) {
                     const int b = __ffs((int)M) - 1;
                     M &= M - 1;
-                    const int r = scores ? (b >> 2) : ((b >> 1) & 7), j = scores ? (b & 3) : ((b & 1) | ((b >> 4) << 1));
-                    plist[pos++] = scores ? (uint16_t)(((row0 + r) << 8) | (4 * col + j)) : (uint16_t)(((row0 + r - 3) << 8) + (4 * col + j - c_first));
+                    plist[pos++] = scores ? (uint16_t)(((row0 + (b >> 2)) << 8) | (4 * col + (b & 3))) : (uint16_t)(code0 | (uint32_t)b);
                 }
                 npx += total;
             } else {                                             // a block alone overflows the list (saturated image): one row at a time
@@ -378,8 +383,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     while (Mr) {
                         const int b = __ffs((int)Mr) - 1;
                         Mr &= Mr - 1;
-                        const int j = scores ? (b & 3) : ((b & 1) | ((b >> 4) << 1));
-                        plist[pos++] = scores ? (uint16_t)(((row0 + r) << 8) | (4 * col + j)) : (uint16_t)(((row0 + r - 3) << 8) + (4 * col + j - c_first));
+                        plist[pos++] = scores ? (uint16_t)(((row0 + r) << 8) | (4 * col + (b & 3))) : (uint16_t)(code0 | (uint32_t)b);
                     }
                     npx += total_r;
                 }
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior
                     M &= vmask8 & (((1u << (2 * nrow)) - 1u) * 0x00010001u);
                 }
-                emit_mask(M, y0, false);
+                emit_mask(M, y0, false, b);
             }
             corners_and_scores(true);
         }
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     const uint32_t nib = ((S & 0xFFu) ? 1u : 0u) | ((S & 0xFF00u) ? 2u : 0u) | ((S & 0xFF0000u) ? 4u : 0u) | ((S & 0xFF000000u) ? 8u : 0u);
                     M |= nib << (4 * r);
                 }
-                emit_mask(M, r0, true);
+                emit_mask(M, r0, true, b);
             }
             if (npx > 0) nms_and_emit();
         }
