@@ -21,7 +21,7 @@ f = first("stats/**/*kernel_stats.csv")
 rows = list(csv.reader(open(f)))
 with open("profiles/%s_kernel_stats.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0\n")
-    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step, one handle -> every kernel launch covers 32 frames; MI355X; tag %s\n" % tag)
+    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step dealt over 2 handles -> every kernel launch covers 16 frames; MI355X; tag %s\n" % tag)
     w = csv.writer(o)
     for r in rows:
         r[0] = r[0].split("(")[0][:60]
@@ -42,7 +42,7 @@ for r in csv.DictReader(open(first("sq/**/*counter_collection.csv"))):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
-    o.write("# per-launch averages; bench.py default (1 handle, 16 pairs): 32 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
+    o.write("# per-launch averages; bench.py default (2 handles x 8 pairs): 16 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
     names = sorted({c for d in agg.values() for c in d})
     o.write("kernel,launches," + ",".join(names) + "\n")
     for k, d in agg.items():
