@@ -34,7 +34,7 @@ __constant__ int8_t c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 1
 #define BL_N 37
 #define H_P 38                   // generic path: row-major u16 row sums
 #define HT_P 46                  // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
-#define H_ELEMS (BL_N * HT_P + 2) // 1704 >= RAW_N * H_P = 1634
+#define H_ELEMS (40 * HT_P)       // fast path: 40 columns are written (37 used); 1840 >= RAW_N * H_P = 1634
 #define BL_P 40
 #define KP_PER_BLOCK 4
 
@@ -165,13 +165,12 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
             const int r = i / 10, gq = i - r * 10;
             const uint32_t* row = reinterpret_cast<const uint32_t*>(&raw[r * RAW_P + 4 * gq]);
             const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
+            uint16_t* out = &hb[4 * gq * HT_P + r];            // columns 37..39 of the last group are written too (storage exists, never read)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int c = 4 * gq + j;
                 const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, j);
                 const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, j);
-                const uint32_t hsum = __builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
-                if (c < BL_N) hb[c * HT_P + r] = (uint16_t)hsum;
+                out[j * HT_P] = (uint16_t)__builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
             }
         }
         if (lane < BL_N) hb[lane * HT_P + 43] = 0;              // pad element (only ever multiplied by a zero tap)
@@ -190,10 +189,11 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
             const uint32_t v1 = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0u))));
             const uint32_t v2 = udot2(a4, e3, udot2(a3, e2, udot2(a2, e1, udot2(a1, e0, 0u))));
             const uint32_t v3 = udot2(a4, o3, udot2(a3, o2, udot2(a2, o1, udot2(a1, o0, 0u))));
-            bl[r * BL_P + c] = (uint8_t)min((v0 + 0x8000u) >> 16, 255u);
-            if (r + 1 < BL_N) bl[(r + 1) * BL_P + c] = (uint8_t)min((v1 + 0x8000u) >> 16, 255u);
-            if (r + 2 < BL_N) bl[(r + 2) * BL_P + c] = (uint8_t)min((v2 + 0x8000u) >> 16, 255u);
-            if (r + 3 < BL_N) bl[(r + 3) * BL_P + c] = (uint8_t)min((v3 + 0x8000u) >> 16, 255u);
+            uint8_t* o = &bl[r * BL_P + c];                    // rows 37..39 of the last group land in the tile's unused tail (the tile is 43 x 48 bytes)
+            o[0] = (uint8_t)min((v0 + 0x8000u) >> 16, 255u);
+            o[BL_P] = (uint8_t)min((v1 + 0x8000u) >> 16, 255u);
+            o[2 * BL_P] = (uint8_t)min((v2 + 0x8000u) >> 16, 255u);
+            o[3 * BL_P] = (uint8_t)min((v3 + 0x8000u) >> 16, 255u);
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
