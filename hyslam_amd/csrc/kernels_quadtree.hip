@@ -29,6 +29,7 @@
 
 #define QT_T HS_QT_THREADS
 #define QT_M HS_QT_MAX_NODES
+#define QT_PTS 6144              // points kept in LDS (a 1080p level has ~5000 candidates); more fall back to the global arrays
 
 struct QtNodes {
     int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M];
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     __shared__ int16_t order_node[QT_M];           // rank -> node
     __shared__ uint16_t new_index[QT_M];           // surviving node -> index in the next list
     __shared__ uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
+    __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node, when there are <= QT_PTS of them:
+    __shared__ uint16_t s_pnode[QT_PTS];           // every pass walks the points twice, from LDS instead of through L2
     __shared__ int s_wave[QT_T / 64];
     __shared__ int s_misc[8];
 
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     int rank = 0;
                     for (int j = first; j < last; j++) rank += s_key[j] < key;
                     pxy[n + first + rank] = key; psk[n + first + rank] = sk;
+                    if (n + first + rank < QT_PTS) s_pxy[n + first + rank] = key;
                 }
                 __syncthreads();                                   // the scratch is reused by the next round
             } else {                                               // saturated image: more records than the scratch holds; one thread per cell
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     int rank = 0;
                     for (int j = 0; j < k; j++) rank += sxy[src + j] < key;
                     pxy[n + pre + rank] = key; psk[n + pre + rank] = ssk[src + i];
+                    if (n + pre + rank < QT_PTS) s_pxy[n + pre + rank] = key;
                 }
             }
             n += tot;
@@ -143,6 +148,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
+    const bool in_lds = n <= QT_PTS;               // uniform
+    auto ld_xy = [&](int p) -> uint32_t { return in_lds ? s_pxy[p] : pxy[p]; };
+    auto ld_node = [&](int p) -> int { return in_lds ? (int)s_pnode[p] : (int)pnode[p]; };
+    auto st_node = [&](int p, int v) { if (in_lds) s_pnode[p] = (uint16_t)v; else pnode[p] = (uint16_t)v; };
 
     const int nIni = L.n_ini;
     const float hX = L.hx;
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     for (int i = tid; i < nIni; i += QT_T) ccount[i] = 0;
     __syncthreads();
     for (int p = tid; p < n; p += QT_T) {
-        int x = pxy[p] & 0xFFFF;
+        int x = ld_xy(p) & 0xFFFF;
         int r = (int)((float)x / hX);               // vpIniNodes[kp.pt.x/hX]
         r = min(r, nIni - 1);
         atomicAdd(&ccount[r], 1u);
@@ -175,9 +184,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     }
     __syncthreads();
     for (int p = tid; p < n; p += QT_T) {
-        int x = pxy[p] & 0xFFFF;
+        int x = ld_xy(p) & 0xFFFF;
         int r = min((int)((float)x / hX), nIni - 1);
-        pnode[p] = new_index[r];
+        st_node(p, new_index[r]);
     }
     int S = s_misc[0];
     __syncthreads();
@@ -239,10 +248,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         for (int i = tid; i < 4 * E; i += QT_T) ccount[i] = 0;
         __syncthreads();
         for (int p = tid; p < n; p += QT_T) {
-            int nd = pnode[p];
+            int nd = ld_node(p);
             int r = proc_rank[nd];
             if (r >= 0) {
-                uint32_t xy = pxy[p];
+                uint32_t xy = ld_xy(p);
                 atomicAdd(&ccount[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)], 1u);
             }
         }
@@ -335,12 +344,12 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 
         // -- relabel the points
         for (int p = tid; p < n; p += QT_T) {
-            int nd = pnode[p];
+            int nd = ld_node(p);
             int r = proc_rank[nd];
             if (r >= 0 && r < P) {
-                uint32_t xy = pxy[p];
-                pnode[p] = child_index[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)];
-            } else pnode[p] = new_index[nd];
+                uint32_t xy = ld_xy(p);
+                st_node(p, child_index[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)]);
+            } else st_node(p, new_index[nd]);
         }
         __syncthreads();
         S = T + nsurv;
@@ -357,10 +366,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     for (int i = tid; i < S; i += QT_T) best[i] = 0ull;
     __syncthreads();
     for (int p = tid; p < n; p += QT_T) {
-        uint32_t xy = pxy[p], sk = psk[p];
+        uint32_t xy = ld_xy(p), sk = psk[p];
         unsigned long long order = ((unsigned long long)(sk & 0xFFFFFFu) << 32) | xy;          // (cell, y, x)
         unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
-        atomicMax(&best[pnode[p]], key);
+        atomicMax(&best[ld_node(p)], key);
     }
     __syncthreads();
     for (int i = tid; i < S; i += QT_T) {
