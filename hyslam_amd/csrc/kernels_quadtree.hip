@@ -31,7 +31,7 @@
 #define QT_M HS_QT_MAX_NODES
 #define QT_PTS 6144              // points kept in LDS (a 1080p level has ~5000 candidates); more fall back to the global arrays
 
-struct QtNodes {
+struct alignas(16) QtNodes {
     int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M];
     uint32_t cnt[QT_M];
 };
@@ -53,6 +53,21 @@ __device__ __forceinline__ int block_scan_excl(int v, int* s_wave /*[16]*/, int&
     return base + incl - v;
 }
 
+// atomicAdd(&arr[key], 1) for the lanes with `valid`, one atomic per DISTINCT key of the wave: with a handful of counters (the roots,
+// the first passes) thousands of points hit the same LDS address and plain atomics serialise
+__device__ __forceinline__ void wave_agg_inc(uint32_t* arr, int key, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k0 = __shfl(key, leader, 64);
+        const unsigned long long m = __ballot(valid && key == k0);
+        if (lane == leader) atomicAdd(&arr[k0], (uint32_t)__popcll(m));
+        todo &= ~m;
+    }
+}
+
 __device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
 {
     // DivideNode: halfX = ceil((UR.x-UL.x)/2); n1.UR.x = UL.x+halfX; n1.BR.y = UL.y+halfY
@@ -61,6 +76,13 @@ __device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
     return (x < mx ? 0 : 1) + (y < my ? 0 : 2);      // n1,n2,n3,n4
 }
 
+#ifdef HS_QT_PROFILE
+__device__ unsigned long long g_qt_prof[128];
+extern "C" void hs_debug_qt_profile(unsigned long long* out128) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_qt_prof), sizeof(unsigned long long) * 128); }
+#define QT_MARK(tag) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && qt_k < 126) { g_qt_prof[qt_k++] = __builtin_amdgcn_s_memtime(); g_qt_prof[qt_k++] = (tag); } } while (0)
+#else
+#define QT_MARK(tag)
+#endif
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
@@ -80,6 +102,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     __shared__ int s_misc[8];
 
     const int tid = threadIdx.x;
+#ifdef HS_QT_PROFILE
+    int qt_k = 0;
+#endif
+    QT_MARK(0);
     const int level = blockIdx.x, img = blockIdx.y;
     const HsLevel& L = lv[level];
     const int N = L.quota;
@@ -148,6 +174,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
+    QT_MARK(1);
     const bool in_lds = n <= QT_PTS;               // uniform
     auto ld_xy = [&](int p) -> uint32_t { return in_lds ? s_pxy[p] : pxy[p]; };
     auto ld_node = [&](int p) -> int { return in_lds ? (int)s_pnode[p] : (int)pnode[p]; };
@@ -164,7 +191,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         int x = ld_xy(p) & 0xFFFF;
         int r = (int)((float)x / hX);               // vpIniNodes[kp.pt.x/hX]
         r = min(r, nIni - 1);
-        atomicAdd(&ccount[r], 1u);
+        wave_agg_inc(ccount, r, true);
     }
     __syncthreads();
     int cur = 0;
@@ -191,6 +218,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     int S = s_misc[0];
     __syncthreads();
 
+    QT_MARK(2);
     // ---- main loop
     bool phase2 = false;     // uniform across the block
     int T_prev = 0;          // number of children created by the previous pass (they sit at list indices [0,T_prev))
@@ -230,7 +258,16 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 uint32_t ci = C.cnt[i];
                 if (ci > 1) {
                     int r = 0;
-                    for (int j = 0; j < T_prev; j++) {
+                    const uint4* c4 = reinterpret_cast<const uint4*>(C.cnt);          // four counts per LDS read
+                    int j = 0;
+                    for (; j + 4 <= T_prev; j += 4) {
+                        const uint4 q = c4[j >> 2];
+                        r += (q.x > 1) && (q.x > ci || (q.x == ci && j < i));
+                        r += (q.y > 1) && (q.y > ci || (q.y == ci && j + 1 < i));
+                        r += (q.z > 1) && (q.z > ci || (q.z == ci && j + 2 < i));
+                        r += (q.w > 1) && (q.w > ci || (q.w == ci && j + 3 < i));
+                    }
+                    for (; j < T_prev; j++) {
                         uint32_t cj = C.cnt[j];
                         r += (cj > 1) && (cj > ci || (cj == ci && j < i));
                     }
@@ -242,21 +279,41 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             E = tot;
         }
         __syncthreads();
+        QT_MARK(10 + (phase2 ? 100 : 0));
         if (E == 0) break;                          // nothing can be split: size == prevSize (:309,374)
 
         // -- count the four children of every candidate node
         for (int i = tid; i < 4 * E; i += QT_T) ccount[i] = 0;
         __syncthreads();
-        for (int p = tid; p < n; p += QT_T) {
-            int nd = ld_node(p);
-            int r = proc_rank[nd];
-            if (r >= 0) {
-                uint32_t xy = ld_xy(p);
-                atomicAdd(&ccount[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)], 1u);
+        if (in_lds) {
+            // all of a thread's points at once: independent LDS loads instead of one dependent chain per point
+            int nd[QT_PTS / QT_T], rk[QT_PTS / QT_T];
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; nd[k] = p < n ? (int)s_pnode[p] : 0; }
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; rk[k] = p < n ? (int)proc_rank[nd[k]] : -1; }
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) {
+                const int p = tid + k * QT_T;
+                const bool on = rk[k] >= 0;
+                const uint32_t xy = on ? s_pxy[p] : 0u;
+                const int key = on ? 4 * rk[k] + child_of(C, nd[k], xy & 0xFFFF, xy >> 16) : 0;
+                if (E <= 4) wave_agg_inc(ccount, key, on);           // <= 16 counters: aggregate per wave
+                else if (on) atomicAdd(&ccount[key], 1u);
+            }
+        } else {
+            for (int p = tid; p < n; p += QT_T) {
+                int nd = pnode[p];
+                int r = proc_rank[nd];
+                if (r >= 0) {
+                    uint32_t xy = pxy[p];
+                    atomicAdd(&ccount[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)], 1u);
+                }
             }
         }
         __syncthreads();
 
+        QT_MARK(11);
         // -- how many of them are actually split this pass
         int P = E;
         if (phase2) {
@@ -285,6 +342,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             P = s_misc[1];
         }
 
+        QT_MARK(12);
         // -- lay out the next list: children of processed nodes in reverse creation order, then survivors
         int T, nToExpand;
         {
@@ -342,16 +400,36 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         __syncthreads();
         if (T + nsurv > QT_M) { if (tid == 0) *out_n = 0; return; }     // cannot happen for quota+8 <= QT_M (host checks)
 
+        QT_MARK(13);
         // -- relabel the points
-        for (int p = tid; p < n; p += QT_T) {
-            int nd = ld_node(p);
-            int r = proc_rank[nd];
-            if (r >= 0 && r < P) {
-                uint32_t xy = ld_xy(p);
-                st_node(p, child_index[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)]);
-            } else st_node(p, new_index[nd]);
+        if (in_lds) {
+            int nd[QT_PTS / QT_T], rk[QT_PTS / QT_T];
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; nd[k] = p < n ? (int)s_pnode[p] : 0; }
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) rk[k] = proc_rank[nd[k]];
+#pragma unroll
+            for (int k = 0; k < QT_PTS / QT_T; k++) {
+                const int p = tid + k * QT_T;
+                if (p < n) {
+                    if (rk[k] >= 0 && rk[k] < P) {
+                        const uint32_t xy = s_pxy[p];
+                        s_pnode[p] = child_index[4 * rk[k] + child_of(C, nd[k], xy & 0xFFFF, xy >> 16)];
+                    } else s_pnode[p] = new_index[nd[k]];
+                }
+            }
+        } else {
+            for (int p = tid; p < n; p += QT_T) {
+                int nd = pnode[p];
+                int r = proc_rank[nd];
+                if (r >= 0 && r < P) {
+                    uint32_t xy = pxy[p];
+                    pnode[p] = child_index[4 * r + child_of(C, nd, xy & 0xFFFF, xy >> 16)];
+                } else pnode[p] = new_index[nd];
+            }
         }
         __syncthreads();
+        QT_MARK(14);
         S = T + nsurv;
         cur ^= 1;
         T_prev = T;
@@ -361,6 +439,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         if (!phase2 && (S + nToExpand * 3) > N) phase2 = true;
     }
 
+    QT_MARK(3);
     // ---- keep the best point of every node (:381-400), emit in list order
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ccount);      // QT_M * 8 bytes <= sizeof(ccount)
     for (int i = tid; i < S; i += QT_T) best[i] = 0ull;
@@ -383,6 +462,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
     }
     if (tid == 0) *out_n = min(S, L.sel_cap);
+    QT_MARK(4);
+#ifdef HS_QT_PROFILE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qt_prof[127] = qt_k;
+#endif
 }
 
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,

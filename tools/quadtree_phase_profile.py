@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Cycle stamps of the level-0 quadtree workgroup of image 0 (library built with `make -C hyslam_amd/csrc EXTRA=-DHS_QT_PROFILE`).
+Tags: 1 gather done, 2 roots done, 10/110 processing order chosen (phase 1 / phase 2), 11 children counted, 12 cut chosen,
+13 next list laid out, 14 points relabelled, 3 loop left, 4 selection written."""
+import ctypes as C, sys
+sys.path.insert(0, ".")
+import hyslam_amd as HS
+from hyslam_amd.synth import synth_stereo_pair
+L, R = synth_stereo_pair(1, 1920, 1080)
+ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000, fScaleFactor=1.2, nLevels=8))
+ex.extract_batch([L, R]); ex.extract_batch([L, R])
+out = (C.c_ulonglong * 128)()
+ex._lib.hs_debug_qt_profile(out)
+k = int(out[127]); t0 = out[0]
+prev = t0
+for i in range(0, k, 2):
+    print("tag %3d  +%7d  (total %7d)" % (out[i + 1], out[i] - prev, out[i] - t0)); prev = out[i]
