@@ -117,8 +117,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 
     // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list.
     // The FAST kernel fills a cell's slots in no particular order; the reference's list order (vToDistributeKeys) is cell by cell and,
-    // inside a cell, cv::FAST's row-major scan = ascending (y<<16 | x) = ascending cand_xy.  Up to QT_T cells per round:
-    //   A  one thread per cell: count, block-wide exclusive scan, and the cell id of each of its records into LDS
+    // inside a cell, cv::FAST's row-major scan = ascending (y<<16 | x) = ascending cand_xy.  Up to 4 * QT_T cells per round:
+    //   A  one thread per 4 cells: counts, block-wide exclusive scan, and the cell id of each of its records into LDS
     //   B  one thread per RECORD: key -> LDS;  then rank inside its cell by counting smaller keys (LDS reads), scatter to the dense list.
     // Record-parallel because the high pyramid levels have few cells with many records each (mean 20, up to 34 at level 7 of a 1080p
     // frame): a per-cell thread loop was k dependent global round trips long.  The node arrays are not live yet: their LDS is the scratch.
@@ -126,21 +126,27 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     {
         uint32_t* const s_key = reinterpret_cast<uint32_t*>(&nodes[0]);          // [QT_GKEYS]
         uint16_t* const s_cell = reinterpret_cast<uint16_t*>(ccount);            // [QT_GKEYS]
-        uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [QT_T] exclusive offset of the round's cell
+        uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [QT_T * CPT] exclusive offset of the round's cell
         constexpr int QT_GKEYS = (int)(sizeof(nodes) / 4) < (int)(sizeof(ccount) / 2) ? (int)(sizeof(nodes) / 4) : (int)(sizeof(ccount) / 2);
-        static_assert(sizeof(child_index) >= QT_T * 4, "s_pre scratch");
         const int ncell = L.ncols * L.nrows;
         const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
         const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
-        for (int c0 = 0; c0 < ncell; c0 += QT_T) {
-            const int c = c0 + tid;
-            const int k = c < ncell ? min(ccnt[c], ccap) : 0;
-            int tot; const int pre = block_scan_excl(k, s_wave, tot);
+        constexpr int CPT = 4;                                     // cells per thread and round: the counts of a round are independent loads
+        static_assert(sizeof(child_index) >= QT_T * CPT * 4, "s_pre scratch");
+        for (int c0 = 0; c0 < ncell; c0 += QT_T * CPT) {
+            int k[CPT], ksum = 0;
+#pragma unroll
+            for (int q = 0; q < CPT; q++) { const int c = c0 + tid * CPT + q; k[q] = c < ncell ? min(ccnt[c], ccap) : 0; ksum += k[q]; }
+            int tot; int pre = block_scan_excl(ksum, s_wave, tot);
             if (tot <= QT_GKEYS) {
-                s_pre[tid] = (uint32_t)pre;
-                for (int i = 0; i < k; i++) s_cell[pre + i] = (uint16_t)tid;
+#pragma unroll
+                for (int q = 0; q < CPT; q++) {
+                    s_pre[tid * CPT + q] = (uint32_t)pre;
+                    for (int i = 0; i < k[q]; i++) s_cell[pre + i] = (uint16_t)(tid * CPT + q);
+                    pre += k[q];
+                }
                 __syncthreads();
                 for (int e = tid; e < tot; e += QT_T) {
                     const int lc = s_cell[e];
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     const int lc = s_cell[e];
                     const int first = (int)s_pre[lc], i = e - first;
                     const uint32_t sk = ssk[(size_t)(c0 + lc) * ccap + i];           // in flight during the rank loop
-                    const int last = (lc + 1 < QT_T) ? (int)s_pre[lc + 1] : tot;     // cells past the last one have k = 0: s_pre = tot
+                    const int last = (lc + 1 < QT_T * CPT) ? (int)s_pre[lc + 1] : tot;   // cells past the last one have k = 0: s_pre = tot
                     const uint32_t key = s_key[e];
                     int rank = 0;
                     for (int j = first; j < last; j++) rank += s_key[j] < key;
@@ -160,13 +166,17 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 }
                 __syncthreads();                                   // the scratch is reused by the next round
             } else {                                               // saturated image: more records than the scratch holds; one thread per cell
-                const size_t src = (size_t)min(c, ncell - 1) * ccap;
-                for (int i = 0; i < k; i++) {
-                    const uint32_t key = sxy[src + i];
-                    int rank = 0;
-                    for (int j = 0; j < k; j++) rank += sxy[src + j] < key;
-                    pxy[n + pre + rank] = key; psk[n + pre + rank] = ssk[src + i];
-                    if (n + pre + rank < QT_PTS) s_pxy[n + pre + rank] = key;
+#pragma unroll
+                for (int q = 0; q < CPT; q++) {
+                    const size_t src = (size_t)min(c0 + tid * CPT + q, ncell - 1) * ccap;
+                    for (int i = 0; i < k[q]; i++) {
+                        const uint32_t key = sxy[src + i];
+                        int rank = 0;
+                        for (int j = 0; j < k[q]; j++) rank += sxy[src + j] < key;
+                        pxy[n + pre + rank] = key; psk[n + pre + rank] = ssk[src + i];
+                        if (n + pre + rank < QT_PTS) s_pxy[n + pre + rank] = key;
+                    }
+                    pre += k[q];
                 }
             }
             n += tot;
