@@ -125,6 +125,34 @@ def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
     stage_parity(synth_image(40 + w, w, h), nfeat, scale)
 
 
+def test_random_geometries(gpu):
+    """seeded sweep over frame sizes, scale factors, level counts, cell sizes and quotas (cell rows with a single-cell last group, levels
+    without cells, tiles of every height class, 4-level pyramids): full feature parity for each"""
+    rng = np.random.default_rng(20261003)
+    for case in range(24):
+        w, h = int(rng.integers(90, 900)), int(rng.integers(80, 600))
+        if w < h // 2 + 1:
+            w = h                                                 # aspect ratios below 0.5 are rejected (nIni == 0 in the reference)
+        scale = float(rng.choice([1.2, 1.25, 1.4, 1.7]))
+        levels = int(rng.choice([3, 5, 8]))
+        cells = int(rng.choice([16, 24, 30, 30, 37, 48]))
+        nfeat = int(rng.integers(100, 2500))
+        img = synth_image(1000 + case, w, h) if case % 5 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        p = oracle.default_params(nfeat, scale, levels)
+        p.cell_px = cells
+        st = settings(nfeat, scale, levels)
+        st.N_CELLS = cells
+        try:
+            ex = HS.ORBExtractor(st)
+            gk, gd = ex(img)
+        except HS.HsError as e:                                   # configurations the library rejects up front are fine; wrong bits are not
+            assert "not supported" in str(e) or "undefined" in str(e) or "collapses" in str(e), (case, w, h, scale, levels, cells, str(e))
+            continue
+        ok, od = oracle.extract(p, img)
+        assert len(gk) == len(ok), (case, w, h, scale, levels, cells, nfeat, len(gk), len(ok))
+        assert gk.tobytes() == ok.tobytes() and np.array_equal(gd, od), (case, w, h, scale, levels, cells, nfeat)
+
+
 def test_custom_blur_taps_and_large_cells(gpu):
     """non-default parameters: a 256-sum tap set and taps that overflow a byte (generic blur path), and N_CELLS = 40
     (cells wider than 37 px: the general FAST tile variant)."""
