@@ -9,21 +9,24 @@
 //   * score = max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1 over the 16 arcs of length 9.
 //
 // MI355X mapping (k_fast_rows).  The unit of work is a ROW GROUP: up to 8 horizontally adjacent cells of one cell row (<= 247 px of
-// interior), one single-wave workgroup per item, persistent launch.  With ~1 % corners a single 31x31 cell leaves a wave's lanes
-// mostly idle after the first pass and pays the per-cell bookkeeping 6342 times per frame; measured on 32 frames of 1080p the first
-// design (one wave per cell: 0.48 ms, ~1.26 issued instructions per pixel, issue-bound at ~1 instruction/cycle/CU) became 0.32 ms.
+// interior), one single-wave workgroup per item, persistent launch, 11 workgroups per CU (14 KB of LDS each).  With ~1 % corners a
+// single 31x31 cell leaves a wave's lanes mostly idle after the first pass and pays the per-cell bookkeeping 6342 times per frame;
+// measured on 32 frames of 1080p the first design (one wave per cell: 0.48 ms, ~1.26 issued instructions per pixel, issue-bound at
+// ~1 instruction/cycle/CU) became 0.24 ms.
 //   stage   the item's tile (interior + 3 px apron, <= 256 x 70 px) is fetched with 16-byte loads into registers while the PREVIOUS
 //           item is processed, then written to LDS; the only HBM traffic of the kernel is this one read of each level
 //   scan A  quick reject on the four compass points, 4 pixel columns x 8 rows per lane and block: 14 tile rows in registers, the
 //           horizontal ring pixels from the neighbouring lanes (DPP wave shifts), all compares as v_pk_*_u16 on two pixels at a time;
-//           the "maybe" pixels of a block go to an LDS list (wave prefix sum of popcounts)
-//   corners maybe pixels: 16-bit darker/brighter ring masks, 9 contiguous cyclic bits; corners are compacted in place and scored
-//           into a dense LDS score tile in which every cell owns its columns plus one zero separator column, so the 3x3 NMS
-//           needs no cell-boundary logic
-//   NMS     over the corner list (or, if the list overflowed and was flushed, over the non-zero bytes of the score tile);
-//           survivors take a slot of their cell with an LDS atomic.
-// The list has a fixed capacity; a scan flushes (runs the later passes on what it has) when a block would overflow it, so saturated
-// images stay correct and merely lose batching.  Work distribution, geometry table and LDS budget: see the kernel and its launcher.
+//           the "maybe" pixels of a block go to an LDS list as codes (wave prefix sum of popcounts, one short bit loop per lane)
+//   corners maybe pixels (decoded on dense lanes): 16-bit darker/brighter ring masks, 9 contiguous cyclic bits; corners are compacted
+//           in place and scored; position and score stay in the list
+//   tile    once every corner is scored the pixel tile is dead: its LDS is zeroed and becomes the dense score tile, in which every
+//           cell owns its columns plus one zero separator column, so the 3x3 NMS needs no cell-boundary logic
+//   NMS     over the corner list; survivors take a slot of their cell with an LDS atomic.
+// The list has a fixed capacity; when a block would overflow it the scan runs the corner passes on what it has and spills the scored
+// corners to a per-wave area in global memory; they come back into the score tile before the NMS, which then walks the non-zero
+// bytes of the tile instead of the list.  Saturated images stay correct and merely lose batching.  Work distribution, geometry table
+// and LDS budget: see the kernel and its launcher.
 // Output: each cell owns a fixed slot range (no global atomics), filled in NO particular order (the quadtree kernel orders a cell's
 // records by (y, x), which is cv::FAST's scan order, when it gathers them):
 //   cand_xy[cell slot] = y<<16 | x         (coordinates relative to (16,16), as in vToDistributeKeys)
