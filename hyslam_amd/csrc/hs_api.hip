@@ -117,7 +117,8 @@ int configure(hs_orb* h, int w, int hh, int batch)
         V.nrows = height > 0 ? (int)(height / W) : 0;
         if (V.ncols < 1 || V.nrows < 1) { V.ncols = V.nrows = 0; V.wcell = V.hcell = 0; }   // reference: division by zero (UB); no keypoints here
         else { V.wcell = (int)ceilf(width / V.ncols); V.hcell = (int)ceilf(height / V.nrows); }
-        if (V.wcell > HS_MAX_CELL || V.hcell > HS_MAX_CELL) return fail(h, HS_ERR_INVALID, "FAST cell larger than 64 px is not supported");
+        if (V.wcell > hs_fast_max_cell_w() || V.hcell > HS_MAX_CELL_H)
+            return fail(h, HS_ERR_INVALID, "FAST cell wider than 247 px or taller than 125 px is not supported");
         V.cell_begin = cells; cells += V.ncols * V.nrows;
         V.grp_cells = hs_fast_group_cells(V.wcell, V.ncols);
         V.ngroups = V.grp_cells > 0 ? (V.ncols + V.grp_cells - 1) / V.grp_cells : 0;

@@ -10,7 +10,7 @@
 #define HS_MAX_LEVELS 16
 #define HS_EDGE 19                 // EDGE_THRESHOLD, ORBExtractor.cpp:74
 #define HS_BORDER 16               // minBorderX = EDGE_THRESHOLD-3, ORBExtractor.cpp:413
-#define HS_MAX_CELL 64             // largest FAST cell interior edge the cell kernel's LDS tile holds
+#define HS_MAX_CELL_H 125           // tallest FAST cell (the FAST kernel's LDS tile holds hcell + 6 rows; list entries keep the row in 7 bits)
 #define HS_QT_MAX_NODES 2048       // quadtree list capacity in LDS (>= largest per-level quota + 8)
 #define HS_QT_THREADS 1024
 
@@ -114,6 +114,7 @@ struct HsOut {                     // extractor outputs, split the same way
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
 int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
+int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,

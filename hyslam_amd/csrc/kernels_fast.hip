@@ -489,12 +489,13 @@ static int fast_rows_lc()
     static int lc = [] { const char* e = getenv("HS_FAST_COLS"); return (e && atoi(e) == 32) ? 5 : 6; }();
     return lc;
 }
+int hs_fast_max_cell_w() { return 4 * (1 << fast_rows_lc()) - 9; }
 int hs_fast_group_cells(int wcell, int ncols)
 {
     if (wcell <= 0 || ncols <= 0) return 0;
     const int iw_max = 4 * (1 << fast_rows_lc()) - 9;
     int gmax = std::min(FR_MAXG, iw_max / wcell);
-    if (gmax < 1) gmax = 1;                                   // cannot happen: wcell <= HS_MAX_CELL = 64 < 119
+    if (gmax < 1) gmax = 1;                                   // cannot happen: configure() rejects wcell > hs_fast_max_cell_w()
     const int ngroups = (ncols + gmax - 1) / gmax;
     return (ncols + ngroups - 1) / ngroups;
 }
@@ -538,7 +539,7 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
     // LDS (the lists follow) and those rows are masked out.  Template instances below.
     const int th_max = max_hcell + 6;
-    c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : 70;
+    c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : th_max <= 70 ? 70 : th_max <= 102 ? 102 : 134;
     FastRowsLds& L = c.lds;
     L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
     if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the spill paths
@@ -574,8 +575,8 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     int force_scan_b = 0; if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) force_scan_b = atoi(e) != 0;   // parity tests: NMS from the score tile
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)
-    if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else FR_LAUNCH(6, 70); }
-    else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else FR_LAUNCH(5, 70); }
+    if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
+    else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
 }
 

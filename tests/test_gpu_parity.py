@@ -155,7 +155,7 @@ def test_random_geometries(gpu):
 
 def test_custom_blur_taps_and_large_cells(gpu):
     """non-default parameters: a 256-sum tap set and taps that overflow a byte (generic blur path), and N_CELLS = 40
-    (cells wider than 37 px: the general FAST tile variant)."""
+    (cells wider than 37 px: the general FAST tile variant), N_CELLS = 60 (cells up to 119 px: tall tiles)."""
     img = synth_image(77, 640, 480)
     for taps in ([16, 34, 50, 56, 50, 34, 16], [300, 20, 10, 5, 10, 20, 300]):
         p = oracle.default_params(800)
@@ -165,14 +165,15 @@ def test_custom_blur_taps_and_large_cells(gpu):
         ex = HS.ORBExtractor(settings(800), blur_taps=taps)
         gk, gd = ex(img)
         assert_same_features(gk, gd, ok, od)
-    p = oracle.default_params(800)
-    p.cell_px = 40
-    ok, od = oracle.extract(p, img)
-    s = settings(800)
-    s.N_CELLS = 40
-    gk, gd = HS.ORBExtractor(s)(img)
-    assert_same_features(gk, gd, ok, od)
-    s.N_CELLS = 300                                           # one cell wider than 64 px: rejected, never mis-computed
+    for cells in (40, 60):                                    # cells up to 2*N_CELLS-1 px: the taller FAST tile variants (up to 125 + 6 rows)
+        p = oracle.default_params(800)
+        p.cell_px = cells
+        ok, od = oracle.extract(p, img)
+        s = settings(800)
+        s.N_CELLS = cells
+        gk, gd = HS.ORBExtractor(s)(img)
+        assert_same_features(gk, gd, ok, od)
+    s.N_CELLS = 300                                           # one cell wider than 247 px: rejected, never mis-computed
     with pytest.raises(HS.HsError):
         HS.ORBExtractor(s)(img)
 
