@@ -72,4 +72,18 @@ s.synchronize()
 for i in range(B):
     okL, odL = oracle.extract(p, pairs[i][0])
     assert kL.view(B, cap * kb)[i].cpu().numpy().view(N.KP_DTYPE)[:int(nL[i])].tobytes() == okL.tobytes(), i
+# padded device buffers: a 16-byte aligned row stride with spare rows between images, and an odd stride (unaligned loads everywhere)
+ex.set_lanes(1)
+for S, extra in ((704, 3), (645, 1)):
+    buf = torch.zeros(B, H + extra, S, dtype=torch.uint8, device=dev)
+    buf[:, :H, :W] = left
+    kL.zero_(); nL.zero_()
+    ex.extract_batch_device(buf.data_ptr(), B, W, H, S, (H + extra) * S, kL.data_ptr(), dL.data_ptr(), nL.data_ptr(), cap, s.cuda_stream)
+    s.synchronize()
+    for i in range(B):
+        okL, odL = oracle.extract(p, pairs[i][0])
+        n_l = int(nL[i])
+        assert n_l == len(okL), (S, i, n_l, len(okL))
+        assert kL.view(B, cap * kb)[i].cpu().numpy().view(N.KP_DTYPE)[:n_l].tobytes() == okL.tobytes(), (S, i)
+        assert np.array_equal(dL.view(B, cap, 32)[i, :n_l].cpu().numpy(), odL), (S, i)
 print("device api ok")
