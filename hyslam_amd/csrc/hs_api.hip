@@ -202,7 +202,7 @@ int configure(hs_orb* h, int w, int hh, int batch)
         hs_fast_build_items(h->lv.data(), L, fi.data());
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell), 256)));
+        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch), 256)));
     }
     h->w = w; h->h = hh; h->batch_cap = batch;
     return HS_OK;

@@ -119,7 +119,7 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[su
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes()*/, hipStream_t s);
-size_t hs_fast_overflow_bytes(int max_hcell);      // per-wave spill areas of the FAST kernel (used only when an item's corner list overflows)
+size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,

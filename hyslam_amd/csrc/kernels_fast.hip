@@ -554,10 +554,17 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     c.ovf_stride = (uint32_t)((4 * cols - 9) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
     return c;
 }
-size_t hs_fast_overflow_bytes(int max_hcell)
+// workgroups of a launch over `total_work` items (non-decreasing in total_work)
+static int fast_rows_grid(const FastRowsCfg& c, int total_work)
+{
+    int nblk = 256 * c.per_cu;
+    while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD ranges)
+    return nblk;
+}
+size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max)
 {
     const FastRowsCfg c = fast_rows_cfg(max_hcell);
-    return (size_t)256 * c.per_cu * c.ovf_stride * 4;
+    return (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
 }
 
 static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
@@ -570,8 +577,7 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const int lc = c.lc, tr = c.tr;
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return;
-    int nblk = 256 * c.per_cu;
-    while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;
+    const int nblk = fast_rows_grid(c, total_work);
     int force_scan_b = 0; if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) force_scan_b = atoi(e) != 0;   // parity tests: NMS from the score tile
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)
