@@ -473,6 +473,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_T(t6);
         FR_ACC(7, t5, t6);
         fr_acc[8] += 1;
+        fr_acc[3] += n_ovf > 0;
 #endif
     }
 #ifdef HS_FAST_PROFILE
@@ -542,6 +543,7 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : th_max <= 70 ? 70 : th_max <= 102 ? 102 : 134;
     FastRowsLds& L = c.lds;
     L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
+    if (const char* e = getenv("HS_FAST_PCAP")) L.pcap = std::max(4 * cols, atoi(e) & ~15);   // tuning knob
     if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the spill paths
     int o = c.tr * pitch;                                     // pixel tile, later the score tile (rows 0..ih+1 <= th-4)
     L.off_plist = o; o += L.pcap * 2;

@@ -26,4 +26,5 @@ print("items %d waves %d, cycles per item (avg) / share of wave lifetime" % (ite
 for i in (0, 1, 2, 4, 5, 6, 7):
     print("%-40s %9.0f  %5.1f %%" % (names[i], v[i] / items, 100 * v[i] / v[9]))
 print("%-40s %9.0f" % ("wave lifetime per item", v[9] / items))
+print("items that spilled corners (list overflow): %d of %d" % (v[3], items))
 print("scan A row steps + expand (derived)      %9.0f  %5.1f %%" % ((v[2] - v[4] - v[5]) / items, 100 * (v[2] - v[4] - v[5]) / v[9]))
