@@ -545,16 +545,24 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     const int th_max = max_hcell + 6;
     c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : th_max <= 70 ? 70 : th_max <= 102 ? 102 : 134;
     FastRowsLds& L = c.lds;
-    L.pcap = 1024;                                            // >= 4*cols (one tile row of pixels)
+    // LDS is granted in 1280-byte granules on gfx950 (160 KB / 128): a workgroup of 13 216 bytes occupies 14 080, and a persistent grid
+    // sized for more workgroups per CU than really fit runs its surplus in a second round (measured: +25 % kernel time).  The list
+    // capacity takes whatever the last granule leaves.
+    constexpr int GRAN = 1280, LDS_CU = 160 * 1024;
+    const int fixed = c.tr * pitch + 4 * FR_MAXG;             // pixel tile (later the score tile: rows 0..ih+1 <= th-4) + per-cell counters
+    const int floor_bytes = std::max(fixed + 3 * 1024, (c.tr + 8) * pitch);   // >= 1024 list entries; the over-read of the last scan block stays inside
+    const int granules = (floor_bytes + GRAN - 1) / GRAN;
+    L.pcap = ((granules * GRAN - fixed) / 3) & ~15;           // 2 bytes position + 1 byte score per entry; >= 4*cols (one tile row of pixels)
     if (const char* e = getenv("HS_FAST_PCAP")) L.pcap = std::max(4 * cols, atoi(e) & ~15);   // tuning knob
     if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the spill paths
-    int o = c.tr * pitch;                                     // pixel tile, later the score tile (rows 0..ih+1 <= th-4)
+    int o = c.tr * pitch;
     L.off_plist = o; o += L.pcap * 2;
     L.off_pscore = o; o += L.pcap;
+    o = (o + 3) & ~3;
     L.off_cnt = o; o += 4 * FR_MAXG;
-    o = std::max(o, (c.tr + 8) * pitch);                      // the over-read of the last scan block stays inside the allocation
+    o = std::max(o, (c.tr + 8) * pitch);
     L.total = (o + 15) & ~15;
-    c.per_cu = std::max(1, std::min(16, (160 * 1024) / L.total));
+    c.per_cu = std::max(1, std::min(16, LDS_CU / ((L.total + GRAN - 1) / GRAN * GRAN)));
     if (const char* e = getenv("HS_FAST_WG_PER_CU")) c.per_cu = std::max(1, std::min(c.per_cu, atoi(e)));
     c.ovf_stride = (uint32_t)((4 * cols - 9) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
     return c;
