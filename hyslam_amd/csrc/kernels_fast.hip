@@ -274,14 +274,15 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         const uint32_t vmask8 = vmask * 0x5555u;                 // the same for the 8 rows of a scan block (row r at << 2r)
         int npx = 0;                                             // wave-uniform list length
-        int n_last_corner = 0, n_ovf = 0;                        // corners of the final corners_and_scores run (in the list); corners spilled by earlier runs
+        int n_done = 0, n_ovf = 0;                               // scored corners at the head of the list (entries [n_done, npx) are scan codes); corners spilled
 
         // ---- pixel list -> corners -> scores
-        auto corners_and_scores = [&](bool final) {
+        // ---- scan codes [n_done, npx) of the list -> corners -> scores; the scored corners stay at the head of the list
+        auto corners_and_scores = [&]() {
             FR_FENCE();
             FR_T(tc0);
-            int n_corner = 0;
-            for (int i0 = 0; i0 < npx; i0 += 64) {
+            int n_corner = n_done;
+            for (int i0 = n_done; i0 < npx; i0 += 64) {
                 const int i = i0 + tid;
                 const bool act = i < npx;
                 const int code = plist[act ? i : 0];
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             FR_FENCE();
             FR_T(tc1);
             FR_ACC(4, tc0, tc1);
-            for (int i = tid; i < n_corner; i += 64) {
+            for (int i = n_done + tid; i < n_corner; i += 64) {
                 const int pos = plist[i];
                 const bool bright = pos & 0x8000;
                 const int py = (pos >> 8) & 127, px = pos & 255;
@@ -326,13 +327,22 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const uint32_t sc_pos = (uint32_t)(((py + 1) << 8) | (1 + px + gc)), sc_val = (uint32_t)fast_corner_score(d) & 0xFFu;
                 plist[i] = (uint16_t)sc_pos;                     // score tile coordinates: what nms_and_emit reads
                 pscore[i] = (uint8_t)sc_val;
-                if (!final) ovf[n_ovf + i] = (sc_pos << 8) | sc_val;   // the list is about to be reused: spill (row, column, score)
             }
-            npx = 0;
-            if (final) n_last_corner = n_corner; else n_ovf += n_corner;
+            npx = n_done = n_corner;
             FR_FENCE();
             FR_T(tc2);
             FR_ACC(5, tc1, tc2);
+        };
+        // the list is full of scored corners (saturated image): spill them (row, column, score) to this wave's global area
+        auto spill_corners = [&]() {
+            for (int i = tid; i < n_done; i += 64) ovf[n_ovf + i] = ((uint32_t)plist[i] << 8) | pscore[i];
+            n_ovf += n_done;
+            npx = n_done = 0;
+        };
+        // make room for `need` more scan codes: score what is pending (corners are ~1/3 of the codes); spill only if that is not enough
+        auto make_room = [&](int need) {
+            corners_and_scores();
+            if (npx + need > lds.pcap) spill_corners();
         };
 
         // ---- pixel list (score tile coordinates) -> strict 3x3 NMS -> the cells' slots, in no particular order (the quadtree kernel
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             const int incl = wave_scan_incl((int)__popc(M));
             const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0) return;
-            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(false); }
+            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else make_room(min(total, lds.pcap)); }
             if (total <= lds.pcap) {
                 int pos = npx + incl - (int)__popc(M);
                 while (M) {
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x00030003u << (2 * r)));
                     const int incl_r = wave_scan_incl((int)__popc(Mr));
                     const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 4*COLS <= pcap
-                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else corners_and_scores(false); }
+                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else make_room(total_r); }
                     int pos = npx + incl_r - (int)__popc(Mr);
                     while (Mr) {
                         const int b = __ffs((int)Mr) - 1;
@@ -426,13 +436,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 }
                 emit_mask(M, y0, false, b);
             }
-            corners_and_scores(true);
+            corners_and_scores();
         }
         FR_T(t4);
         FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
         // ---- the pixel tile is dead: its LDS becomes the dense score tile (rows 0..ih+1, zero except at the corners)
         for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < n_last_corner; i += 64) {
+        for (int i = tid; i < n_done; i += 64) {
             const int pos = plist[i];
             score[(pos >> 8) * PITCH + (pos & 255)] = pscore[i];
         }
@@ -445,11 +455,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         // ---- NMS.  Usual case: every corner of the item is still in the list (score coordinates).
         if (n_ovf == 0 && !force_scan_b) {
-            npx = n_last_corner;
+            npx = n_done;
             nms_and_emit();
         } else {
             // ---- scan B (the list overflowed and corners were spilled): find the corners again as the non-zero bytes of the score tile
             FR_FENCE();
+            npx = 0;                                             // the list is scratch from here on (its corners are in the tile)
             const int nblock = (cur.ih + BR * RS - 1) / (BR * RS);
             for (int b = 0; b < nblock; b++) {
                 const int r0 = 1 + BR * (RS * b + sub);
