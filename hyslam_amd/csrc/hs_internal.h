@@ -91,6 +91,13 @@ template <typename T> __device__ __forceinline__ T hs_gload(const void* p) { ret
 // read-only tables at a wave-uniform address: the constant address space lets the compiler use scalar loads (SGPR result, no VALU/VMEM slot)
 #define HS_CONSTANT __attribute__((address_space(4)))
 template <typename T> __device__ __forceinline__ T hs_cload(const void* p) { return *(const HS_CONSTANT T*)(uintptr_t)p; }
+// element `idx` of a read-only int16 table (4-byte aligned base) at a wave-uniform index: there are no sub-dword scalar loads, so the
+// containing dword is fetched and the half picked with SALU (a plain int16 load would be a VECTOR load and put the value in a VGPR)
+__device__ __forceinline__ int hs_cload_i16(const int16_t* base, int idx)
+{
+    const uint32_t w = hs_cload<uint32_t>(reinterpret_cast<const uint8_t*>(base) + 4 * (size_t)(idx >> 1));
+    return (int)(int16_t)((idx & 1) ? (w >> 16) : (w & 0xFFFFu));
+}
 // a pointer the compiler must keep in SGPRs (so that `uniform base + 32-bit lane offset` becomes the saddr form of global_load)
 __device__ __forceinline__ const uint8_t* hs_uniform_ptr(const uint8_t* p)
 {

@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
 
     // source rectangle of this tile (wave-uniform)
     const int dy_last = min(dy_tile + LT_ROWS, D.h) - 1, dx_last = min(dx_tile + 256, D.w) - 1;
-    const int sy_first = min(max((int)hs_cload<int16_t>(D.yofs + dy_tile), 0), sh - 1);
-    const int sy_last = min(max((int)hs_cload<int16_t>(D.yofs + dy_last) + 1, 0), sh - 1);
-    const int col0 = hs_cload<int16_t>(&xt[dx_tile].sx) & ~15;
-    const int col_last = min(hs_cload<int16_t>(&xt[dx_last].sx) + 1, sw - 1);
+    const int sy_first = min(max(hs_cload_i16(D.yofs, dy_tile), 0), sh - 1);
+    const int sy_last = min(max(hs_cload_i16(D.yofs, dy_last) + 1, 0), sh - 1);
+    const int col0 = (int)(int16_t)hs_cload<uint32_t>(&xt[dx_tile]) & ~15;      // .sx = low half of the record's first dword
+    const int col_last = min((int)(int16_t)hs_cload<uint32_t>(&xt[dx_last]) + 1, sw - 1);
     const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch - 16, nrow <= lds_rows
     // ---- A: a wave takes whole source rows, floor(64 / nvec) at a time (no per-lane division by the runtime nvec)
     {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     for (int rr = 0; rr < LT_ROWS / 4; rr++) {
         const int dy = dy_tile + wave + 4 * rr;
         if (dy >= D.h) break;
-        const int sy = hs_cload<int16_t>(D.yofs + dy);
+        const int sy = hs_cload_i16(D.yofs, dy);
         const uint32_t b01 = hs_cload<uint32_t>(D.ibeta + 2 * dy);
         const uint32_t b0 = b01 & 0xFFFFu, b1 = b01 >> 16;
         const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
