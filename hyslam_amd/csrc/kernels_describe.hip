@@ -100,14 +100,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index: uniform, so everything derived from the
+    const int img = blockIdx.y;                                                                // keypoint record stays in SGPRs / scalar loads
     const int g = blockIdx.x * KP_PER_BLOCK + wv;          // keypoint index inside the image (levels concatenated)
 
     // locate the level: prefix over the per-level selection counts (wave-uniform scalar loop)
     int level = -1, first = 0, total = 0;
     for (int l = 0; l < nlevels; l++) {
-        int c = sel_count[img * nlevels + l];
+        int c = hs_cload<int32_t>(sel_count + img * nlevels + l);
         if (level < 0 && g < total + c) { level = l; first = total; }
         total += c;
     }
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
     const HsLevel& L = lv[level];
     const uint32_t* sel = sel_xys + ((size_t)img * sel_img_stride + L.sel_off + (g - first)) * 3;
-    const int cx = (int)sel[0], cy = (int)sel[1];
-    const int score = (int)sel[2];
+    const int cx = (int)hs_cload<uint32_t>(sel), cy = (int)hs_cload<uint32_t>(sel + 1);
+    const int score = (int)hs_cload<uint32_t>(sel + 2);
 
     const uint8_t* base; size_t pitch;
     if (level == 0) { base = hs_img0_ptr(img0, img); pitch = img0.row_stride; }
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
     uint8_t* raw = s_raw[wv]; uint16_t* hb = s_h[wv];
     uint8_t* bl = s_raw[wv];      // the blurred 37x37 tile reuses the raw tile's LDS: the raw bytes are dead once the row pass has run
-    uint32_t tp[7];
+    uint32_t tp[7];                                         // seven 16-bit taps in four dwords (the buffer holds 16 bytes): scalar loads
 #pragma unroll
-    for (int k = 0; k < 7; k++) tp[k] = taps7[k];
+    for (int k = 0; k < 7; k++) { const uint32_t w = hs_cload<uint32_t>(reinterpret_cast<const uint8_t*>(taps7) + 4 * (k >> 1)); tp[k] = (k & 1) ? (w >> 16) : (w & 0xFFFFu); }
 
     // ---- raw 43x43 neighbourhood.  Interior keypoints: aligned dword rows, the tile keeps the source misalignment `sh`.
     //      Patches that touch the level border: byte loads with BORDER_REFLECT_101.
