@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const h
                                                            int32_t* __restrict__ match_idx, float* __restrict__ match_dist)
 {
     const int lane = threadIdx.x & 63;
-    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int li = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave index: uniform
     if (li >= L) return;
     const hs_landmark& lm = lms[li];
     int out_idx = -1; float out_dist = -1.f;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ p
                                                    HsEpi epi, const hs_keypoint* __restrict__ kps1, const hs_keypoint* __restrict__ kps2,
                                                    float score_threshold, float ratio, int32_t* __restrict__ match12)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int a = pair_a[blockIdx.x], b = pair_b[blockIdx.x];
     const int p0 = ptr1[a], p1 = ptr1[a + 1], q0 = ptr2[b], q1 = ptr2[b + 1];
     for (int p = p0 + wv; p < p1; p += 4) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
                                               int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i >= nq) return;
     const unsigned long long* dq = reinterpret_cast<const unsigned long long*>(q + (size_t)i * 32);
     const unsigned long long a0 = dq[0], a1 = dq[1], a2 = dq[2], a3 = dq[3];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(1024) void k_search_init(HsFrameDev F2, const uint8
 {
     __shared__ unsigned long long s_best[16];
     __shared__ int s_second[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < F2.n; i += 1024) { owner[i] = -1; odist[i] = -1; }
     __syncthreads();
     const float invW = (float)GRID_COLS / (F2.max_x - F2.min_x), invH = (float)GRID_ROWS / (F2.max_y - F2.min_y);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict_
                                                       int cap, hs_stereo_params sp,
                                                       float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ best_dist)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the left keypoint's record comes through scalar loads
     const int pair = blockIdx.y;
     const int iL = blockIdx.x * 4 + wv;
     const int nL = min(nLs[pair], cap);
