@@ -229,6 +229,7 @@ int ensure_stereo_strips(hs_orb* h, int pairs, int cap, int n_rows)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     hipFree(h->d_strip_count); hipFree(h->d_strip_list); h->d_strip_count = nullptr; h->d_strip_list = nullptr;
     HIP_TRY(h, hipMalloc(&h->d_strip_count, (size_t)pairs * hs_stereo_strips(n_rows) * 4));
+    HIP_TRY(h, hipMemset(h->d_strip_count, 0, (size_t)pairs * hs_stereo_strips(n_rows) * 4));      // every call leaves the counters zero again
     HIP_TRY(h, hipMalloc(&h->d_strip_list, (size_t)pairs * hs_stereo_strips(n_rows) * cap * 2));
     h->strip_entries = need;
     return HS_OK;
@@ -294,7 +295,7 @@ void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32
     mark(h, 4, s);
     hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
     mark(h, 5, s);
-    hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, s);
+    hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, h->d_strip_count, sp.n_rows, s);
     mark(h, -1, s);
 }
 

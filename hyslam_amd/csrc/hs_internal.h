@@ -140,7 +140,8 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
                       int32_t* best_dist /*[pairs][cap] scratch*/,
                       int32_t* strip_count /*[pairs][strips]*/, uint16_t* strip_list /*[pairs][strips][cap]*/, hipStream_t s);
 inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
-void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s);
+void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist,
+                             int32_t* strip_count /*zero on entry of hs_launch_stereo; zeroed again here*/, int n_rows, hipStream_t s);
 
 // kernels_match.hip
 void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, hipStream_t s);

@@ -117,8 +117,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict_
 
 __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict__ nLs, int cap,
                                                        float* __restrict__ uRight, float* __restrict__ depth,
-                                                       const int32_t* __restrict__ best_dist)
+                                                       const int32_t* __restrict__ best_dist,
+                                                       int32_t* __restrict__ strip_count, int n_strips)
 {
+    // the pair's strip counters are dead now: leave them zero for the next call (saves a memset launch per call)
+    for (int i = threadIdx.x; i < n_strips; i += 256) strip_count[(size_t)blockIdx.x * n_strips + i] = 0;
     __shared__ int hist[257];
     __shared__ float s_th;
     const int pair = blockIdx.x;
@@ -159,14 +162,14 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
 {
     if (pairs <= 0 || cap <= 0) return;
     const int n_strips = hs_stereo_strips(sp.n_rows);
-    hipMemsetAsync(strip_count, 0, (size_t)pairs * n_strips * 4, s);
     hipLaunchKernelGGL(k_stereo_strips, dim3((cap + 255) / 256, pairs), dim3(256), 0, s, kpsR, nR, cap, sp.size_ref, sp.n_rows, n_strips, strip_count, strip_list);
     dim3 grid((cap + 3) / 4, pairs, 1);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, s, strip_count, strip_list, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
 }
 
-void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist, hipStream_t s)
+void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist,
+                             int32_t* strip_count, int n_rows, hipStream_t s)
 {
     if (pairs <= 0 || cap <= 0) return;
-    hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, nL, cap, uRight, depth, best_dist);
+    hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, nL, cap, uRight, depth, best_dist, strip_count, hs_stereo_strips(n_rows));
 }
