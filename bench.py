@@ -319,10 +319,10 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
 
 
 def measured_traffic(kernel, pairs_per_step, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_j_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_k_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled per the gfx950 calibration).  Counters cannot be read from
     inside this process, so the value is only reported when the profiled batch size matches; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
     try:
         t = json.load(open(path))
         k = {"fast_cells": "k_fast_rows", "pyramid": "k_resize_level_lds", "describe": "k_describe", "quadtree": "k_quadtree"}[kernel]
@@ -330,7 +330,7 @@ def measured_traffic(kernel, pairs_per_step, frames_per_launch):
         if t["pairs_per_step"] != pairs_per_step or e["frames_per_launch"] != frames_per_launch:
             return None, None
         mult = 7 if kernel == "pyramid" else 1          # the pyramid stage is 7 launches of k_resize_level; the file holds the per-launch mean
-        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_j_hbm_traffic.json"
+        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_k_hbm_traffic.json"
     except Exception:
         return None, None
 
