@@ -632,12 +632,12 @@ int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = F->n;
     const size_t nn = (size_t)std::max(n, 1);
-    int rc = scratch_begin(h, pad256(nn * sizeof(hs_keypoint)) + pad256(nn * 32) + 2 * pad256(nn * 4) + pad256(nn * 2) + pad256(nn * 4) +
+    int rc = scratch_begin(h, pad256(nn * sizeof(hs_keypoint)) + pad256(nn * 32) + 2 * pad256(nn * 4) + pad256(hs_frame_grid_bytes((int)nn)) + pad256(nn * 4) +
                               pad256((size_t)L * sizeof(hs_landmark)) + 3 * pad256((size_t)L * 4) + 256);
     if (rc != HS_OK) return rc;
     hipStream_t s = h->stream;
     hs_keypoint* d_kps = carve<hs_keypoint>(h, nn); uint8_t* d_desc = carve<uint8_t>(h, nn * 32);
-    float* d_uR = carve<float>(h, nn); int32_t* d_obs = carve<int32_t>(h, nn); int8_t* d_cell = carve<int8_t>(h, nn * 2);
+    float* d_uR = carve<float>(h, nn); int32_t* d_obs = carve<int32_t>(h, nn); int8_t* d_cell = carve<int8_t>(h, hs_frame_grid_bytes((int)nn));
     int32_t* d_winner = carve<int32_t>(h, nn);
     hs_landmark* d_lms = carve<hs_landmark>(h, L);
     int32_t* d_midx = carve<int32_t>(h, L); float* d_mdist = carve<float>(h, L); float* d_pangle = carve<float>(h, L);
@@ -649,7 +649,7 @@ int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark
         if (F->kp_lm_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, F->kp_lm_obs, (size_t)n * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(h, hipMemcpyAsync(d_lms, lms, (size_t)L * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
-    hs_launch_frame_grid(*F, d_kps, d_cell, s);
+    hs_launch_frame_grid(*F, d_kps, d_cell, true, s);
     hs_launch_search_projection(*F, d_kps, d_desc, F->uR ? d_uR : nullptr, F->kp_lm_obs ? d_obs : nullptr, d_cell, d_lms, L, *pp,
                                 d_midx, d_mdist, d_winner, d_pangle, d_nm, s);
     HIP_TRY(h, hipGetLastError());
@@ -671,12 +671,12 @@ int hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_l
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t nn = F->n;
     // scratch is per handle: a second call may only start after the first finished (same stream ordering is enough)
-    const size_t need = pad256(nn * 2) + pad256(nn * 4) + pad256((size_t)L * 4) + 4096;
+    const size_t need = pad256(hs_frame_grid_bytes((int)nn)) + pad256(nn * 4) + pad256((size_t)L * 4) + 4096;
     if (need > h->scratch_bytes) { int rc = scratch_begin(h, need); if (rc != HS_OK) return rc; }
     h->scratch_used = 0;
-    int8_t* d_cell = carve<int8_t>(h, nn * 2); int32_t* d_winner = carve<int32_t>(h, nn); float* d_pangle = carve<float>(h, L);
+    int8_t* d_cell = carve<int8_t>(h, hs_frame_grid_bytes((int)nn)); int32_t* d_winner = carve<int32_t>(h, nn); float* d_pangle = carve<float>(h, L);
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    hs_launch_frame_grid(*F, F->kps, d_cell, s);
+    hs_launch_frame_grid(*F, F->kps, d_cell, true, s);
     hs_launch_search_projection(*F, F->kps, F->desc, F->uR, F->kp_lm_obs, d_cell, d_lms, L, *pp, d_match_idx, d_match_dist, d_winner, d_pangle, d_n_matches, s);
     HIP_TRY(h, hipGetLastError());
     return HS_OK;
@@ -779,7 +779,7 @@ int hs_search_for_initialization(hs_orb* h, const hs_keypoint* kps1, const uint8
     HIP_TRY(h, hipMemcpyAsync(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(d_d2, F2->desc, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(d_prev, prev_matched_xy, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
-    hs_launch_frame_grid(*F2, d_k2, d_cell, s);
+    hs_launch_frame_grid(*F2, d_k2, d_cell, false, s);
     hs_launch_search_init(*F2, d_k2, d_d2, d_cell, d_k1, d_d1, n1, d_prev, (float)window, th_low, nnratio, d_owner, d_odist, d_ang, d_self, d_nm, s);
     HIP_TRY(h, hipGetLastError());
     std::vector<int32_t> owner(n2);

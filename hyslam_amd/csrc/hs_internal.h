@@ -144,7 +144,8 @@ void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRigh
                              int32_t* strip_count /*zero on entry of hs_launch_stereo; zeroed again here*/, int n_rows, hipStream_t s);
 
 // kernels_match.hip
-void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, hipStream_t s);
+size_t hs_frame_grid_bytes(int n);               // cells + cell lists of n keypoints
+void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell /*hs_frame_grid_bytes(n)*/, bool with_lists, hipStream_t s);
 void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const float* d_uR,
                                  const int32_t* d_obs, const int8_t* d_cell, const hs_landmark* d_lms, int L, const hs_proj_params& pp,
                                  int32_t* d_match_idx, float* d_match_dist, int32_t* d_winner, float* d_prev_angle_scratch,

@@ -31,6 +31,8 @@ struct HsFrameDev {            // hs_frame_view with device pointers
     int32_t n;
     const hs_keypoint* kps; const uint8_t* desc; const float* uR; const int32_t* kp_lm_obs;
     const int8_t* cell;        // [n][2] grid cell of each keypoint, -1 = outside
+    const int32_t* cell_start; // [GRID_ROWS*GRID_COLS + 1] first entry of cell cy*GRID_COLS + cx in cell_items (nullptr: no cell lists)
+    const uint16_t* cell_items;// [n] keypoint indices cell by cell
 };
 
 __global__ void k_frame_grid(HsFrameDev F, int8_t* __restrict__ cell)
@@ -43,6 +45,40 @@ __global__ void k_frame_grid(HsFrameDev F, int8_t* __restrict__ cell)
     bool ok = !(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS);
     cell[2 * i] = ok ? (int8_t)px : (int8_t)-1;
     cell[2 * i + 1] = ok ? (int8_t)py : (int8_t)-1;
+}
+
+// Cell lists of the frame grid (the reference's mGrid[col][row] vectors, Frame.cc:137-153), rows of cells contiguous: one workgroup
+// counts, scans and scatters.  The order inside a cell is arbitrary: the matcher's candidate key carries the keypoint index.
+__global__ __launch_bounds__(1024) void k_frame_grid_lists(int n, const int8_t* __restrict__ cell, int32_t* __restrict__ cell_start, uint16_t* __restrict__ cell_items)
+{
+    constexpr int NC = GRID_ROWS * GRID_COLS, PER = (NC + 1023) / 1024;
+    __shared__ uint32_t cnt[NC];
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < NC; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) { const int cx = cell[2 * i], cy = cell[2 * i + 1]; if (cx >= 0) atomicAdd(&cnt[cy * GRID_COLS + cx], 1u); }
+    __syncthreads();
+    uint32_t loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int c = tid * PER + k; loc[k] = c < NC ? cnt[c] : 0; sum += loc[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t x = s_wave[w]; if (w < (tid >> 6)) base += x; total += x; }
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int c = tid * PER + k; if (c < NC) { cell_start[c] = (int32_t)run; cnt[c] = run; run += loc[k]; } }
+    if (tid == 0) cell_start[NC] = (int32_t)total;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int cx = cell[2 * i], cy = cell[2 * i + 1];
+        if (cx >= 0) cell_items[atomicAdd(&cnt[cy * GRID_COLS + cx], 1u)] = (uint16_t)i;
+    }
 }
 
 // Frame::ProjectLandMark + Camera::Project.  uv = (u, v, ur); returns validity.
@@ -160,30 +196,43 @@ __global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const h
         const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(lm.desc);
         const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
         unsigned long long best = NO_KEY; int second = NO_DIST;
-        if (any) {
+        // candidates: the keypoints of the grid cells [minCX,maxCX] x [minCY,maxCY] (GetFeaturesInAreaNEW); a row of cells is one
+        // contiguous span of the cell lists.  Without lists (cell_start == nullptr) every keypoint is tested against the cell range.
+        auto consider = [&](int i, int cx, int cy) {
+            const hs_keypoint kp = F.kps[i];
+            if (!(fabsf(__fsub_rn(kp.x, u)) < r && fabsf(__fsub_rn(kp.y, v)) < r)) return;
+            if (pp.use_prev_matched && F.kp_lm_obs && F.kp_lm_obs[i] > 0) return;        // PreviouslyMatchedCriterionCore
+            if (!(kp.size > smin && kp.size < smax)) return;                              // FeatureSizeCriterionCore
+            if (stereo) { const float urv = F.uR[i]; if (!(fabsf(__fsub_rn(ur, urv)) < r && urv > 0.f)) return; }
+            if (pp.use_reprojection) {                                                      // ProjectionViewCriterion + KeyFrame::ReprojectionError
+                const float ex = __fsub_rn(u, kp.x), ey = __fsub_rn(v, kp.y);
+                const float urv = F.uR ? F.uR[i] : -1.f;
+                const float er = urv >= 0.0f ? __fsub_rn(ur, urv) : 0.0f;
+                const float err = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                const float sf = __fdiv_rn(kp.size, F.size_ref);
+                const float sigma = __fmul_rn(pp.sigma_ref, __fmul_rn(sf, sf));
+                const float stereo_factor = urv > 0.f ? 1.30f : 1.00f;
+                if (!(__fdiv_rn(err, sigma) < __fmul_rn(stereo_factor, pp.reproj_threshold))) return;
+            }
+            const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F.desc + (size_t)i * 32);
+            const int d = __popcll(l0 ^ dk[0]) + __popcll(l1 ^ dk[1]) + __popcll(l2 ^ dk[2]) + __popcll(l3 ^ dk[3]);
+            const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned)i;
+            if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+            else second = min(second, d);
+        };
+        if (any && F.cell_start) {
+            for (int cy = minCY; cy <= maxCY; cy++) {
+                const int a = hs_cload<int32_t>(F.cell_start + cy * GRID_COLS + minCX), b = hs_cload<int32_t>(F.cell_start + cy * GRID_COLS + maxCX + 1);
+                for (int t = a + lane; t < b; t += 64) {
+                    const int i = F.cell_items[t];
+                    consider(i, F.cell[2 * i], cy);
+                }
+            }
+        } else if (any) {
             for (int i = lane; i < F.n; i += 64) {
                 const int cx = F.cell[2 * i], cy = F.cell[2 * i + 1];
                 if (cx < minCX || cx > maxCX || cy < minCY || cy > maxCY) continue;           // also drops cx == -1
-                const hs_keypoint kp = F.kps[i];
-                if (!(fabsf(__fsub_rn(kp.x, u)) < r && fabsf(__fsub_rn(kp.y, v)) < r)) continue;
-                if (pp.use_prev_matched && F.kp_lm_obs && F.kp_lm_obs[i] > 0) continue;        // PreviouslyMatchedCriterionCore
-                if (!(kp.size > smin && kp.size < smax)) continue;                              // FeatureSizeCriterionCore
-                if (stereo) { const float urv = F.uR[i]; if (!(fabsf(__fsub_rn(ur, urv)) < r && urv > 0.f)) continue; }
-                if (pp.use_reprojection) {                                                      // ProjectionViewCriterion + KeyFrame::ReprojectionError
-                    const float ex = __fsub_rn(u, kp.x), ey = __fsub_rn(v, kp.y);
-                    const float urv = F.uR ? F.uR[i] : -1.f;
-                    const float er = urv >= 0.0f ? __fsub_rn(ur, urv) : 0.0f;
-                    const float err = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
-                    const float sf = __fdiv_rn(kp.size, F.size_ref);
-                    const float sigma = __fmul_rn(pp.sigma_ref, __fmul_rn(sf, sf));
-                    const float stereo_factor = urv > 0.f ? 1.30f : 1.00f;
-                    if (!(__fdiv_rn(err, sigma) < __fmul_rn(stereo_factor, pp.reproj_threshold))) continue;
-                }
-                const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F.desc + (size_t)i * 32);
-                const int d = __popcll(l0 ^ dk[0]) + __popcll(l1 ^ dk[1]) + __popcll(l2 ^ dk[2]) + __popcll(l3 ^ dk[3]);
-                const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)cx << 22) | ((unsigned long long)cy << 16) | (unsigned)i;
-                if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
-                else second = min(second, d);
+                consider(i, cx, cy);
             }
         }
         wave_best2(best, second);
@@ -346,11 +395,18 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
 }
 
 // ---------------------------------------------------------------- launchers (declared in hs_internal.h)
-void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, hipStream_t s)
+// d_cell: hs_frame_grid_bytes(n) bytes: [n][2] cells, then (with_lists) the cell lists read by hs_launch_search_projection
+size_t hs_frame_grid_bytes(int n) { return (((size_t)n * 2 + 15) & ~(size_t)15) + ((size_t)GRID_ROWS * GRID_COLS + 1) * 4 + (size_t)n * 2 + 16; }
+static int32_t* grid_lists_start(int8_t* d_cell, int n) { return reinterpret_cast<int32_t*>(d_cell + (((size_t)n * 2 + 15) & ~(size_t)15)); }
+void hs_launch_frame_grid(const hs_frame_view& F, const hs_keypoint* d_kps, int8_t* d_cell, bool with_lists, hipStream_t s)
 {
     if (F.n <= 0) return;
     HsFrameDev D{}; D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.n = F.n; D.kps = d_kps;
     hipLaunchKernelGGL(k_frame_grid, dim3((F.n + 255) / 256), dim3(256), 0, s, D, d_cell);
+    if (with_lists) {
+        int32_t* start = grid_lists_start(d_cell, F.n);
+        hipLaunchKernelGGL(k_frame_grid_lists, dim3(1), dim3(1024), 0, s, F.n, d_cell, start, reinterpret_cast<uint16_t*>(start + GRID_ROWS * GRID_COLS + 1));
+    }
 }
 
 void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const float* d_uR,
@@ -364,6 +420,10 @@ void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kp
     D.fx = F.fx; D.fy = F.fy; D.cx = F.cx; D.cy = F.cy; D.mbf = F.mbf; D.sensor = F.sensor;
     D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.size_ref = F.size_ref; D.n = F.n;
     D.kps = d_kps; D.desc = d_desc; D.uR = d_uR; D.kp_lm_obs = d_obs; D.cell = d_cell;
+    if (F.n > 0) {                                             // the cell lists follow the cells (hs_launch_frame_grid with_lists)
+        const int32_t* start = grid_lists_start(const_cast<int8_t*>(d_cell), F.n);
+        D.cell_start = start; D.cell_items = reinterpret_cast<const uint16_t*>(start + GRID_ROWS * GRID_COLS + 1);
+    }
     HsProjDev P; static_cast<hs_proj_params&>(P) = pp; P.cos_view_angle = cosf(pp.max_view_angle);
     hipLaunchKernelGGL(k_search_projection, dim3((L + 3) / 4), dim3(256), 0, s, D, d_lms, L, P, d_match_idx, d_match_dist);
     if (pp.first_wins) {
