@@ -306,14 +306,21 @@ __global__ __launch_bounds__(1024) void k_rotation_filter(int n, int32_t* __rest
     if (tid == 0) *n_out = total;
 }
 
-__global__ void k_count_matches(int n, const int32_t* __restrict__ match, int32_t* __restrict__ n_out)
+__global__ __launch_bounds__(1024) void k_count_matches(int n, const int32_t* __restrict__ match, int32_t* __restrict__ n_out)
 {
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     int c = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) c += match[i] >= 0;
-    atomicAdd(&total, c);
+    // 16-byte loads, several in flight per thread (one workgroup: the count is a 200 KB read for 50 k landmarks)
+    const int n4 = ((reinterpret_cast<uintptr_t>(match) & 15) == 0) ? (n >> 2) : 0;
+    const int4* m4 = reinterpret_cast<const int4*>(match);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 1024) { const int4 v = m4[i]; c += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0); }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 1024) c += match[i] >= 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
     __syncthreads();
     if (threadIdx.x == 0) *n_out = total;
 }
