@@ -171,9 +171,11 @@ def main():
         stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items()}
         # dominant kernel among those with an HBM-byte model (the quadtree is a latency-bound LDS kernel: a host stage in the reference,
         # no compulsory HBM bytes in SURVEY.md's accounting; its time is still listed in stage_ms_per_step)
-        dom = max(("pyramid", "fast_cells", "describe"), key=lambda s: stage_ms[s])
-        dom_bytes = per_stage[dom] * frames_per_launch
-        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        launches = {"pyramid": max(ex.GetLevels() - 1, 1), "fast_cells": 1, "describe": 1}   # the pyramid stage is one launch of k_resize_level per level
+        launch_ms = {s: stage_ms[s] / launches[s] for s in launches}
+        dom = max(launches, key=lambda s: launch_ms[s])             # the kernel with the longest launch
+        dom_bytes = per_stage[dom] * frames_per_launch / launches[dom]
+        achieved = dom_bytes / (launch_ms[dom] * 1e-3) / 1e9 if launch_ms[dom] > 0 else 0.0
         pair_bytes = 2 * per_frame
         traffic, traffic_src = measured_traffic(dom, B, frames_per_launch)
         out = {
@@ -188,7 +190,7 @@ def main():
                        "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(stage_ms[dom], 5),
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(launch_ms[dom], 5),
                          "frames_per_launch": frames_per_launch},
             "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
             "end_to_end": {"algorithmic_bytes_per_pair": int(pair_bytes),
@@ -329,8 +331,7 @@ def measured_traffic(kernel, pairs_per_step, frames_per_launch):
         e = t["kernels"][k]
         if t["pairs_per_step"] != pairs_per_step or e["frames_per_launch"] != frames_per_launch:
             return None, None
-        mult = 7 if kernel == "pyramid" else 1          # the pyramid stage is 7 launches of k_resize_level; the file holds the per-launch mean
-        return int((e["read_MB"] + e["written_MB"]) * 1e6 * mult), "profiles/r01_k_hbm_traffic.json"
+        return int((e["read_MB"] + e["written_MB"]) * 1e6), "profiles/r01_k_hbm_traffic.json"
     except Exception:
         return None, None
 
