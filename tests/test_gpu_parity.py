@@ -117,11 +117,12 @@ def test_stereo_golden_and_identical_views(gpu):
 
 
 @pytest.mark.parametrize("w,h,nfeat,scale", [(643, 481, 700, 1.2), (320, 200, 500, 1.2), (800, 600, 1500, 1.4), (1024, 400, 6000, 1.2),
-                                              (97, 83, 300, 1.2), (2562, 1441, 3000, 1.2), (3840, 2160, 3000, 1.2), (4096, 64, 500, 1.2)])
+                                              (97, 83, 300, 1.2), (2562, 1441, 3000, 1.2), (3840, 2160, 3000, 1.2), (4000, 3000, 3000, 1.4),
+                                              (4096, 64, 500, 1.2)])
 def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
     """odd widths (byte-wise tile loads at level 0), levels too small for a FAST cell, the 1.4 'Imaging' profile,
     a wide frame with three root nodes and a quota above 1300, frames with ~3900 and ~8800 cells at level 0 (one and several gather rounds in the
-    quadtree kernel), a 64:1 strip (127 root nodes, capacity beyond the generic bound)."""
+    quadtree kernel), the 4000x3000 documentation camera of BASELINE config 4 with the reference's 'Imaging' settings (3000 features, 1.4), a 64:1 strip (127 root nodes, capacity beyond the generic bound)."""
     stage_parity(synth_image(40 + w, w, h), nfeat, scale)
 
 
