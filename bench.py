@@ -5,15 +5,22 @@ A *step* is one pass of the hot path (pyramid -> FAST/NMS cells -> quadtree dist
 left and right frames, then the stereo matcher) over one batch of `--pairs` synthetic stereo pairs that are already
 resident in HBM.  One process per GPU; frames shard across ranks with no data-path collective (weak scaling).
 
+  python bench.py                      N = 1
+  python bench.py --gpus N             spawns N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1) when it was not
+                                       started by torch.distributed.run; under torchrun it uses the environment it is given and insists
+                                       that WORLD_SIZE == --gpus
 Prints ONE JSON line on rank 0:
-  value     whole-job stereo pairs per second (all ranks)
-  roofline  the dominant kernel of the step: algorithmic bytes per launch / its HIP-event-measured duration vs 8 TB/s
-  cpu_baseline  the oracle ("port" of the reference's CPU path, left||right on 2 threads) timed on this box, N=1 only
+  value         whole-job stereo pairs per second (all ranks)
+  roofline      the dominant kernel of the step: algorithmic bytes per launch / its HIP-event-measured duration vs 8 TB/s, the PMC traffic
+                and the VALU issue fraction of the same launch shape from the committed counter passes
+  cpu_baseline  the oracle ("port" of the reference's CPU path) timed on this box, N = 1 only: 2 threads (the reference's structure) and all cores
+Other BASELINE configurations: --config c3 | c4 | c5.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,9 +30,92 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md); issue-rate fractions are quoted against it
 W, H, NFEAT = 1920, 1080, 2000
+PROFILE_TAG = "r02"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
+    ap.add_argument("--distinct", type=int, default=4,
+                    help="distinct synthetic pairs generated per rank; the batch holds --pairs separate copies (pair i = distinct pair i %% distinct), "
+                         "so no two frames of a step share an address")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH of the two CPU baseline samples (0 = skip)")
+    ap.add_argument("--handles", type=int, default=2,
+                    help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
+                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32)")
+    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
+                    help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="c2 = stereo extract+match (the headline metric); c3 = batched 64 mono frames, extract only (per-kernel GB/s); "
+                         "c4 = dual camera (stereo pair + 4000x3000 'Imaging' frame) + 50k-landmark projection search; "
+                         "c5 = one mono stream per GPU + all-gather + cross-camera match")
+    ap.add_argument("--c5-match", choices=["knn2", "bow"], default="knn2", help="c5: brute-force 2-NN or vocabulary-grouped (BoW) matching against every peer")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: ranks rendezvous over gloo, exchange one tensor and rank 0 prints a JSON line (covers the --gpus spawn path on CPU)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 without torchrun: spawn the ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """Parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): starts one child per GPU and relays rank 0's JSON
+    line.  The parent never touches the GPU (no torch import, no HIP call), so starting children is safe on this pool."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+        rc = rc or p.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc:
+        sys.stderr.write("bench.py: a rank failed (exit codes %s)\n" % [p.returncode for p in procs])
+    return 1 if rc else 0
+
+
+def dry_run(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert int(t.item()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "stereo_pairs/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ accounting
 def pyramid_pixels(ex, w, h):
     inv = ex.GetInverseScaleFactors()
     sizes = [(int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))) for s in inv]
@@ -39,52 +129,107 @@ def algorithmic_bytes(px, k):
         "pyramid": (P - p7) + (P - p0),          # each level read once to make the next + levels 1.. written
         "fast_cells": P,                         # FAST reads every level once
         "quadtree": 0,                           # host stage in the reference; candidate lists only
-        "describe": 2 * P + k * 1369 + k * 60,   # blur read+write, 37x37 window per keypoint, record out
+        "describe": 2 * P + k * 1369 + k * 60,   # the reference's full-level blur (read + write) + 37x37 window per keypoint + record out
     }
     return per_stage, sum(per_stage.values())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--handles", type=int, default=2,
-                    help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
-                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  Two independent launch sequences overlap one "
-                         "sequence's latency-bound kernels (quadtree, stereo, small pyramid levels) with the other's issue-bound ones: +10 %")
-    ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
-                    help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
-    ap.add_argument("--config", choices=["c2", "c3", "c5"], default="c2",
-                    help="c2 = stereo extract+match (the headline metric); c3 = batched 64 mono frames, extract only (per-kernel GB/s); "
-                         "c5 = one mono stream per GPU + all-gather + cross-camera 2-NN")
-    args = ap.parse_args()
+KERNEL_OF_STAGE = {"fast_cells": "k_fast_rows", "pyramid": "k_resize", "describe": "k_describe", "quadtree": "k_quadtree"}
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+def committed_counters(stage, pairs_per_step, frames_per_launch):
+    """Per-launch HBM traffic and VALU wave-instructions of `stage`'s kernel from the committed rocprofv3 counter passes of THIS workload
+    (profiles/<tag>_hbm_traffic.json: --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 calibration;
+    profiles/<tag>_sq_counters.json: --pmc SQ_INSTS_VALU ...).  Counters cannot be read from inside this process, so values are only
+    reported when the profiled launch shape matches; otherwise null."""
+    traffic = valu = None
+    src = []
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")))
+        if t["pairs_per_step"] == pairs_per_step:
+            for k, e in t["kernels"].items():
+                if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch:
+                    traffic = int((e["read_MB"] + e["written_MB"]) * 1e6 * e.get("launches_per_stage", 1))
+                    src.append("profiles/%s_hbm_traffic.json" % PROFILE_TAG)
+    except Exception:
+        pass
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.json")))
+        if t["pairs_per_step"] == pairs_per_step:
+            for k, e in t["kernels"].items():
+                if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch:
+                    valu = float(e["SQ_INSTS_VALU"]) * e.get("launches_per_stage", 1)
+                    src.append("profiles/%s_sq_counters.json" % PROFILE_TAG)
+    except Exception:
+        pass
+    return traffic, valu, src
+
+
+def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches, pairs_per_step, moved_bytes=None):
+    """roofline of one stage (= `launches` kernel launches): algorithmic bytes / HIP-event time against the HBM peak, the measured traffic, and
+    the VALU issue fraction = VALU wave-instructions / (256 CUs x cycles of the launch at 2.4 GHz) — every big kernel of this path is bound
+    by instruction issue, not by HBM, so that is the axis that explains the time."""
+    ms = stage_ms[stage]
+    algo = per_stage_bytes[stage] * frames_per_launch
+    achieved = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, valu, src = committed_counters(stage, pairs_per_step, frames_per_launch)
+    rl = {"bound": "hbm", "kernel": stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "counter_source": src or None,
+          "algorithmic_bytes_per_launch": int(algo / launches), "launch_ms": round(ms / launches, 5), "launches_per_step_and_handle": launches,
+          "frames_per_launch": frames_per_launch}
+    if moved_bytes is not None:       # describe: the kernel does not move the reference's full-level blur; GB/s on the bytes it requests
+        rl["moved_bytes_per_launch"] = int(moved_bytes * frames_per_launch)
+        rl["achieved_on_moved_bytes"] = round(moved_bytes * frames_per_launch / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0
+    if valu is not None and ms > 0:
+        per_cu_cycle = valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9)
+        rl["valu_insts_per_launch"] = int(valu / launches)
+        rl["valu_issue_frac"] = round(per_cu_cycle, 4)       # of 1 VALU wave-instruction per cycle and CU
+    return rl
+
+
+def fence_fn(torch, dist, world):
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    return fence
+
+
+def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    if begin:
+        begin()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if end:
+        end()
+    fence()
+    if begin:
+        begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    prof = end() if end else None
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    return float(elapsed.item()), prof
 
-    import hyslam_amd as HS
-    from hyslam_amd import _native as N
+
+def base_line(metric, value, unit, args, world, elapsed):
+    return {"metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic"}
+
+
+# ------------------------------------------------------------------------------------------------ C2 (headline)
+def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     from hyslam_amd.synth import synth_stereo_pair
-
-    if args.config == "c5":
-        return run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N)
-    if args.config == "c3":
-        return run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N)
-
-    # ---- synthetic input, resident in HBM before the timed region
+    from hyslam_amd.distributed import shard_range
     B = args.pairs
     nd = max(1, min(args.distinct, B))
     pairs = [synth_stereo_pair(1000 + 97 * rank + i, W, H) for i in range(nd)]
@@ -105,7 +250,6 @@ def main():
     nR = torch.zeros(B, dtype=torch.int32, device=dev)
     uR = torch.empty(B * cap, dtype=torch.float32, device=dev)
     depth = torch.empty_like(uR)
-    from hyslam_amd.distributed import shard_range
     parts = [shard_range(B, i, nh) for i in range(nh)]          # contiguous blocks of pairs per handle
     lanes = args.lanes if min(b - a for a, b in parts) >= 2 else 1
     for e, (a, b) in zip(exs, parts):
@@ -132,85 +276,47 @@ def main():
                 tot[k] = (m0 + ms, c0 + c)
         return tot
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    profile_begin()             # warm-up also pre-creates part of the event pool
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    profile_end()
-
-    fence()
-    profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    prof = profile_end()
-
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    total_pairs = world * B * args.steps
-    value = total_pairs / elapsed
-
+    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, profile_begin, profile_end)
+    value = world * B * args.steps / elapsed
     n_left = nL.cpu().numpy()
     n_match = int((depth.view(B, cap)[0] > 0).sum().item())
-
-    out = None
-    if rank == 0:
-        px = pyramid_pixels(ex, W, H)
-        per_stage, per_frame = algorithmic_bytes(px, NFEAT)
-        frames_per_launch = 2 * max(b - a for a, b in parts) // lanes     # every launch sequence covers its own share of the pairs
-        stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items()}
-        # dominant kernel among those with an HBM-byte model (the quadtree is a latency-bound LDS kernel: a host stage in the reference,
-        # no compulsory HBM bytes in SURVEY.md's accounting; its time is still listed in stage_ms_per_step)
-        launches = {"pyramid": max(ex.GetLevels() - 1, 1), "fast_cells": 1, "describe": 1}   # the pyramid stage is one launch of k_resize_level per level
-        launch_ms = {s: stage_ms[s] / launches[s] for s in launches}
-        dom = max(launches, key=lambda s: launch_ms[s])             # the kernel with the longest launch
-        dom_bytes = per_stage[dom] * frames_per_launch / launches[dom]
-        achieved = dom_bytes / (launch_ms[dom] * 1e-3) / 1e9 if launch_ms[dom] > 0 else 0.0
-        pair_bytes = 2 * per_frame
-        traffic, traffic_src = measured_traffic(dom, B, frames_per_launch)
-        out = {
-            "metric": "stereo frames/sec ORB extract+match, 1920x1080 @2000 feat",
-            "value": round(value, 2), "unit": "stereo_pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2: 1920x1080 stereo pair, 2000 features/frame, 8 levels @1.2, extract L+R + stereo match",
-                       "pairs_per_step_per_gpu": B, "handles": nh, "lanes_per_handle": lanes, "distinct_pairs": nd, "sharding": "frames round-robin, no collective",
-                       "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(launch_ms[dom], 5),
-                         "frames_per_launch": frames_per_launch},
-            "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
-            "end_to_end": {"algorithmic_bytes_per_pair": int(pair_bytes),
-                           "achieved_GBps": round(value / world * pair_bytes / 1e9, 2),
-                           "frac_of_hbm_peak": round(value / world * pair_bytes / 1e9 / HBM_PEAK_GBS, 5)},
-        }
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return
+    px = pyramid_pixels(ex, W, H)
+    per_stage, per_frame = algorithmic_bytes(px, NFEAT)
+    frames_per_launch = 2 * max(b - a for a, b in parts) // lanes     # every launch sequence covers its own share of the pairs
+    stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items()}   # per stage invocation (one launch sequence)
+    # dominant kernel among those with an HBM-byte model, by single-launch duration (the quadtree is an LDS kernel: a host stage in the
+    # reference with no compulsory HBM bytes in SURVEY.md's accounting; its time is still listed in stage_ms_per_step)
+    launches = {"pyramid": ex.pyramid_launches(), "fast_cells": 1, "describe": 1}
+    dom = max(launches, key=lambda s: stage_ms[s] / launches[s])
+    moved = {"describe": NFEAT * (43 * 48 + 60)}                     # what k_describe requests: 43 rows x 48 B per keypoint + the record
+    rls = {s: roofline_block(s, stage_ms, per_stage, frames_per_launch, launches[s], B, moved.get(s)) for s in launches}
+    out = base_line("stereo frames/sec ORB extract+match, 1920x1080 @2000 feat", value, "stereo_pairs/s", args, world, elapsed)
+    out["config"] = {"workload": "C2: 1920x1080 stereo pair, 2000 features/frame, 8 levels @1.2, extract L+R + stereo match",
+                     "pairs_per_step_per_gpu": B, "handles": nh, "lanes_per_handle": lanes,
+                     "distinct_pairs": "%d distinct synthetic pairs per rank; the %d pairs of a step are separate copies in HBM (pair i = distinct pair i %% %d): "
+                                       "no address reuse inside a step, every step re-reads the same %d MB of frames" % (nd, B, nd, 2 * B * W * H // 1000000),
+                     "sharding": "pairs sharded over ranks, no collective",
+                     "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match}
+    out["roofline"] = rls[dom]
+    out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
+    out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
+    pair_bytes = 2 * per_frame
+    out["end_to_end"] = {"algorithmic_bytes_per_pair": int(pair_bytes), "achieved_GBps": round(value / world * pair_bytes / 1e9, 2),
+                         "frac_of_hbm_peak": round(value / world * pair_bytes / 1e9 / HBM_PEAK_GBS, 5),
+                         "note": "algorithmic bytes include the reference's full-level blur (2P per frame) that k_describe does not move"}
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ C3
 def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
-    """BASELINE config 3: 64 synthetic 1920x1080 mono frames per step (seeds 100..163, 8 distinct tiled), extract only; per-kernel
-    achieved GB/s of algorithmic bytes (the 'HBM roofline run')."""
+    """BASELINE config 3: 64 synthetic 1920x1080 mono frames per step (8 distinct tiled), extract only; per-kernel achieved GB/s of
+    algorithmic bytes (the 'HBM roofline run')."""
     from hyslam_amd.synth import synth_image
-    B = 64
-    nd = 8
+    B, nd = 64, 8
     imgs = [synth_image(100 + 64 * rank + i, W, H) for i in range(nd)]
     frames = torch.from_numpy(np.stack([imgs[i % nd] for i in range(B)])).to(dev)
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
@@ -223,122 +329,184 @@ def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
     def step():
         ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, 0)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, ex.profile_begin, ex.profile_end)
+    if rank != 0:
+        return
+    per_stage, per_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
+    stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items() if c}
+    gbs = {s: round(per_stage[s] * B / (stage_ms[s] * 1e-3) / 1e9, 1) for s in ("pyramid", "fast_cells", "describe") if s in stage_ms}
+    value = world * B * args.steps / elapsed
+    out = base_line("mono frames/sec ORB extract, 1920x1080 @2000 feat, batch 64", value, "frames/s", args, world, elapsed)
+    out["config"] = {"workload": "C3: 64 x 1920x1080 mono frames per step, 2000 features, extract only", "distinct_frames": nd,
+                     "keypoints_frame0": int(n[0].item())}
+    out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
+    out["per_kernel_algorithmic_GBps"] = gbs
+    out["end_to_end"] = {"algorithmic_bytes_per_frame": int(per_frame), "achieved_GBps": round(value / world * per_frame / 1e9, 1),
+                         "frac_of_hbm_peak": round(value / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)}
+    print(json.dumps(out), flush=True)
 
-    ex.profile_begin()
-    for _ in range(args.warmup):
-        step()
+
+# ------------------------------------------------------------------------------------------------ C4
+def run_c4(args, rank, world, local_rank, dev, torch, dist, HS, N):
+    """BASELINE config 4: dual-camera stream + tracking search.  Per step: one 1920x1080 stereo pair (extract L+R + stereo match), one
+    4000x3000 documentation-camera frame with the reference's 'Imaging' settings (3000 features, scale 1.4; config/slam_feature_config.yaml:22-29)
+    on a second handle / stream, and SearchByProjection (local-map variant, th = 5, nnratio 0.8; slam_tracking_config.yaml:101-103) of a
+    50 000-landmark local map against the stereo frame's OWN device-resident outputs (hs_search_by_projection_device).  Harness mirrored:
+    ImageProcessing::ProcessStereoImage / ProcessMonoImage (src/main/ImageProcessing.cpp:41-116) + TrackLocalMap (TrackLocalMap.cpp:55-78)."""
+    import ctypes as C
+    from hyslam_amd.synth import synth_image, synth_stereo_pair, synth_local_map
+    IW, IH, IFEAT, L = 4000, 3000, 3000, 50000
+    Limg, Rimg = synth_stereo_pair(2 + 31 * rank, W, H)
+    left, right = torch.from_numpy(Limg).to(dev), torch.from_numpy(Rimg).to(dev)
+    big = torch.from_numpy(synth_image(3 + 31 * rank, IW, IH)).to(dev)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+    exi = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=IFEAT, fScaleFactor=1.4), device=local_rank)
+    ex.reserve(W, H, 2)
+    exi.reserve(IW, IH, 1)
+    cap, icap = ex.max_keypoints(), exi.max_keypoints()
+    kb = N.KP_DTYPE.itemsize
+    mk = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device=dev)
+    kL, kR, dL, dR, nL, nR = mk(cap * kb), mk(cap * kb), mk(cap * 32), mk(cap * 32), mk(1, torch.int32), mk(1, torch.int32)
+    uR, depth = mk(cap, torch.float32), mk(cap, torch.float32)
+    ik, idesc, inn = mk(icap * kb), mk(icap * 32), mk(1, torch.int32)
+    fx = 1050.0
+    sp = HS.stereo_params(HS.Camera(fx=fx, mbf=fx * 0.12, mnMaxY=float(H)))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def frontend():
+        ex.stereo_frontend_batch_device(left.data_ptr(), right.data_ptr(), 1, W, H, W, W * H, kL.data_ptr(), dL.data_ptr(), nL.data_ptr(),
+                                        kR.data_ptr(), dR.data_ptr(), nR.data_ptr(), cap, sp, uR.data_ptr(), depth.data_ptr(), s1.cuda_stream)
+
+    # the local map: landmarks back-projected from the frame's own features (the bench cannot call the oracle; the parity test of this shape
+    # is tests/test_gpu_matchers.py::test_c4_projection_50k_landmarks_1080p)
+    frontend()
     torch.cuda.synchronize()
-    ex.profile_end()
-    fence()
-    ex.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    n0 = int(nL.item())
+    kps0 = kL.cpu().numpy().view(N.KP_DTYPE)[:n0]
+    lms = synth_local_map(kps0, dL.cpu().numpy().reshape(-1, 32)[:n0], depth.cpu().numpy()[:n0], L, 77 + rank, fx, fx, W / 2 - 0.5, H / 2 - 0.5)
+    d_lms = torch.from_numpy(lms.view(np.uint8).reshape(-1)).to(dev)
+    obs = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    F = N.FrameView()
+    for i, v in enumerate(np.eye(3, dtype=np.float32).reshape(-1)):
+        F.Rcw[i] = float(v)
+    F.fx, F.fy, F.cx, F.cy, F.mbf, F.sensor = fx, fx, W / 2 - 0.5, H / 2 - 0.5, fx * 0.12, 1
+    F.min_x, F.max_x, F.min_y, F.max_y, F.size_ref, F.n = 0.0, float(W), 0.0, float(H), 31.0, n0
+    F.kps, F.desc, F.uR, F.kp_lm_obs = kL.data_ptr(), dL.data_ptr(), uR.data_ptr(), obs.data_ptr()
+    pp = N.ProjParams(5.0, 100.0, 0.8, 0.5, 1.5, 1, 1, 0)
+    midx, mdist, nm = mk(L, torch.int32), mk(L, torch.float32), mk(1, torch.int32)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    times = {"stereo_frontend": 0.0, "projection_50k": 0.0, "imaging_extract": 0.0}
+    timing = {"on": False}
+
+    def step():
+        if timing["on"]:
+            ev[0].record(s1)
+        frontend()
+        if timing["on"]:
+            ev[1].record(s1)
+        N.check(ex._h, ex._lib.hs_search_by_projection_device(ex._h, C.byref(F), d_lms.data_ptr(), L, C.byref(pp), midx.data_ptr(), mdist.data_ptr(),
+                                                              nm.data_ptr(), s1.cuda_stream))
+        if timing["on"]:
+            ev[2].record(s1)
+            ev[3].record(s2)
+        exi.extract_batch_device(big.data_ptr(), 1, IW, IH, IW, IW * IH, ik.data_ptr(), idesc.data_ptr(), inn.data_ptr(), icap, s2.cuda_stream)
+
+    elapsed, _ = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev)
+    # per-stage device times from a few serialised extra steps (events on the launch streams; outside the timed region)
+    timing["on"] = True
+    reps = 10
+    for _ in range(reps):
+        torch.cuda.synchronize()
         step()
-    fence()
-    t1 = time.perf_counter()
-    prof = ex.profile_end()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    if rank == 0:
-        per_stage, per_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
-        stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items() if c}
-        gbs = {s: round(per_stage[s] * B / (stage_ms[s] * 1e-3) / 1e9, 1) for s in ("pyramid", "fast_cells", "describe") if s in stage_ms}
-        value = world * B * args.steps / elapsed
-        print(json.dumps({
-            "metric": "mono frames/sec ORB extract, 1920x1080 @2000 feat, batch 64", "value": round(value, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C3: 64 x 1920x1080 mono frames per step, 2000 features, extract only", "keypoints_frame0": int(n[0].item())},
-            "stage_ms_per_step": {s: round(v, 5) for s, v in stage_ms.items()},
-            "per_kernel_algorithmic_GBps": gbs,
-            "end_to_end": {"algorithmic_bytes_per_frame": int(per_frame), "achieved_GBps": round(value / world * per_frame / 1e9, 1),
-                           "frac_of_hbm_peak": round(value / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)}}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        e_end = torch.cuda.Event(enable_timing=True)
+        e_end.record(s2)
+        torch.cuda.synchronize()
+        times["stereo_frontend"] += ev[0].elapsed_time(ev[1]) / reps
+        times["projection_50k"] += ev[1].elapsed_time(ev[2]) / reps
+        times["imaging_extract"] += ev[3].elapsed_time(e_end) / reps
+    if rank != 0:
+        return
+    _, pair_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
+    _, img_frame = algorithmic_bytes(pyramid_pixels(exi, IW, IH), IFEAT)
+    proj_bytes = L * lms.dtype.itemsize + n0 * (24 + 32 + 4)
+    step_bytes = 2 * pair_frame + img_frame + proj_bytes
+    value = world * args.steps / elapsed
+    out = base_line("dual-camera steps/sec: 1080p stereo extract+match + 4000x3000 extract + 50k-landmark SearchByProjection", value, "steps/s", args, world, elapsed)
+    out["config"] = {"workload": "C4: per step one 1920x1080 stereo pair (2000 feat @1.2) + one 4000x3000 frame (3000 feat @1.4) + SearchByProjection of a "
+                                 "50 000-landmark local map (th 5, nnratio 0.8) on the stereo frame's device-resident outputs",
+                     "keypoints_stereo_left": n0, "keypoints_imaging": int(inn.item()), "projection_matches": int(nm.item()), "landmarks": L}
+    out["stage_ms"] = {k: round(v, 4) for k, v in times.items()}
+    dom = max(times, key=times.get)
+    dom_bytes = {"stereo_frontend": 2 * pair_frame, "projection_50k": proj_bytes, "imaging_extract": img_frame}[dom]
+    ach = dom_bytes / (times[dom] * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                       "traffic": None, "algorithmic_bytes_per_launch": int(dom_bytes), "launch_ms": round(times[dom], 4),
+                       "note": "stage = the whole launch sequence of that stream (batch 1: latency-bound, see DESIGN.md)"}
+    out["end_to_end"] = {"algorithmic_bytes_per_step": int(step_bytes), "achieved_GBps": round(value / world * step_bytes / 1e9, 2),
+                         "frac_of_hbm_peak": round(value / world * step_bytes / 1e9 / HBM_PEAK_GBS, 5)}
+    print(json.dumps(out), flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ C5
 def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
-    """BASELINE config 5: one 1920x1080 mono stream per GPU; per step every rank extracts its frame straight into the
-    all-gather record, one RCCL all-gather moves all records, then each rank runs the Hamming 2-NN of its descriptors against
-    every peer's.  value = frames/s over all ranks."""
+    """BASELINE config 5: one 1920x1080 mono stream per GPU; per step every rank extracts its frame straight into the all-gather
+    record, one RCCL all-gather moves all records, then each rank matches its descriptors against every peer's: brute-force 2-NN
+    (one launch, counts read from the record headers on the device) or vocabulary-grouped BoW matching.  Nothing synchronises with the
+    host inside a step.  value = frames/s over all ranks."""
     from hyslam_amd import distributed as D
     from hyslam_amd.synth import synth_image
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
     cap = ex.max_keypoints()
     frame = torch.from_numpy(synth_image(200 + rank, W, H)).to(dev)
-    rec = torch.zeros(D.record_bytes(cap), dtype=torch.uint8, device=dev)
+    rb = D.record_bytes(cap)
+    gathered = torch.zeros((world, rb), dtype=torch.uint8, device=dev)
+    rec = gathered[rank] if world == 1 else torch.zeros(rb, dtype=torch.uint8, device=dev)
     o_n, o_k, o_d = D.record_offsets(cap)
     ex.reserve(W, H, 1)
     stream = torch.cuda.current_stream().cuda_stream
-    n_matches = torch.zeros(1, dtype=torch.int64, device=dev)
+    outs = tuple(torch.zeros((world, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    bow = None
+    if args.c5_match == "bow":
+        if not hasattr(D, "BowCrossCamera"):
+            sys.exit("bench.py: --c5-match bow needs the device-resident vocabulary path (hyslam_amd.distributed.BowCrossCamera)")
+        bow = D.BowCrossCamera(ex, world, cap, seed=17)
 
     def step():
         ex.extract_batch_device(frame.data_ptr(), 1, W, H, W, W * H, rec.data_ptr() + o_k, rec.data_ptr() + o_d, rec.data_ptr() + o_n, cap, stream)
-        g = D.all_gather_records(rec) if world > 1 else rec.unsqueeze(0)
-        res, counts = D.cross_camera_knn2(ex, g, rank, cap, stream)
-        return res, counts
-
-    def fence():
-        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_gather_into_tensor(gathered.view(-1), rec)
+        if bow is not None:
+            bow.match(gathered, rank, stream)
+        else:
+            D.cross_camera_knn2(ex, gathered, rank, cap, stream, out=outs)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res, counts = step()
-    fence()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed, _ = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev)
+    counts = gathered[:, :4].view(torch.int32)[:, 0].cpu().tolist()
     good = 0
-    for peer, (bi, bd, sd) in res.items():
+    if bow is None:
         n = counts[rank]
-        good += int(((bd[:n] < 50) & (bd[:n].float() < 0.8 * sd[:n].float())).sum().item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "mono frames/sec ORB extract + all-gather + cross-camera 2-NN, 1920x1080 @2000 feat", "value": round(world * args.steps / elapsed, 2),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C5: one 1920x1080 mono stream per GPU, 2000 features, all-gather of %d-byte records, brute-force Hamming 2-NN vs every peer"
-                                   % D.record_bytes(cap), "keypoints_rank0": counts[0], "ratio_test_matches_rank0": good}}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        for peer in range(world):
+            if peer != rank:
+                bd, sd = outs[1][peer, :n], outs[2][peer, :n]
+                good += int(((bd < 50) & (bd.float() < 0.8 * sd.float())).sum().item())
+    else:
+        good = bow.total_matches(rank)
+    if rank != 0:
+        return
+    out = base_line("mono frames/sec ORB extract + all-gather + cross-camera match, 1920x1080 @2000 feat", world * args.steps / elapsed, "frames/s",
+                    args, world, elapsed)
+    out["config"] = {"workload": "C5: one 1920x1080 mono stream per GPU, 2000 features, all-gather of %d-byte records, %s vs every peer"
+                                 % (rb, "brute-force Hamming 2-NN" if bow is None else "vocabulary transform + BoW-grouped match (synthetic 10-ary vocabulary)"),
+                     "keypoints_rank0": counts[0], "matches_rank0": good}
+    print(json.dumps(out), flush=True)
 
 
-def measured_traffic(kernel, pairs_per_step, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01_k_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs of this workload, FETCH_SIZE doubled per the gfx950 calibration).  Counters cannot be read from
-    inside this process, so the value is only reported when the profiled batch size matches; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
-    try:
-        t = json.load(open(path))
-        k = {"fast_cells": "k_fast_rows", "pyramid": "k_resize_level_lds", "describe": "k_describe", "quadtree": "k_quadtree"}[kernel]
-        e = t["kernels"][k]
-        if t["pairs_per_step"] != pairs_per_step or e["frames_per_launch"] != frames_per_launch:
-            return None, None
-        return int((e["read_MB"] + e["written_MB"]) * 1e6), "profiles/r01_k_hbm_traffic.json"
-    except Exception:
-        return None, None
-
-
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(pairs, budget_s):
-    """The oracle in the reference's structure (ImageProcessing::ProcessStereoImage, src/main/ImageProcessing.cpp:69-116):
-    left frame on a spawned thread, right on the caller, then the stereo matcher — 2 host cores per pair."""
+    """The oracle in the reference's structure (ImageProcessing::ProcessStereoImage, src/main/ImageProcessing.cpp:69-116): left frame on a
+    spawned thread, right on the caller, then the stereo matcher.  Two figures: `cpu_ref_structure` = one instance
+    (2 host threads per pair), `cpu_all_cores` = nproc/2 such workers side by side."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
     p = oracle.default_params(NFEAT)
@@ -352,10 +520,55 @@ def cpu_baseline(pairs, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s and n >= 4:
             break
+    nproc = os.cpu_count() or 2
+    workers = max(1, nproc // 2)
+    per_worker = max(2, int(round(budget_s * n / el)))           # about budget_s seconds of work per worker (the oracle holds no GIL)
+    def work(i):
+        for j in range(per_worker):
+            L, R = pairs[(i + j) % len(pairs)]
+            oracle.stereo_frontend(p, sp, L, R)
+    t1 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(work, range(workers)))
+    el_all = time.perf_counter() - t1
     return {"value": round(n / el, 3), "unit": "stereo_pairs/s", "cores": 2, "kind": "port",
+            "cpu_ref_structure": {"value": round(n / el, 3), "threads": 2},
+            "cpu_all_cores": {"value": round(workers * per_worker / el_all, 2), "threads": 2 * workers, "nproc": nproc, "workers": workers,
+                              "sample": "%d pairs in %.1f s" % (workers * per_worker, el_all)},
             "sample": "%d synthetic 1920x1080 pairs in %.1f s; oracle/ C++ restatement (left||right threads + stereo match), "
-                      "omits the reference's cv::Mat/FeatureDescriptor allocation overheads; host has %d logical cores"
-                      % (n, el, os.cpu_count())}
+                      "omits the reference's cv::Mat/FeatureDescriptor allocation overheads (an optimistic stand-in); host has %d logical cores"
+                      % (n, el, nproc)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                # before torch / HIP are touched
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without it to let "
+                 "bench.py spawn the ranks)" % (args.gpus, world, args.gpus))
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    import hyslam_amd as HS
+    from hyslam_amd import _native as N
+    {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args, rank, world, local_rank, dev, torch, dist, HS, N)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -70,7 +70,8 @@ EXPORTS = [
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
     "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
-    "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
+    "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
+    "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
 
@@ -123,7 +124,13 @@ def lib():
     L.hs_bow_transform.argtypes = [vp, C.POINTER(VocabTree), vp, C.c_int, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.hs_record_bytes.argtypes = [C.c_int]
+    L.hs_record_bytes.restype = sz
+    L.hs_record_offsets.argtypes = [C.c_int, vp, vp, vp]
+    L.hs_record_offsets.restype = None
+    L.hs_records_knn2_device.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.hs_debug_stream_copy.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.hs_orb_stage_launches.argtypes = [vp, C.c_int]
     L.hs_orb_profile_begin.argtypes = [vp]
     L.hs_orb_profile_end.argtypes = [vp, vp, vp]
     L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]

@@ -18,6 +18,7 @@ struct hs_orb {
     hipStream_t stream = nullptr;
     std::string err;
     uint16_t taps[7];
+    HsFastKnobs fast_knobs{};          // HS_FAST_* environment knobs, read once in hs_orb_create
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -44,7 +45,10 @@ struct hs_orb {
     uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
-    int32_t* d_strip_count = nullptr; uint16_t* d_strip_list = nullptr; size_t strip_entries = 0;
+    int32_t* d_strip_count = nullptr; uint16_t* d_strip_list = nullptr; size_t strip_count_entries = 0, strip_list_entries = 0;
+    // persistent staging of hs_stereo_match (host-pointer call): device keypoints / descriptors / counts and one pinned host block
+    hs_keypoint* d_sm_kps = nullptr; uint8_t* d_sm_desc = nullptr; int32_t* d_sm_n = nullptr; int sm_cap = 0;
+    uint8_t* h_pin = nullptr; size_t pin_bytes = 0;
     int last_batch = 0; HsImg0 last_img0{};
     // bump-allocated scratch for the host-pointer matcher entry points
     uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
@@ -86,16 +90,25 @@ void free_geometry(hs_orb* h)
     h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
     hipFree(h->d_sel); h->d_sel = nullptr;
+    // nothing is configured any more: a failed configure() must not leave a geometry that the early exit would accept
+    h->w = h->h = h->batch_cap = 0; h->max_kp = 0; h->total_cells = 0; h->fast_items = 0;
 }
 
 // (Re)build per-level geometry, tables and workspace for batches of `batch` frames of w x h.
+int configure_impl(hs_orb* h, int w, int hh, int batch);
 int configure(hs_orb* h, int w, int hh, int batch)
 {
     if (w == h->w && hh == h->h && batch <= h->batch_cap) return HS_OK;
     if (w < 1 || hh < 1 || w > 16384 || hh > 16384 || batch < 1 || batch > 65535)
         return fail(h, HS_ERR_INVALID, "image size / batch out of range");
+    const int rc = configure_impl(h, w, hh, batch);
+    if (rc != HS_OK) free_geometry(h);             // partial allocations of a failed attempt go away; the handle stays usable
+    return rc;
+}
+int configure_impl(hs_orb* h, int w, int hh, int batch)
+{
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    free_geometry(h);
+    free_geometry(h);                  // also un-configures: every failure return below leaves w = h = batch_cap = 0
     const int L = h->p.nlevels;
     h->lv.assign(L, HsLevel{});
     std::vector<int16_t> tables;
@@ -202,9 +215,9 @@ int configure(hs_orb* h, int w, int hh, int batch)
         hs_fast_build_items(h->lv.data(), L, fi.data());
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch), 256)));
+        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch, h->fast_knobs), 256)));
     }
-    h->w = w; h->h = hh; h->batch_cap = batch;
+    h->w = w; h->h = hh; h->batch_cap = batch;      // configured only now
     return HS_OK;
 }
 
@@ -224,14 +237,21 @@ int ensure_outputs(hs_orb* h, int batch, int cap)
 
 int ensure_stereo_strips(hs_orb* h, int pairs, int cap, int n_rows)
 {
-    const size_t need = (size_t)pairs * hs_stereo_strips(n_rows) * ((size_t)cap + 2);
-    if (need <= h->strip_entries) return HS_OK;
+    // two capacities: the counters (pairs * strips) and the lists (pairs * strips * cap) grow independently
+    const size_t need_count = (size_t)pairs * hs_stereo_strips(n_rows), need_list = need_count * (size_t)cap;
+    if (need_count <= h->strip_count_entries && need_list <= h->strip_list_entries) return HS_OK;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    hipFree(h->d_strip_count); hipFree(h->d_strip_list); h->d_strip_count = nullptr; h->d_strip_list = nullptr;
-    HIP_TRY(h, hipMalloc(&h->d_strip_count, (size_t)pairs * hs_stereo_strips(n_rows) * 4));
-    HIP_TRY(h, hipMemset(h->d_strip_count, 0, (size_t)pairs * hs_stereo_strips(n_rows) * 4));      // every call leaves the counters zero again
-    HIP_TRY(h, hipMalloc(&h->d_strip_list, (size_t)pairs * hs_stereo_strips(n_rows) * cap * 2));
-    h->strip_entries = need;
+    if (need_count > h->strip_count_entries) {
+        hipFree(h->d_strip_count); h->d_strip_count = nullptr; h->strip_count_entries = 0;
+        HIP_TRY(h, hipMalloc(&h->d_strip_count, need_count * 4));
+        HIP_TRY(h, hipMemset(h->d_strip_count, 0, need_count * 4));      // every call leaves the counters it used zero again
+        h->strip_count_entries = need_count;
+    }
+    if (need_list > h->strip_list_entries) {
+        hipFree(h->d_strip_list); h->d_strip_list = nullptr; h->strip_list_entries = 0;
+        HIP_TRY(h, hipMalloc(&h->d_strip_list, need_list * 2));
+        h->strip_list_entries = need_list;
+    }
     return HS_OK;
 }
 
@@ -255,7 +275,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
     hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, s);
+                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_knobs, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
@@ -348,6 +368,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev) return HS_ERR_NO_DEVICE;
     hs_orb* h = new hs_orb();
     h->p = *p; h->device = device;
+    h->fast_knobs = hs_fast_read_knobs();
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
     static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
     for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];
@@ -392,6 +413,8 @@ void hs_orb_destroy(hs_orb* h)
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
     hipFree(h->d_kps); hipFree(h->d_desc); hipFree(h->d_n);
     hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd); hipFree(h->d_scratch); hipFree(h->d_strip_count); hipFree(h->d_strip_list);
+    hipFree(h->d_sm_kps); hipFree(h->d_sm_desc); hipFree(h->d_sm_n);
+    if (h->h_pin) hipHostFree(h->h_pin);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -542,31 +565,47 @@ int hs_stereo_match(hs_orb* h, const hs_keypoint* kpsL, const uint8_t* descL, in
     HIP_TRY(h, hipSetDevice(h->device));
     const int cap = std::max(std::max(nL, nR), 1);
     hipStream_t s = h->stream;
-    hs_keypoint *dk = nullptr; uint8_t* dd = nullptr; int32_t* dn = nullptr;
-    HIP_TRY(h, hipMalloc(&dk, (size_t)2 * cap * sizeof(hs_keypoint)));
-    HIP_TRY(h, hipMalloc(&dd, (size_t)2 * cap * HS_DESC_BYTES));
-    HIP_TRY(h, hipMalloc(&dn, 8));
+    // persistent staging (grow-only): no allocation on the steady-state path.  Inputs go through one pinned block so that the five
+    // H2D copies are real asynchronous DMAs; outputs come back into the same block.
+    if (cap > h->sm_cap) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        hipFree(h->d_sm_kps); hipFree(h->d_sm_desc); hipFree(h->d_sm_n); h->d_sm_kps = nullptr; h->d_sm_desc = nullptr; h->d_sm_n = nullptr; h->sm_cap = 0;
+        const int grow = std::max(cap, 2048);
+        HIP_TRY(h, hipMalloc(&h->d_sm_kps, (size_t)2 * grow * sizeof(hs_keypoint)));
+        HIP_TRY(h, hipMalloc(&h->d_sm_desc, (size_t)2 * grow * HS_DESC_BYTES));
+        HIP_TRY(h, hipMalloc(&h->d_sm_n, 8));
+        h->sm_cap = grow;
+    }
+    const size_t kb = (size_t)cap * sizeof(hs_keypoint), db = (size_t)cap * HS_DESC_BYTES;
+    const size_t pin_need = 2 * kb + 2 * db + 16 + 2 * (size_t)cap * 4;
+    if (pin_need > h->pin_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (h->h_pin) hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_bytes = 0;
+        const size_t grow = std::max<size_t>(pin_need, 1 << 18);
+        HIP_TRY(h, hipHostMalloc(&h->h_pin, grow, hipHostMallocDefault));
+        h->pin_bytes = grow;
+    }
     int rc = ensure_stereo_scratch(h, (size_t)cap);
     if (rc == HS_OK) rc = ensure_stereo_strips(h, 1, cap, sp->n_rows);
-    int32_t cnt[2] = { nL, nR };
-    hipError_t e = hipSuccess;
-    if (rc == HS_OK) {
-        e = hipMemcpyAsync(dk, kpsL, (size_t)nL * sizeof(hs_keypoint), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && nR) e = hipMemcpyAsync(dk + cap, kpsR, (size_t)nR * sizeof(hs_keypoint), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(dd, descL, (size_t)nL * 32, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && nR) e = hipMemcpyAsync(dd + (size_t)cap * 32, descR, (size_t)nR * 32, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(dn, cnt, 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) {
-            run_stereo(h, dk, dd, dn, dk + cap, dd + (size_t)cap * 32, dn + 1, 1, cap, *sp, h->d_ur, h->d_depth, s);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(uRight, h->d_ur, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(depth, h->d_depth, (size_t)nL * 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-    }
-    hipFree(dk); hipFree(dd); hipFree(dn);
     if (rc != HS_OK) return rc;
-    if (e != hipSuccess) return fail(h, HS_ERR_HIP, hipGetErrorString(e));
+    hs_keypoint* dk = h->d_sm_kps; uint8_t* dd = h->d_sm_desc; int32_t* dn = h->d_sm_n;
+    uint8_t* pk = h->h_pin; uint8_t* pd = pk + 2 * kb; int32_t* pn = reinterpret_cast<int32_t*>(pd + 2 * db); float* pout = reinterpret_cast<float*>(pd + 2 * db + 16);
+    memcpy(pk, kpsL, (size_t)nL * sizeof(hs_keypoint));
+    if (nR) memcpy(pk + kb, kpsR, (size_t)nR * sizeof(hs_keypoint));
+    memcpy(pd, descL, (size_t)nL * 32);
+    if (nR) memcpy(pd + db, descR, (size_t)nR * 32);
+    pn[0] = nL; pn[1] = nR;
+    HIP_TRY(h, hipMemcpyAsync(dk, pk, 2 * kb, hipMemcpyHostToDevice, s));                 // left at [0, cap), right at [cap, 2 cap)
+    HIP_TRY(h, hipMemcpyAsync(dd, pd, 2 * db, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(dn, pn, 8, hipMemcpyHostToDevice, s));
+    run_stereo(h, dk, dd, dn, dk + cap, dd + (size_t)cap * 32, dn + 1, 1, cap, *sp, h->d_ur, h->d_depth, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(pout, h->d_ur, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(pout + cap, h->d_depth, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    memcpy(uRight, pout, (size_t)nL * 4);
+    memcpy(depth, pout + cap, (size_t)nL * 4);
     return HS_OK;
 }
 
@@ -864,6 +903,29 @@ int hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int n
     return HS_OK;
 }
 
+size_t hs_record_bytes(int cap) { return cap < 0 ? 0 : (size_t)HS_RECORD_HEADER + (size_t)cap * (sizeof(hs_keypoint) + HS_DESC_BYTES); }
+
+void hs_record_offsets(int cap, size_t* off_count, size_t* off_kps, size_t* off_desc)
+{
+    if (off_count) *off_count = 0;
+    if (off_kps) *off_kps = HS_RECORD_HEADER;
+    if (off_desc) *off_desc = (size_t)HS_RECORD_HEADER + (size_t)std::max(cap, 0) * sizeof(hs_keypoint);
+}
+
+int hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,
+                           int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!d_records || world < 1 || world > 65535 || rank < 0 || rank >= world || cap < 1 || cap > 65535 || record_stride < hs_record_bytes(cap) ||
+        (record_stride & 3) || ((uintptr_t)d_records & 15) || !d_best_idx || !d_best_dist || !d_second_dist)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t od; hs_record_offsets(cap, nullptr, nullptr, &od);
+    hs_launch_knn2_records(d_records, record_stride, world, rank, cap, od, d_best_idx, d_best_dist, d_second_dist, stream ? (hipStream_t)stream : h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
 int hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes, int width, void* stream)
 {
     if (!h) return HS_ERR_INVALID;
@@ -872,6 +934,13 @@ int hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes
     hs_launch_stream_copy(d_dst, d_src, bytes, width, stream ? (hipStream_t)stream : h->stream);
     HIP_TRY(h, hipGetLastError());
     return HS_OK;
+}
+
+int hs_orb_stage_launches(const hs_orb* h, int stage)
+{
+    if (!h || stage < 0 || stage >= HS_NUM_STAGES) return 0;
+    if (stage == 0) return hs_pyramid_launch_count(h->p.nlevels);
+    return stage == 4 ? 2 : 1;
 }
 
 int hs_orb_profile_begin(hs_orb* h)
@@ -888,16 +957,20 @@ int hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches)
     if (!ms || !launches) return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     for (int i = 0; i < HS_NUM_STAGES; i++) { ms[i] = 0; launches[i] = 0; }
-    h->prof = false;
-    if (h->ev_used) HIP_TRY(h, hipEventSynchronize(h->ev_pool[h->ev_used - 1]));
-    for (size_t i = 0; i + 1 < h->ev_used; i++) {
-        int st = h->prof_stage[i];
-        if (st < 0 || st >= HS_NUM_STAGES) continue;
-        float t = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
-        ms[st] += t; launches[st]++;
+    // the second lane (hs_orb_set_lanes) records its own event sequence: both are summed
+    for (hs_orb* q : { h, h->lane2 }) {
+        if (!q) continue;
+        q->prof = false;
+        if (q->ev_used) HIP_TRY(h, hipEventSynchronize(q->ev_pool[q->ev_used - 1]));
+        for (size_t i = 0; i + 1 < q->ev_used; i++) {
+            int st = q->prof_stage[i];
+            if (st < 0 || st >= HS_NUM_STAGES) continue;
+            float t = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&t, q->ev_pool[i], q->ev_pool[i + 1]));
+            ms[st] += t; launches[st]++;
+        }
+        q->ev_used = 0; q->prof_stage.clear();
     }
-    h->ev_used = 0; h->prof_stage.clear();
     return HS_OK;
 }
 

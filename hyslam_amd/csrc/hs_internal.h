@@ -120,13 +120,16 @@ struct HsOut {                     // extractor outputs, split the same way
 
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+int hs_pyramid_launch_count(int nlevels);          // kernel launches of one hs_launch_pyramid call
 int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
 int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
+struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b; };   // HS_FAST_* test / tuning knobs, read once per handle
+HsFastKnobs hs_fast_read_knobs();
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes()*/, hipStream_t s);
-size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
+                    int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes()*/, const HsFastKnobs& knobs, hipStream_t s);
+size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
@@ -157,6 +160,8 @@ void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs
                    int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
+void hs_launch_knn2_records(const uint8_t* d_recs, size_t stride, int world, int rank, int cap, size_t off_desc,
+                            int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);
 void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, const int32_t* d_cc, const uint8_t* d_ndesc, const int32_t* d_word,
                              const float* d_weight, int levels, int levelsup, int32_t* d_out_word, float* d_out_weight, int32_t* d_out_node, hipStream_t s);

@@ -544,9 +544,20 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
     }
 }
 
+// test / tuning knobs: read from the environment ONCE per handle (hs_orb_create), never on the launch path
+HsFastKnobs hs_fast_read_knobs()
+{
+    HsFastKnobs k{};
+    if (const char* e = getenv("HS_FAST_PCAP")) k.pcap = atoi(e);                         // tuning: list capacity
+    if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) k.small_lists = atoi(e) != 0; // parity tests: force the spill paths
+    if (const char* e = getenv("HS_FAST_WG_PER_CU")) k.wg_per_cu = atoi(e);               // tuning: workgroups per CU
+    if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) k.force_scan_b = atoi(e) != 0;     // parity tests: NMS from the score tile
+    return k;
+}
+
 // launch configuration shared by the launcher and by hs_fast_overflow_bytes()
 struct FastRowsCfg { int lc, tr, per_cu; uint32_t ovf_stride; FastRowsLds lds; };
-static FastRowsCfg fast_rows_cfg(int max_hcell)
+static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs)
 {
     FastRowsCfg c;
     c.lc = fast_rows_lc();
@@ -564,8 +575,8 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     const int floor_bytes = std::max(fixed + 3 * 1024, (c.tr + 8) * pitch);   // >= 1024 list entries; the over-read of the last scan block stays inside
     const int granules = (floor_bytes + GRAN - 1) / GRAN;
     L.pcap = ((granules * GRAN - fixed) / 3) & ~15;           // 2 bytes position + 1 byte score per entry; >= 4*cols (one tile row of pixels)
-    if (const char* e = getenv("HS_FAST_PCAP")) L.pcap = std::max(4 * cols, atoi(e) & ~15);   // tuning knob
-    if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) if (atoi(e)) L.pcap = 4 * cols;   // parity tests: force the spill paths
+    if (knobs.pcap > 0) L.pcap = std::max(4 * cols, knobs.pcap & ~15);
+    if (knobs.small_lists) L.pcap = 4 * cols;
     int o = c.tr * pitch;
     L.off_plist = o; o += L.pcap * 2;
     L.off_pscore = o; o += L.pcap;
@@ -574,7 +585,7 @@ static FastRowsCfg fast_rows_cfg(int max_hcell)
     o = std::max(o, (c.tr + 8) * pitch);
     L.total = (o + 15) & ~15;
     c.per_cu = std::max(1, std::min(16, LDS_CU / ((L.total + GRAN - 1) / GRAN * GRAN)));
-    if (const char* e = getenv("HS_FAST_WG_PER_CU")) c.per_cu = std::max(1, std::min(c.per_cu, atoi(e)));
+    if (knobs.wg_per_cu > 0) c.per_cu = std::max(1, std::min(c.per_cu, knobs.wg_per_cu));
     c.ovf_stride = (uint32_t)((4 * cols - 9) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
     return c;
 }
@@ -585,24 +596,24 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
     while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD ranges)
     return nblk;
 }
-size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max)
+size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
-    const FastRowsCfg c = fast_rows_cfg(max_hcell);
+    const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
     return (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
 }
 
 static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, uint32_t* overflow, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)max_wcell;
-    const FastRowsCfg c = fast_rows_cfg(max_hcell);
+    const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
     const FastRowsLds& L = c.lds;
     const int lc = c.lc, tr = c.tr;
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return;
     const int nblk = fast_rows_grid(c, total_work);
-    int force_scan_b = 0; if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) force_scan_b = atoi(e) != 0;   // parity tests: NMS from the score tile
+    const int force_scan_b = knobs.force_scan_b;
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
@@ -612,9 +623,9 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0) return;
-    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, s);
+    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, knobs, s);
 }

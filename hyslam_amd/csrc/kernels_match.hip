@@ -377,12 +377,11 @@ __global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ p
     }
 }
 
-__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
-                                              int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+// one wavefront: 2-NN of query descriptor i over the train set (first minimum wins; second = second smallest of the multiset)
+__device__ __forceinline__ void knn2_wave(const uint8_t* __restrict__ q, int i, const uint8_t* __restrict__ t, int nt,
+                                          int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (i >= nq) return;
     const unsigned long long* dq = reinterpret_cast<const unsigned long long*>(q + (size_t)i * 32);
     const unsigned long long a0 = dq[0], a1 = dq[1], a2 = dq[2], a3 = dq[3];
     unsigned long long best = NO_KEY; int second = NO_DIST;
@@ -399,6 +398,29 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int
         best_dist[i] = best == NO_KEY ? -1 : (int)(best >> 32);
         second_dist[i] = second == NO_DIST ? -1 : second;
     }
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t, int nt,
+                                              int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (i >= nq) return;
+    knn2_wave(q, i, t, nt, best_idx, best_dist, second_dist);
+}
+
+// Cross-camera 2-NN over gathered frame records (hs_records_knn2_device): blockIdx.y = peer record; the counts come from the record
+// headers on the device, so the step needs no host round trip between the all-gather and the matcher.
+__global__ __launch_bounds__(256) void k_knn2_records(const uint8_t* __restrict__ recs, size_t stride, int rank, int cap, size_t off_desc,
+                                                      int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    const int peer = blockIdx.y;
+    if (peer == rank) return;
+    const int nq = min(max(hs_cload<int32_t>(recs + (size_t)rank * stride), 0), cap);
+    const int nt = min(max(hs_cload<int32_t>(recs + (size_t)peer * stride), 0), cap);
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (i >= nq) return;
+    const size_t o = (size_t)peer * cap;
+    knn2_wave(recs + (size_t)rank * stride + off_desc, i, recs + (size_t)peer * stride + off_desc, nt, best_idx + o, best_dist + o, second_dist + o);
 }
 
 // ---------------------------------------------------------------- launchers (declared in hs_internal.h)
@@ -490,6 +512,13 @@ void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int3
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, d_q, nq, d_t, nt, d_bi, d_bd, d_sd);
+}
+
+void hs_launch_knn2_records(const uint8_t* d_recs, size_t stride, int world, int rank, int cap, size_t off_desc,
+                            int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s)
+{
+    if (world <= 0 || cap <= 0) return;
+    hipLaunchKernelGGL(k_knn2_records, dim3((cap + 3) / 4, world), dim3(256), 0, s, d_recs, stride, rank, cap, off_desc, d_bi, d_bd, d_sd);
 }
 
 // DBoW2 transform: one lane per descriptor walks the tree (k children x L levels Hamming distances; the tree is L2-resident)

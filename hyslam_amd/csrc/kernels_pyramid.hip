@@ -212,6 +212,8 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
     }
 }
 
+int hs_pyramid_launch_count(int nlevels) { return nlevels > 1 ? nlevels - 1 : 0; }
+
 // ---- calibration kernels of known HBM traffic (hs_debug_stream_copy): one dword / one 16-byte vector per lane, grid-stride
 __global__ __launch_bounds__(256) void k_copy_u32(uint32_t* __restrict__ d, const uint32_t* __restrict__ s, size_t n)
 {

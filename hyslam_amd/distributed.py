@@ -20,6 +20,7 @@ DESC_BYTES = 32
 
 
 def record_bytes(cap):
+    """== hs_record_bytes(cap) of the C ABI (tests/test_abi.py checks the two agree)"""
     return HEADER + cap * (KP_BYTES + DESC_BYTES)
 
 
@@ -70,27 +71,25 @@ def all_gather_records(record, group=None):
     return out
 
 
-def cross_camera_knn2(extractor, gathered, rank, cap, stream=0):
-    """Brute-force Hamming 2-NN of this rank's descriptors against every other rank's (hs_hamming_knn2_device).
-    gathered: torch uint8 [world, record_bytes(cap)] on the GPU.  Returns {peer: (best_idx, best_dist, second_dist)} int32 tensors
-    of length cap (entries beyond this rank's count are meaningless)."""
+def records_knn2_device(extractor, d_records, record_stride, world, rank, cap, d_best_idx, d_best_dist, d_second_dist, stream=0):
+    """hs_records_knn2_device on raw device addresses (integers): 2-NN of record `rank`'s descriptors against every other record's;
+    outputs [world][cap] int32.  The counts are read from the record headers on the device — nothing synchronises with the host."""
     import ctypes as C
-    import torch
     from . import _native as N
+    N.check(extractor._h, extractor._lib.hs_records_knn2_device(extractor._h, C.c_void_p(d_records), record_stride, world, rank, cap,
+                                                                C.c_void_p(d_best_idx), C.c_void_p(d_best_dist), C.c_void_p(d_second_dist),
+                                                                C.c_void_p(stream) if stream else None))
+
+
+def cross_camera_knn2(extractor, gathered, rank, cap, stream=0, out=None):
+    """Brute-force Hamming 2-NN of this rank's descriptors against every other rank's, ONE launch, no host round trip.
+    gathered: torch uint8 [world, record_bytes(cap)] on the GPU.  Returns (best_idx, best_dist, second_dist) int32 tensors [world, cap]
+    (row `rank` and entries beyond this rank's count are meaningless) and the device view of the per-record counts."""
+    import torch
     world = gathered.shape[0]
-    counts = gathered[:, :4].contiguous().view(torch.int32).view(-1).cpu().tolist()
-    o_n, o_k, o_d = record_offsets(cap)
-    base = gathered.data_ptr()
-    stride = gathered.shape[1]
-    out = {}
-    for peer in range(world):
-        if peer == rank:
-            continue
-        bi = torch.empty(cap, dtype=torch.int32, device=gathered.device)
-        bd = torch.empty_like(bi)
-        sd = torch.empty_like(bi)
-        N.check(extractor._h, extractor._lib.hs_hamming_knn2_device(
-            extractor._h, C.c_void_p(base + rank * stride + o_d), counts[rank], C.c_void_p(base + peer * stride + o_d), counts[peer],
-            C.c_void_p(bi.data_ptr()), C.c_void_p(bd.data_ptr()), C.c_void_p(sd.data_ptr()), C.c_void_p(stream) if stream else None))
-        out[peer] = (bi, bd, sd)
+    if out is None:
+        out = tuple(torch.empty((world, cap), dtype=torch.int32, device=gathered.device) for _ in range(3))
+    records_knn2_device(extractor, gathered.data_ptr(), gathered.shape[1], world, rank, cap,
+                        out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stream)
+    counts = gathered[:, :4].view(torch.int32).view(-1) if gathered.shape[1] % 4 == 0 else gathered[:, :4].contiguous().view(torch.int32).view(-1)
     return out, counts

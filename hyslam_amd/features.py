@@ -162,6 +162,10 @@ class ORBExtractor:
 
     STAGES = ("pyramid", "fast_cells", "quadtree", "describe", "stereo_match", "stereo_median")
 
+    def pyramid_launches(self):
+        """kernel launches of the pyramid stage per call (hs_orb_stage_launches)"""
+        return max(1, self._lib.hs_orb_stage_launches(self._h, 0))
+
     def profile_begin(self):
         N.check(self._h, self._lib.hs_orb_profile_begin(self._h))
 

@@ -82,3 +82,42 @@ def synth_stereo_pair(seed, w, h, n_shapes=None):
     left = _render(scene, w, h, False, 4) + _noise(seed, 2, h, w)
     right = _render(scene, w, h, True, 4) + _noise(seed, 3, h, w)
     return np.clip(left, 0, 255).astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8)
+
+
+def synth_local_map(kps, desc, depth, n_landmarks, seed, fx, fy, cx, cy, Rcw=None, tcw=None):
+    """A synthetic local map for the projection matchers (BASELINE config 4): `n_landmarks` landmarks made by back-projecting the
+    frame's own keypoints (cycled) at their stereo depth (a seeded depth where there is none), jittered by ~1.5 px and 3 % depth, with a
+    few descriptor bits flipped; `size` / `min_dist` / `max_dist` / `normal` filled consistently with the pose (Rcw, tcw; identity if None).
+    Returns a numpy array with the layout of hs_landmark (include/hyslam_amd.h)."""
+    from ._native import LM_DTYPE
+    n = len(kps)
+    r = splitmix64(seed, n_landmarks * 8, stream=7).reshape(n_landmarks, 8)
+    u = lambda c: (r[:, c] >> np.uint64(11)).astype(np.float64) / float(1 << 53)          # uniform [0,1)
+    src = np.arange(n_landmarks) % max(n, 1)
+    Rcw = np.eye(3, dtype=np.float32) if Rcw is None else np.asarray(Rcw, np.float32)
+    tcw = np.zeros(3, np.float32) if tcw is None else np.asarray(tcw, np.float32)
+    Rwc = Rcw.T.astype(np.float64)
+    Ow = -Rwc @ tcw.astype(np.float64)
+    d0 = np.asarray(depth, np.float64)[src]
+    d = np.where(d0 > 0, d0, 2.0 + 23.0 * u(0)) * (0.97 + 0.06 * u(1))
+    px = kps["x"][src].astype(np.float64) + 3.0 * (u(2) - 0.5)
+    py = kps["y"][src].astype(np.float64) + 3.0 * (u(3) - 0.5)
+    Pc = np.stack([(px - cx) * d / fx, (py - cy) * d / fy, d], 1)
+    Pw = (Rwc @ (Pc - tcw.astype(np.float64)).T).T
+    lms = np.zeros(n_landmarks, LM_DTYPE)
+    lms["pos"] = Pw.astype(np.float32)
+    lms["size"] = (kps["size"][src] * d / fx * (0.8 + 0.4 * u(4))).astype(np.float32)
+    dist = np.linalg.norm(Pw - Ow, axis=1)
+    lms["min_dist"] = (dist * 0.5).astype(np.float32)
+    lms["max_dist"] = (dist * 2.0).astype(np.float32)
+    lms["normal"] = ((Pw - Ow) / dist[:, None]).astype(np.float32)
+    dd = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)[src].copy()
+    flip = (r[:, 5] % np.uint64(256)).astype(np.int64)                                    # one flipped bit per landmark, two for the later copies
+    dd[np.arange(n_landmarks), flip >> 3] ^= (1 << (flip & 7)).astype(np.uint8)
+    late = np.arange(n_landmarks) >= n
+    flip2 = (r[:, 6] % np.uint64(256)).astype(np.int64)
+    dd[late, flip2[late] >> 3] ^= (1 << (flip2[late] & 7)).astype(np.uint8)
+    lms["desc"] = dd
+    lms["assoc_kp"] = -1
+    lms["prev_angle"] = kps["angle"][src]
+    return lms

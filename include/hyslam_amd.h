@@ -254,12 +254,27 @@ int  hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int 
 int  hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                             int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
 
+/* ---- frame records: the fixed-size unit of the cross-camera exchange (BASELINE config 5; new — the reference has no
+ * multi-camera exchange).  record = { int32 count; 12 bytes pad; hs_keypoint kps[cap]; uint8 desc[cap][32] }: the extractor's three
+ * outputs laid out in one buffer, so hs_orb_extract_batch_device writes a frame straight into the all-gather message. */
+#define HS_RECORD_HEADER 16
+size_t hs_record_bytes(int cap);
+void   hs_record_offsets(int cap, size_t* off_count, size_t* off_kps, size_t* off_desc);
+/* Cross-camera brute-force 2-NN over `world` gathered records (device memory, `record_stride` bytes apart): for every peer p != rank the
+ * descriptors of record `rank` are matched against record p's.  The counts are read from the record headers ON THE DEVICE (clamped to
+ * [0, cap]) — no host synchronisation between the all-gather and the matcher.  Outputs are [world][cap]; row `rank` and the entries beyond
+ * the query count are left untouched.  One launch.  Asynchronous. */
+int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,
+                            int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
+
 /* ---- per-stage device timing (HIP events recorded on the stream the kernels run on) ----
  * Stages: 0 pyramid, 1 FAST+NMS cells, 2 quadtree distribution, 3 blur+orient+rBRIEF, 4 stereo match, 5 stereo median.
  * begin: start collecting (events are recorded around every stage of every later call on this handle);
  * end:   synchronise, write the summed milliseconds per stage into ms[6] and the number of launches of each
  *        stage into launches[6] (pyramid counts one launch per call although it is nlevels-1 kernels), stop collecting. */
 #define HS_NUM_STAGES 6
+/* kernel launches that stage `stage` issues per call (the pyramid is several launches, the stereo match two) */
+int  hs_orb_stage_launches(const hs_orb* h, int stage);
 int  hs_orb_profile_begin(hs_orb* h);
 int  hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches);
 

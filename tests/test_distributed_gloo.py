@@ -94,3 +94,19 @@ def test_record_layout_and_sharding():
             r = [D.shard_range(n, i, w) for i in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` (no torchrun): the parent spawns two ranks with RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line and
+    fails when WORLD_SIZE disagrees with --gpus.  --dry-run keeps the ranks off the GPU (gloo rendezvous only)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 3
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
