@@ -48,13 +48,14 @@ class ProjParams(C.Structure):
                 ("frac_smaller", C.c_float), ("frac_larger", C.c_float),
                 ("use_distance", C.c_int32), ("use_stereo", C.c_int32), ("check_rotation", C.c_int32),
                 ("use_prev_matched", C.c_int32), ("use_viewing_angle", C.c_int32), ("max_view_angle", C.c_float),
-                ("use_reprojection", C.c_int32), ("reproj_threshold", C.c_float), ("sigma_ref", C.c_float), ("first_wins", C.c_int32)]
+                ("use_reprojection", C.c_int32), ("reproj_threshold", C.c_float), ("sigma_ref", C.c_float), ("first_wins", C.c_int32),
+                ("dist_is_invariance_range", C.c_int32)]
 
     def __init__(self, th=3.0, score_threshold=100.0, second_best_ratio=0.6, frac_smaller=0.5, frac_larger=1.5, use_distance=1, use_stereo=1,
                  check_rotation=0, use_prev_matched=1, use_viewing_angle=0, max_view_angle=1.047, use_reprojection=0, reproj_threshold=5.99,
-                 sigma_ref=1.0, first_wins=0):
+                 sigma_ref=1.0, first_wins=0, dist_is_invariance_range=0):
         super().__init__(th, score_threshold, second_best_ratio, frac_smaller, frac_larger, use_distance, use_stereo, check_rotation,
-                         use_prev_matched, use_viewing_angle, max_view_angle, use_reprojection, reproj_threshold, sigma_ref, first_wins)
+                         use_prev_matched, use_viewing_angle, max_view_angle, use_reprojection, reproj_threshold, sigma_ref, first_wins, dist_is_invariance_range)
 
 
 class HsError(RuntimeError):

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void k_search_projection(HsFrameDev F, const h
         const float ox = __fsub_rn(lm.pos[0], F.Ow[0]), oy = __fsub_rn(lm.pos[1], F.Ow[1]), oz = __fsub_rn(lm.pos[2], F.Ow[2]);
         const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz));
         const float dist = (float)sqrt(n2);
-        if (dist < __fmul_rn(0.8f, lm.min_dist) || dist > __fmul_rn(1.2f, lm.max_dist)) ok = false;
+        const float lo = pp.dist_is_invariance_range ? lm.min_dist : __fmul_rn(0.8f, lm.min_dist);
+        const float hi = pp.dist_is_invariance_range ? lm.max_dist : __fmul_rn(1.2f, lm.max_dist);
+        if (dist < lo || dist > hi) ok = false;
     }
     if (ok && pp.use_viewing_angle) {                                                               // ViewingAngleCriterionCore
         const float ox = __fsub_rn(lm.pos[0], F.Ow[0]), oy = __fsub_rn(lm.pos[1], F.Ow[1]), oz = __fsub_rn(lm.pos[2], F.Ow[2]);

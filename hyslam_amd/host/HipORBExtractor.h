@@ -10,10 +10,13 @@
 #ifdef HYSLAM_AMD_WITH_HYSLAM
 #include <FeatureExtractor.h>
 #include <FeatureMatcher.h>
+#include <FeatureViews.h>
+#include <Camera.h>
 #include <opencv2/core/core.hpp>
 #else
 #include "cv_compat.h"
 #endif
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -46,7 +49,10 @@ public:
         cap = hs_orb_max_keypoints(h);
         kps.resize(cap); desc.resize((size_t)cap * HS_DESC_BYTES);
     }
-    ~HipORBExtractor() override { hs_orb_destroy(h); }
+    // HYSLAM::FeatureExtractor has no virtual destructor (src/features/FeatureExtractor.h:25-37): own a HipORBExtractor through
+    // std::make_shared<HipORBExtractor>(...) (the control block remembers the concrete type, as HipORBFactory::getExtractor does) and never
+    // `delete` it through a FeatureExtractor*.
+    ~HipORBExtractor() { hs_orb_destroy(h); }
     HipORBExtractor(const HipORBExtractor&) = delete;
     HipORBExtractor& operator=(const HipORBExtractor&) = delete;
 
@@ -55,7 +61,7 @@ public:
                     std::vector<FeatureDescriptor>& descriptors) override {
         cv::Mat image = _image.getMat();
         if (image.empty()) return;
-        if (image.type() != 0) throw std::runtime_error("HipORBExtractor: image must be CV_8UC1");
+        if (image.type() != CV_8UC1) throw std::runtime_error("HipORBExtractor: image must be CV_8UC1");
         int32_t n = 0;
         int st = hs_orb_extract(h, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(), cap, &n);
         if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
@@ -67,7 +73,7 @@ public:
             k.pt.x = kps[i].x; k.pt.y = kps[i].y; k.size = kps[i].size; k.angle = kps[i].angle;
             k.response = kps[i].response; k.octave = kps[i].octave; k.class_id = -1;
             _keypoints.push_back(k);
-            descriptors.push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, desc.data() + (size_t)i * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
+            descriptors.push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + (size_t)i * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
         }
     }
     int GetLevels() override { return hs_orb_get_levels(h); }
@@ -92,9 +98,20 @@ private:
     std::shared_ptr<DescriptorDistance> dist_func;
 };
 
-// Stereomatcher (src/features/Stereomatcher.h:25-51) over flat arrays: construct, computeStereoMatches(), getData().
+// Stereomatcher (src/features/Stereomatcher.h:25-51): the reference's constructor (FeatureViews, Camera, FeatureMatcherSettings),
+// computeStereoMatches(), getData(...) — src/main/ImageProcessing.cpp:100-103 compiles unchanged against it.
+// The reference constructor carries no device handle, so the matcher runs on a process-wide handle created on first use (device 0 or
+// HipStereomatcher::setDefaultDevice); calls are serialised by a mutex (a handle is thread-compatible, and ImageProcessing calls from one thread).
 class HipStereomatcher {
 public:
+    HipStereomatcher(FeatureViews views, Camera cam_data, FeatureMatcherSettings settings) : h(nullptr) {
+        // what Stereomatcher::Stereomatcher reads (src/features/Stereomatcher.cpp:7-24)
+        const FeatureExtractorSettings orb_params = views.orbParams();
+        sp.fx = cam_data.fx(); sp.mbf = cam_data.mbf; sp.n_rows = (int)cam_data.mnMaxY;
+        sp.th_high = settings.TH_HIGH; sp.th_low = settings.TH_LOW; sp.size_ref = orb_params.size_ref;
+        gather(views.getKeys(), views.getDescriptors(), kL, dL); gather(views.getKeysR(), views.getDescriptorsR(), kR, dR);
+    }
+    // explicit-handle form (tests, callers that own an extractor on another device)
     HipStereomatcher(hs_orb* handle, const std::vector<cv::KeyPoint>& keys, const std::vector<cv::KeyPoint>& keysR,
                      const std::vector<FeatureDescriptor>& descs, const std::vector<FeatureDescriptor>& descsR,
                      float fx, float mbf, float mnMaxY, FeatureMatcherSettings settings, float size_ref = 31.f)
@@ -104,12 +121,28 @@ public:
     }
     void computeStereoMatches() {
         mvuRight.assign(kL.size(), -1.0f); mvDepth.assign(kL.size(), -1.0f);
-        int st = hs_stereo_match(h, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
+        std::unique_lock<std::mutex> lock(shared_mutex(), std::defer_lock);
+        hs_orb* use = h;
+        if (!use) { lock.lock(); use = shared_handle(); }
+        int st = hs_stereo_match(use, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
         if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
     }
     void getData(std::vector<float>& mvuRight_, std::vector<float>& mvDepth_) { mvuRight_ = mvuRight; mvDepth_ = mvDepth; }
+    void getData(FeatureViews& views) { views.setuRs(mvuRight); views.setDepths(mvDepth); }       // Stereomatcher.cpp:31-34
+    static void setDefaultDevice(int device) { default_device() = device; }
 
 private:
+    static int& default_device() { static int d = 0; return d; }
+    static std::mutex& shared_mutex() { static std::mutex m; return m; }
+    static hs_orb* shared_handle() {                     // caller holds shared_mutex()
+        static hs_orb* hh = nullptr;
+        if (!hh) {
+            hs_orb_params p; hs_orb_default_params(&p);
+            int st = hs_orb_create(&p, default_device(), &hh);
+            if (st != HS_OK) { hh = nullptr; throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st)); }
+        }
+        return hh;
+    }
     static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) {
         ok.resize(k.size()); od.resize(k.size() * HS_DESC_BYTES);
         for (size_t i = 0; i < k.size(); i++) {

@@ -183,6 +183,8 @@ typedef struct hs_proj_params {
     float   reproj_threshold;          /* 5.99                                                          */
     float   sigma_ref;                 /* FeatureExtractorSettings::sigma_ref (1.0), determineSigma2    */
     int32_t first_wins;                /* Fuse: the first landmark that matched a keypoint keeps it (:515) */
+    int32_t dist_is_invariance_range;  /* 1: hs_landmark::min_dist / max_dist already hold GetMinDistanceInvariance() / GetMaxDistanceInvariance()
+                                          (= 0.8f*mfMinDistance, 1.2f*mfMaxDistance, MapPoint.cc:139-149) — what a hySLAM adaptor can read */
 } hs_proj_params;
 
 /* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria of SearchByProjection(Frame, MapPoints, th)

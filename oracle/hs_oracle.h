@@ -177,6 +177,7 @@ typedef struct hso_proj_params {
     float   reproj_threshold;          /* 5.99 */
     float   sigma_ref;                 /* FeatureExtractorSettings::sigma_ref (1.0) for determineSigma2 */
     int32_t first_wins;                /* Fuse: fuse_matches.insert(idx, lm) keeps the FIRST landmark that matched a keypoint (:515) */
+    int32_t dist_is_invariance_range;  /* 1: min_dist / max_dist already carry the 0.8 / 1.2 factors (GetMin/MaxDistanceInvariance()) */
 } hso_proj_params;
 
 /* FeatureMatcher::_SearchByProjection_ (FeatureMatcher.cc:57-121) with the criteria lists of the three Frame variants

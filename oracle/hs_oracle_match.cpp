@@ -184,7 +184,8 @@ int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, i
             const hso_landmark& lm = lms[i];
             float PO[3] = { lm.pos[0] - F->Ow[0], lm.pos[1] - F->Ow[1], lm.pos[2] - F->Ow[2] };
             const float lm_dist = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);   // cv::norm: double accumulation
-            const float maxDistance = 1.2f * lm.max_dist, minDistance = 0.8f * lm.min_dist;                                   // MapPoint.cc:139-149
+            const float maxDistance = pp->dist_is_invariance_range ? lm.max_dist : 1.2f * lm.max_dist;                       // MapPoint.cc:139-149
+            const float minDistance = pp->dist_is_invariance_range ? lm.min_dist : 0.8f * lm.min_dist;
             if (lm_dist < minDistance || lm_dist > maxDistance) continue;
             passed.push_back(i);
         }

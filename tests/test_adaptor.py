@@ -1,19 +1,23 @@
-"""The header-only C++ adaptor (hyslam_amd/host/HipORBExtractor.h: FeatureExtractor / Stereomatcher call surface over the
-C ABI) compiled against host/cv_compat.h and run like ImageProcessing::ProcessStereoImage uses it."""
+"""The header-only C++ adaptors (hyslam_amd/host/: FeatureExtractor / Stereomatcher / FeatureMatcher / FeatureFactory call surface over the
+C ABI) compiled against host/cv_compat.h and run like hySLAM's call sites use them (ImageProcessing::ProcessStereoImage, TrackLocalMap,
+TrackMotionModel, TrackReferenceKeyFrame, LandMarkFuser)."""
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cpp", "_build", "test_adaptor")
+BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
+EXE = os.path.join(BUILD, "test_adaptor")
+EXE_M = os.path.join(BUILD, "test_matcher_adaptor")
 
 
-def build():
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+def build(src="test_adaptor.cpp", exe=EXE):
+    os.makedirs(BUILD, exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_adaptor.cpp"), "-o", EXE,
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "cpp", src), "-o", exe,
                            "-L" + os.path.join(ROOT, "hyslam_amd"), "-lhyslam_amd", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lhs_oracle",
                            "-Wl,-rpath," + os.path.join(ROOT, "hyslam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_build")])
 
@@ -24,6 +28,28 @@ def run():
     return subprocess.run([EXE, "640", "480"], input=L.tobytes() + R.tobytes(), capture_output=True, timeout=300)
 
 
+def write_scene(path):
+    """a tracking scene (tests/scenes.py) in the flat layout tests/cpp/test_matcher_adaptor.cpp reads"""
+    import scenes
+    sc = scenes.projection_scene(71, 640, 480, nfeat=1000, copies=3)
+    fa, lms = sc["frame_args"], sc["lms"]
+    with open(path, "wb") as f:
+        np.array([len(fa["kps"]), len(lms), fa["sensor"], 640, 480, 0, 0, 0], np.int32).tofile(f)
+        np.concatenate([np.asarray(fa["Rcw"], np.float32).reshape(-1), np.asarray(fa["tcw"], np.float32),
+                        np.array([fa["fx"], fa["fy"], fa["cx"], fa["cy"], fa["mbf"]], np.float32)]).tofile(f)
+        np.ascontiguousarray(fa["kps"]).tofile(f)
+        np.ascontiguousarray(fa["desc"], np.uint8).tofile(f)
+        np.ascontiguousarray(fa["uR"], np.float32).tofile(f)
+        np.ascontiguousarray(fa["kp_lm_obs"], np.int32).tofile(f)
+        np.ascontiguousarray(lms).tofile(f)
+
+
+def run_matcher():
+    scene = os.path.join(BUILD, "scene.bin")
+    write_scene(scene)
+    return subprocess.run([EXE_M, scene], capture_output=True, timeout=600)
+
+
 def test_adaptor_compiles_and_fails_loudly_without_gpu():
     build()
     r = run()
@@ -31,8 +57,24 @@ def test_adaptor_compiles_and_fails_loudly_without_gpu():
     assert b"NO DEVICE" in r.stdout or b"ADAPTOR OK" in r.stdout
 
 
+def test_matcher_adaptor_and_factory_compile_and_fail_loudly_without_gpu():
+    build("test_matcher_adaptor.cpp", EXE_M)
+    r = run_matcher()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert b"NO DEVICE" in r.stdout or b"MATCHER ADAPTOR OK" in r.stdout
+
+
 @pytest.mark.gpu
 def test_adaptor_bit_exact_on_gpu(gpu):
     build()
     r = run()
     assert r.returncode == 0 and b"ADAPTOR OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_matcher_adaptor_replays_associations_in_address_order_on_gpu(gpu):
+    """HipORBFactory -> unique_ptr<FeatureMatcher> -> HipFeatureMatcher: gather -> C ABI -> associateLandMark replay (D6: address-sorted
+    landmarks) == oracle + reference-order replay; Fuse, SearchByBoW(KF, Frame) and the reference-signature Stereomatcher as well"""
+    build("test_matcher_adaptor.cpp", EXE_M)
+    r = run_matcher()
+    assert r.returncode == 0 and b"MATCHER ADAPTOR OK" in r.stdout, r.stdout + r.stderr
