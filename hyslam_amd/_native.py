@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhyslam_amd.so")
+# HYSLAM_AMD_LIB: development only — an instrumented build of the same sources (make BUILD=_build_prof OUT=../libhyslam_amd_prof.so EXTRA=-D...)
+LIB_PATH = os.environ.get("HYSLAM_AMD_LIB") or os.path.join(_HERE, "libhyslam_amd.so")
 
 HS_OK, HS_ERR_INVALID, HS_ERR_HIP, HS_ERR_CAPACITY, HS_ERR_NO_DEVICE = 0, 1, 2, 3, 4
 

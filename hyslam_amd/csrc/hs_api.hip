@@ -77,8 +77,10 @@ void mark(hs_orb* h, int stage, hipStream_t s)
     h->prof_stage.push_back(stage);
 }
 
-#define HIP_TRY(h, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) \
-    return fail(h, HS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+// a failed HIP call leaves its code in the runtime's sticky "last error": it is cleared here so that the next successful call sequence on this
+// thread does not report it again through hipGetLastError()
+#define HIP_TRY(h, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { (void)hipGetLastError(); \
+    return fail(h, HS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
 
 void free_geometry(hs_orb* h)
 {

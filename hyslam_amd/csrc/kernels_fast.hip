@@ -72,8 +72,10 @@ __device__ __forceinline__ int fast_corner_score(const int (&d)[16])
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
 __device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ uint32_t lane_from_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }  // wave_shr:1
-__device__ __forceinline__ uint32_t lane_from_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }  // wave_shl:1
+// bound_ctrl: the lane without a source (lane 0 / lane 63) reads 0 — a single v_mov_b32_dpp, no separate zero-initialisation of the result
+// (those lanes' outer pixels are apron columns and are masked out of the scan anyway)
+__device__ __forceinline__ uint32_t lane_from_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true); }  // wave_shr:1
+__device__ __forceinline__ uint32_t lane_from_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true); }  // wave_shl:1
 
 // Quick reject of 2 pixels held in the HIGH bytes of the two 16-bit fields (low bytes: anything).  Exact condition:
 // (r0 or r8 darker than v-t) and (r4 or r12 darker), or the same for brighter.  Garbage in the low bytes can only add
