@@ -189,7 +189,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
     uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
     uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
-    uint32_t* const ovf = overflow + (size_t)blockIdx.x * overflow_stride;       // this wave's spill area for scored corners (list overflow only)
+    uint32_t* const queue = overflow;                                            // 8 work counters, 128 bytes apart (HS_FAST_QUEUE_DWORDS)
+    uint32_t* const ovf = overflow + HS_FAST_QUEUE_DWORDS + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
     const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
     const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
 
@@ -202,17 +203,48 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     constexpr int RO[16] = { 3 * PITCH + 0, 3 * PITCH + 1, 2 * PITCH + 2, 1 * PITCH + 3, 0 * PITCH + 3, -1 * PITCH + 3, -2 * PITCH + 2, -3 * PITCH + 1,
                              -3 * PITCH + 0, -3 * PITCH - 1, -2 * PITCH - 2, -1 * PITCH - 3, 0 * PITCH - 3, 1 * PITCH - 3, 2 * PITCH - 2, 3 * PITCH - 1 };
 
-    // Work distribution: the item list is cut into 8 contiguous ranges, one per XCD (blockIdx % 8); the waves of an XCD walk their
-    // range in lock-step strides, so at any time an XCD works on ~nblk/8 neighbouring items (shared apron lines hit in its L2) while
-    // every wave's items are spread over all levels and image regions.  Corner-rich regions cost several times more than flat ones:
-    // contiguous per-wave ranges left the average wave idle for ~40 % of the kernel.  Dynamic alternatives were measured slower: one atomic
-    // work counter per XCD serialises (2816 waves on 8 addresses); one counter per group of 11 waves (256 groups, a cache line each, the
-    // grab for the item after next in flight during the current one) gave 0.275 ms against 0.240 ms for these static strides, although
-    // single-wave workgroups land 3,3,3,2 on a CU's four SIMDs and 11.05 items per wave round up to 12.
+    // Work distribution: the item list is cut into 8 contiguous ranges, one per queue (home queue = blockIdx % 8, i.e. the waves that share
+    // an XCD under round-robin placement, so that neighbouring items — shared apron lines — meet in one L2; placement is a speed
+    // matter only).  A wave takes its FIRST item statically (range start + its rank among the queue's waves) and every further item from
+    // the queue's atomic counter: corner-rich items cost several times more than flat ones, and with static strides the slowest of the
+    // 2816 waves (5 items each) set the kernel time while the average wave idled for a third of it (SQ counters: 68 % VALU issue, 27 % of
+    // wave cycles waiting).  The grab for the item after next is issued right after the next tile's prefetch and consumed an item later,
+    // so its latency is never exposed; 8 counters on lines of their own see ~11 grabs/us each.  When a queue runs dry its waves steal
+    // from the other queues, and leave when all eight are empty (every wave reaches that exit: the counters only grow).
+    // The counters are zeroed by the launcher (a 1 KB hipMemsetAsync ahead of the kernel, only for launches with more items than waves).
     const int per_x = (total_work + 7) >> 3, wpx = gridDim.x >> 3;
-    const int x_end = min(total_work, ((int)(blockIdx.x & 7) + 1) * per_x);
-    int w = (int)(blockIdx.x & 7) * per_x + (int)(blockIdx.x >> 3);
-    if (w >= x_end) return;
+    int q = (int)(blockIdx.x & 7);                               // current queue (wave-uniform)
+    auto q_size = [&](int qq) { return min(max(total_work - qq * per_x, 0), per_x); };
+    // one lane asks; the value comes back in a VGPR and is only read (readfirstlane) an item later
+    auto grab_async = [&](int qq) -> uint32_t {
+        uint32_t v = 0;
+        if (tid == 0) v = atomicAdd(&queue[qq * 32], 1u);
+        return v;
+    };
+    // raw counter value -> work unit, stealing from the other queues when the home queue is exhausted; -1 = nothing left anywhere.
+    // A thief first LOOKS at all eight counters with one load (lanes 0..7; plain loads do not serialise like atomics) and only then grabs
+    // from the fullest queue: at the end of a launch thousands of waves would otherwise queue up failing atomics on eight addresses.
+    const bool dynamic = wpx < per_x;                            // fewer items than waves: the static first items are the whole job
+    auto resolve = [&](uint32_t raw) -> int {
+        if (!dynamic) return -1;
+        int idx = (int)__builtin_amdgcn_readfirstlane(raw) + wpx;
+        if (idx < q_size(q)) return q * per_x + idx;
+        for (int tries = 0; tries < 8; tries++) {
+            int rem = 0;
+            if (tid < 8) rem = q_size(tid) - wpx - (int)__hip_atomic_load(&queue[tid * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int best = 0, best_q = -1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int r = __builtin_amdgcn_readlane(rem, i); if (r > best) { best = r; best_q = i; } }
+            if (best_q < 0) return -1;
+            q = best_q;
+            idx = (int)__builtin_amdgcn_readfirstlane(grab_async(q)) + wpx;      // synchronous: only at the very end of the launch
+            if (idx < q_size(q)) return q * per_x + idx;
+        }
+        return -1;
+    };
+    int w = (int)(blockIdx.x >> 3) < q_size(q) ? q * per_x + (int)(blockIdx.x >> 3) : (dynamic ? resolve(grab_async(q)) : -1);
+    if (w < 0) return;
+    uint32_t raw_next = dynamic ? grab_async(q) : 0u;            // the second item
 
     if (tid < FR_MAXG) cellcnt[tid] = 0;
 
@@ -243,12 +275,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     };
     prefetch(g);
 
-    for (; w < x_end; w += wpx) {
-        const int w_next = w + wpx < x_end ? w + wpx : -1;
+    for (; w >= 0;) {
         int32_t* const cnt_out = &cell_count[(size_t)g.img * total_cells + g.gcell0];
         if (!g.valid) {
             if (tid < g.ncell) cnt_out[tid] = 0;
-            if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); }
+            w = resolve(raw_next);
+            if (w >= 0) { g = row_geom(items, img0, items_per_img, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
             continue;
         }
         // ---- stage the tile
@@ -263,7 +295,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         const RowGeom cur = g;
         const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1, ccap = cur.ccap;
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
-        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); }   // in flight during the passes
+        // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
+        const int w_next = resolve(raw_next);
+        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
         FR_T(t2);
         FR_ACC(1, t1, t2);
 
@@ -491,6 +525,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         fr_acc[8] += 1;
         fr_acc[3] += n_ovf > 0;
 #endif
+        w = w_next;
     }
 #ifdef HS_FAST_PROFILE
     FR_T(t_kernel1);
@@ -601,7 +636,7 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
-    return (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
+    return (size_t)HS_FAST_QUEUE_DWORDS * 4 + (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
 }
 
 static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
@@ -615,6 +650,7 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return;
     const int nblk = fast_rows_grid(c, total_work);
+    if (total_work > nblk) (void)hipMemsetAsync(overflow, 0, HS_FAST_QUEUE_DWORDS * 4, s);      // work-queue counters (dynamic launches only)
     const int force_scan_b = knobs.force_scan_b;
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)

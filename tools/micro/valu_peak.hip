@@ -31,6 +31,24 @@ __global__ __launch_bounds__(64) void k_issue(uint32_t* out, unsigned long long*
             if (OP == 9) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(x));
             if (OP == 10) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(x) : "v"(c));
             if (OP == 11) asm volatile("v_dot2_u32_u16 %0, %0, %1, %0" : "+v"(x) : "v"(c));
+            if (OP == 12) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 13) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 14) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 15) asm volatile("v_lshrrev_b32 %0, 2, %0" : "+v"(x));
+            if (OP == 16) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xa8" : "+v"(x) : "v"(c), "v"(r[(k + 1) & 15]));
+            if (OP == 17) asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(x) : "v"(c));
+            if (OP == 18) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(r[(k + 1) & 15]));
+            if (OP == 19) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(r[(k + 1) & 15]));
+            if (OP == 20) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 21) asm volatile("v_add_u32 %0, %0, %1\n v_pk_min_u16 %2, %2, %1" : "+v"(x), "+v"(r[(k + 8) & 15]) : "v"(c));
+            if (OP == 22) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 23) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(x) : "v"(c));
+            if (OP == 24) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(x) : "v"(c));
+            if (OP == 25) asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(c), "v"(r[(k + 1) & 15]));
+            if (OP == 26) asm volatile("v_min_i32 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 27) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 28) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(c));
+            if (OP == 29) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(c));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -43,7 +61,7 @@ __global__ __launch_bounds__(64) void k_issue(uint32_t* out, unsigned long long*
 
 template <int OP> void run(const char* name, uint32_t* d_out, unsigned long long* d_cyc)
 {
-    for (int wps : {1, 2, 3, 4, 8}) {
+    for (int wps : {1, 3, 4}) {
         const int nblk = 256 * 4 * wps;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k_issue<OP>, dim3(nblk), dim3(64), 0, 0, d_out, d_cyc);
@@ -77,5 +95,23 @@ int main()
     run<9>("v_bfe_u32", d_out, d_cyc);
     run<10>("v_pk_max_u16", d_out, d_cyc);
     run<11>("v_dot2_u32_u16", d_out, d_cyc);
+    run<12>("v_sub_u32", d_out, d_cyc);
+    run<13>("v_and_b32", d_out, d_cyc);
+    run<14>("v_or_b32", d_out, d_cyc);
+    run<15>("v_lshrrev_b32", d_out, d_cyc);
+    run<16>("v_bitop3_b32", d_out, d_cyc);
+    run<17>("v_lshl_or_b32", d_out, d_cyc);
+    run<18>("v_and_or_b32", d_out, d_cyc);
+    run<19>("v_add3_u32", d_out, d_cyc);
+    run<20>("v_xor_b32", d_out, d_cyc);
+    run<21>("v_add_u32+v_pk_min_u16 (x2)", d_out, d_cyc);
+    run<22>("v_pk_add_u16", d_out, d_cyc);
+    run<23>("v_sad_u8", d_out, d_cyc);
+    run<24>("v_alignbit_b32", d_out, d_cyc);
+    run<25>("v_max3_u32", d_out, d_cyc);
+    run<26>("v_min_i32", d_out, d_cyc);
+    run<27>("v_pk_mul_lo_u16", d_out, d_cyc);
+    run<28>("v_mad_u32_u24", d_out, d_cyc);
+    run<29>("v_mul_u32_u24", d_out, d_cyc);
     return 0;
 }
