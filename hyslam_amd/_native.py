@@ -41,7 +41,7 @@ class FrameView(C.Structure):
 
 class VocabTree(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("levels", C.c_int32), ("child_begin", C.c_void_p), ("child_count", C.c_void_p),
-                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
+                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p), ("orig_id", C.c_void_p)]
 
 
 class ProjParams(C.Structure):
@@ -71,7 +71,9 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
-    "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
+    "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
+    "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
+    "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
     "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
@@ -118,11 +120,26 @@ def lib():
     L.hs_orb_synchronize.argtypes = [vp, vp]
     L.hs_search_by_projection.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
     L.hs_search_by_projection_device.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp, vp]
+    L.hs_search_by_projection_sim3.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.c_int, C.c_int, f32, vp, vp, vp]
+    L.hs_search_by_sim3.argtypes = [vp, C.POINTER(FrameView), vp, C.POINTER(FrameView), vp, f32, vp, vp, f32, f32, vp, vp]
     L.hs_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                    vp, f32, f32, C.c_int, vp, vp]
     L.hs_search_by_bow_ex.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                       vp, vp, vp, f32, f32, f32, f32, C.c_int, vp, vp]
     L.hs_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FrameView), vp, C.c_int, f32, f32, vp, vp]
+    L.hs_vocab_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.hs_vocab_from_tree.argtypes = [C.POINTER(VocabTree), C.c_int, C.POINTER(vp)]
+    L.hs_vocab_save.argtypes = [vp, C.c_char_p]
+    L.hs_vocab_destroy.argtypes = [vp]
+    L.hs_vocab_destroy.restype = None
+    L.hs_vocab_get_tree.argtypes = [vp, C.POINTER(VocabTree)]
+    L.hs_vocab_info.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.hs_vocab_upload.argtypes = [vp, C.POINTER(VocabTree), C.c_int, C.POINTER(vp)]
+    L.hs_vocab_dev_destroy.argtypes = [vp]
+    L.hs_vocab_dev_destroy.restype = None
+    L.hs_vocab_dev_groups.argtypes = [vp]
+    L.hs_bow_transform_device.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.hs_records_bow_match_device.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, C.c_int, f32, f32, C.c_int, vp, vp, vp]
     L.hs_bow_transform.argtypes = [vp, C.POINTER(VocabTree), vp, C.c_int, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     L.hs_hamming_knn2_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]

@@ -323,6 +323,11 @@ void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32
 
 } // namespace
 
+// accessors for the other translation units of the library (kernels_bow.hip)
+void hs_set_error(hs_orb* h, const char* msg) { if (h) h->err = msg ? msg : ""; }
+int hs_orb_device_of(const hs_orb* h) { return h ? h->device : 0; }
+hipStream_t hs_orb_stream_of(const hs_orb* h) { return h ? h->stream : nullptr; }
+
 extern "C" {
 
 const char* hs_version(void) { return HS_VERSION; }
@@ -723,6 +728,101 @@ int hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_l
     return HS_OK;
 }
 
+namespace {
+// uploads what the Sim3 matchers read of a keyframe and builds its grid lists; returns the carved device pointers
+struct DevFrame { hs_keypoint* kps; uint8_t* desc; int8_t* cell; };
+int upload_frame(hs_orb* h, const hs_frame_view* F, hipStream_t s, DevFrame* o)
+{
+    const size_t nn = (size_t)std::max(F->n, 1);
+    o->kps = carve<hs_keypoint>(h, nn); o->desc = carve<uint8_t>(h, nn * 32); o->cell = carve<int8_t>(h, hs_frame_grid_bytes((int)nn));
+    if (F->n > 0) {
+        HIP_TRY(h, hipMemcpyAsync(o->kps, F->kps, (size_t)F->n * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(o->desc, F->desc, (size_t)F->n * 32, hipMemcpyHostToDevice, s));
+        hs_launch_frame_grid(*F, o->kps, o->cell, true, s);
+    }
+    return HS_OK;
+}
+size_t frame_bytes(int n) { const size_t nn = (size_t)std::max(n, 1); return pad256(nn * sizeof(hs_keypoint)) + pad256(nn * 32) + pad256(hs_frame_grid_bytes((int)nn)); }
+// one row of A*B (+c): double accumulation, alpha in double, one rounding (cv::gemm on float matrices)
+float gemm3h(const float* A, const float* B, float c, double alpha = 1.0)
+{
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)A[k] * (double)B[k];
+    return (float)(alpha * s + (double)c);
+}
+}
+
+int hs_search_by_projection_sim3(hs_orb* h, const hs_frame_view* KF, const float* Scw, const hs_landmark* lms, int L, int th, float th_low,
+                                 uint8_t* kp_matched, int32_t* match_idx, int32_t* n_matches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!KF || !Scw || L < 0 || !n_matches || (L > 0 && (!lms || !match_idx)) || KF->n < 0 || KF->n > 65535 || (KF->n > 0 && (!KF->kps || !KF->desc || !kp_matched)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_matches = 0;
+    for (int i = 0; i < L; i++) match_idx[i] = -1;
+    if (L == 0 || KF->n == 0) return HS_OK;
+    // Decompose Scw like the reference (FeatureMatcher.cc:641-646): scw = |row 0| (double accumulation), Rcw = sRcw/scw and tcw = t/scw are
+    // cv::Mat scalings (every element times (float)(1/scw) in float), Ow = -Rcw.t()*tcw one gemm
+    float R[9], t[3], Ow[3];
+    const float scw = (float)std::sqrt((double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2]);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[3 * r + c] = Scw[4 * r + c] * inv + 0.0f; t[r] = Scw[4 * r + 3] * inv + 0.0f; }
+    for (int i = 0; i < 3; i++) { const float col[3] = { R[i], R[3 + i], R[6 + i] }; Ow[i] = gemm3h(col, t, 0.f, -1.0); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = scratch_begin(h, frame_bytes(KF->n) + pad256((size_t)L * sizeof(hs_landmark)) + pad256((size_t)L * 12) + pad256((size_t)KF->n) + pad256((size_t)L * 4) + 512);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    DevFrame D; rc = upload_frame(h, KF, s, &D);
+    if (rc != HS_OK) return rc;
+    hs_landmark* d_lms = carve<hs_landmark>(h, L); float* d_geo = carve<float>(h, (size_t)L * 3);
+    uint8_t* d_taken = carve<uint8_t>(h, KF->n); int32_t* d_midx = carve<int32_t>(h, L); int32_t* d_n = carve<int32_t>(h, 1);
+    HIP_TRY(h, hipMemcpyAsync(d_lms, lms, (size_t)L * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_taken, kp_matched, KF->n, hipMemcpyHostToDevice, s));
+    hs_launch_sim3_projection(*KF, D.kps, D.desc, D.cell, R, t, Ow, d_lms, L, (float)th, th_low, d_geo, d_taken, d_midx, d_n, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(match_idx, d_midx, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(kp_matched, d_taken, KF->n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_matches, d_n, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
+int hs_search_by_sim3(hs_orb* h, const hs_frame_view* KF1, const hs_landmark* lms1, const hs_frame_view* KF2, const hs_landmark* lms2,
+                      float s12, const float* R12, const float* t12, float th, float th_high, int32_t* match12, int32_t* n_found)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!KF1 || !KF2 || !R12 || !t12 || !n_found || KF1->n < 0 || KF2->n < 0 || KF1->n > 65535 || KF2->n > 65535 ||
+        (KF1->n > 0 && (!KF1->kps || !KF1->desc || !lms1 || !match12)) || (KF2->n > 0 && (!KF2->kps || !KF2->desc || !lms2)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_found = 0;
+    for (int i = 0; i < KF1->n; i++) match12[i] = -1;
+    if (KF1->n == 0 || KF2->n == 0) return HS_OK;
+    // Transformation between cameras (FeatureMatcher.cc:757-760): sR12 = s12*R12, sR21 = (1/s12)*R12.t() (cv::Mat scalings), t21 = -sR21*t12 (gemm)
+    float sR12[9], sR21[9], t21[3];
+    const float a12 = (float)(double)s12, a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12[3 * r + c] = R12[3 * r + c] * a12 + 0.0f; sR21[3 * r + c] = R12[3 * c + r] * a21 + 0.0f; }
+    for (int i = 0; i < 3; i++) t21[i] = gemm3h(&sR21[3 * i], t12, 0.f, -1.0);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n1 = KF1->n, n2 = KF2->n;
+    int rc = scratch_begin(h, frame_bytes(n1) + frame_bytes(n2) + pad256((size_t)n1 * sizeof(hs_landmark)) + pad256((size_t)n2 * sizeof(hs_landmark)) +
+                              2 * pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4) + 512);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    DevFrame D1, D2;
+    rc = upload_frame(h, KF1, s, &D1); if (rc != HS_OK) return rc;
+    rc = upload_frame(h, KF2, s, &D2); if (rc != HS_OK) return rc;
+    hs_landmark* d_l1 = carve<hs_landmark>(h, n1); hs_landmark* d_l2 = carve<hs_landmark>(h, n2);
+    int32_t* d_m1 = carve<int32_t>(h, n1); int32_t* d_m12 = carve<int32_t>(h, n1); int32_t* d_m2 = carve<int32_t>(h, n2); int32_t* d_n = carve<int32_t>(h, 1);
+    HIP_TRY(h, hipMemcpyAsync(d_l1, lms1, (size_t)n1 * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_l2, lms2, (size_t)n2 * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
+    hs_launch_sim3_search(*KF1, D1.kps, D1.desc, D1.cell, *KF2, D2.kps, D2.desc, D2.cell, d_l1, d_l2, sR21, t21, sR12, t12, th, th_high, d_m1, d_m2, d_m12, d_n, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(match12, d_m12, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_found, d_n, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
 int hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
                      const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
                      const hs_keypoint* kps2, const uint8_t* desc2, int n2,
@@ -869,6 +969,7 @@ int hs_bow_transform(hs_orb* h, const hs_vocab_tree* T, const uint8_t* desc, int
     HIP_TRY(h, hipMemcpyAsync(weight, o_wt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(node_id, o_n, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (T->orig_id) for (int i = 0; i < n; i++) node_id[i] = T->orig_id[node_id[i]];      // renumbered vocabulary: report DBoW2's NodeId
     return HS_OK;
 }
 

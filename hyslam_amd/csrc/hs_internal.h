@@ -161,6 +161,13 @@ void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs
                    int32_t* d_match12, int n1, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle2_scratch,
                    int check_rotation, int32_t* d_self_scratch, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
+void hs_launch_sim3_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const int8_t* d_cell,
+                               const float* R9, const float* t3, const float* Ow3, const hs_landmark* d_lms, int L, float th, float th_low,
+                               float* d_geo, uint8_t* d_kp_matched, int32_t* d_match_idx, int32_t* d_n_matches, hipStream_t s);
+void hs_launch_sim3_search(const hs_frame_view& F1, const hs_keypoint* d_kps1, const uint8_t* d_desc1, const int8_t* d_cell1,
+                           const hs_frame_view& F2, const hs_keypoint* d_kps2, const uint8_t* d_desc2, const int8_t* d_cell2,
+                           const hs_landmark* d_lms1, const hs_landmark* d_lms2, const float* sR21, const float* t21, const float* sR12, const float* t12,
+                           float th, float th_high, int32_t* d_m1, int32_t* d_m2, int32_t* d_match12, int32_t* d_n_found, hipStream_t s);
 void hs_launch_knn2_records(const uint8_t* d_recs, size_t stride, int world, int rank, int cap, size_t off_desc,
                             int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);

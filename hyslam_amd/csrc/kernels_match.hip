@@ -81,7 +81,18 @@ __global__ __launch_bounds__(1024) void k_frame_grid_lists(int n, const int8_t* 
     }
 }
 
-// Frame::ProjectLandMark + Camera::Project.  uv = (u, v, ur); returns validity.
+// one row of a cv::Mat product A*B (+ C): float inputs, double accumulation, alpha applied in double, one rounding to float (cv::gemm)
+__device__ __forceinline__ float gemm3(const float* A, float b0, float b1, float b2, float c, double alpha = 1.0)
+{
+    double s = 0.0;
+    s = __dadd_rn(s, __dmul_rn((double)A[0], (double)b0));
+    s = __dadd_rn(s, __dmul_rn((double)A[1], (double)b1));
+    s = __dadd_rn(s, __dmul_rn((double)A[2], (double)b2));
+    return (float)__dadd_rn(__dmul_rn(alpha, s), (double)c);
+}
+// Camera::Project(Pc, uv) (Camera.cpp:116-153) on a point in camera coordinates.  uv = (u, v, ur); returns validity.
+__device__ __forceinline__ bool cam_project(const HsFrameDev& F, const float* Pc, float& u, float& v, float& ur);
+// Frame::ProjectLandMark + Camera::Project.
 __device__ __forceinline__ bool project(const HsFrameDev& F, float px, float py, float pz, float& u, float& v, float& ur)
 {
     float Pc[3];
@@ -93,6 +104,10 @@ __device__ __forceinline__ bool project(const HsFrameDev& F, float px, float py,
         s = __dadd_rn(s, __dmul_rn((double)F.Rcw[3 * i + 2], (double)pz));
         Pc[i] = (float)__dadd_rn(s, (double)F.tcw[i]);
     }
+    return cam_project(F, Pc, u, v, ur);
+}
+__device__ __forceinline__ bool cam_project(const HsFrameDev& F, const float* Pc, float& u, float& v, float& ur)
+{
     const float PcZ = Pc[2];
     const float invz = __fdiv_rn(1.0f, PcZ);
     const float hx = __fdiv_rn(Pc[0], PcZ), hy = __fdiv_rn(Pc[1], PcZ), hz = __fdiv_rn(Pc[2], PcZ);
@@ -425,6 +440,144 @@ __global__ __launch_bounds__(256) void k_knn2_records(const uint8_t* __restrict_
     knn2_wave(recs + (size_t)rank * stride + off_desc, i, recs + (size_t)peer * stride + off_desc, nt, best_idx + o, best_dist + o, second_dist + o);
 }
 
+// ---------------------------------------------------------------- legacy loop-closing matchers (FeatureMatcher.cc:628-934)
+// landMarkSizePixels of a landmark in frame F (projects with F's OWN pose — also in the Sim3 variants, KeyFrame.cc:258-279)
+__device__ __forceinline__ float landmark_size_px(const HsFrameDev& F, const hs_landmark& lm)
+{
+    if (lm.assoc_kp >= 0) return F.kps[lm.assoc_kp].size;
+    const float half = __fdiv_rn(lm.size, 2.0f);
+    float ul, vl, url, u2, v2, ur2;
+    project(F, __fsub_rn(lm.pos[0], half), lm.pos[1], lm.pos[2], ul, vl, url);
+    project(F, __fadd_rn(lm.pos[0], half), lm.pos[1], lm.pos[2], u2, v2, ur2);
+    return __fsub_rn(u2, ul);
+}
+// best Hamming over GetFeaturesInArea(u, v, r) in the reference's candidate order (first minimum wins), skipping keypoints whose bit is set in
+// `taken` (LDS bitmask, may be null).  Wave-wide; returns the key dist<<32 | cellx<<22 | celly<<16 | idx or NO_KEY.
+__device__ __forceinline__ unsigned long long best_in_area(const HsFrameDev& F, float u, float v, float r, const uint8_t* desc32, const uint32_t* taken)
+{
+    const int lane = threadIdx.x & 63;
+    const float invW = (float)GRID_COLS / (F.max_x - F.min_x), invH = (float)GRID_ROWS / (F.max_y - F.min_y);
+    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(u, F.min_x), r), invW)));
+    const int maxCX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(u, F.min_x), r), invW)));
+    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(v, F.min_y), r), invH)));
+    const int maxCY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(v, F.min_y), r), invH)));
+    unsigned long long best = NO_KEY;
+    if (minCX >= GRID_COLS || maxCX < 0 || minCY >= GRID_ROWS || maxCY < 0) return best;
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(desc32);
+    const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
+    for (int cy = minCY; cy <= maxCY; cy++) {
+        const int a = F.cell_start[cy * GRID_COLS + minCX], b = F.cell_start[cy * GRID_COLS + maxCX + 1];
+        for (int t = a + lane; t < b; t += 64) {
+            const int i = F.cell_items[t];
+            const hs_keypoint kp = F.kps[i];
+            if (!(fabsf(__fsub_rn(kp.x, u)) < r && fabsf(__fsub_rn(kp.y, v)) < r)) continue;
+            if (taken && ((taken[i >> 5] >> (i & 31)) & 1u)) continue;
+            const unsigned long long* dk = reinterpret_cast<const unsigned long long*>(F.desc + (size_t)i * 32);
+            const int d = __popcll(l0 ^ dk[0]) + __popcll(l1 ^ dk[1]) + __popcll(l2 ^ dk[2]) + __popcll(l3 ^ dk[3]);
+            const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)F.cell[2 * i] << 22) | ((unsigned long long)cy << 16) | (unsigned)i;
+            best = min(best, key);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) best = min(best, (unsigned long long)__shfl_xor(best, s, 64));
+    return best;
+}
+
+struct HsSim3 { float R[9], t[3], Ow[3]; };        // decomposed on the host exactly like the reference does (launcher)
+
+// SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), phase A (parallel): everything that does not depend on vpMatched.
+// geo[li] = (u, v, radius) or radius < 0 when the landmark is rejected before the candidate search.
+__global__ __launch_bounds__(256) void k_sim3_project(HsFrameDev F, HsSim3 S, const hs_landmark* __restrict__ lms, int L, float th, float* __restrict__ geo)
+{
+    const int li = blockIdx.x * 256 + threadIdx.x;
+    if (li >= L) return;
+    const hs_landmark& lm = lms[li];
+    float u = 0.f, v = 0.f, radius = -1.f;
+    if (!lm.skip) {
+        const float z = gemm3(&S.R[6], lm.pos[0], lm.pos[1], lm.pos[2], S.t[2]);
+        if (!(z < 0.0f)) {
+            const float invz = __fdiv_rn(1.0f, z);
+            const float x = __fmul_rn(gemm3(&S.R[0], lm.pos[0], lm.pos[1], lm.pos[2], S.t[0]), invz);
+            const float y = __fmul_rn(gemm3(&S.R[3], lm.pos[0], lm.pos[1], lm.pos[2], S.t[1]), invz);
+            u = __fadd_rn(__fmul_rn(F.fx, x), F.cx); v = __fadd_rn(__fmul_rn(F.fy, y), F.cy);
+            if (u >= F.min_x && u < F.max_x && v >= F.min_y && v < F.max_y) {                   // KeyFrame::IsInImage
+                const float ox = __fsub_rn(lm.pos[0], S.Ow[0]), oy = __fsub_rn(lm.pos[1], S.Ow[1]), oz = __fsub_rn(lm.pos[2], S.Ow[2]);
+                const float dist = (float)sqrt(__dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)ox), __dmul_rn((double)oy, (double)oy)), __dmul_rn((double)oz, (double)oz)));
+                if (!(dist < lm.min_dist || dist > lm.max_dist)) {                                  // invariance range
+                    const double dot = __dadd_rn(__dadd_rn(__dmul_rn((double)ox, (double)lm.normal[0]), __dmul_rn((double)oy, (double)lm.normal[1])), __dmul_rn((double)oz, (double)lm.normal[2]));
+                    if (!(dot < __dmul_rn(0.5, (double)dist)))
+                        radius = __fdiv_rn(__fmul_rn(th, landmark_size_px(F, lm)), F.size_ref);
+                }
+            }
+        }
+    }
+    geo[3 * li] = u; geo[3 * li + 1] = v; geo[3 * li + 2] = radius;
+}
+// phase B (one wave, landmarks in order): best untaken keypoint in the area; a match takes its keypoint (vpMatched[bestIdx] = pMP, :731)
+__global__ __launch_bounds__(64) void k_sim3_assign(HsFrameDev F, const hs_landmark* __restrict__ lms, int L, const float* __restrict__ geo, float th_low,
+                                                    uint8_t* __restrict__ kp_matched, int32_t* __restrict__ match_idx, int32_t* __restrict__ n_matches)
+{
+    __shared__ uint32_t taken[2048];                                     // 65536 keypoints
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 2048; i += 64) taken[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < F.n; i += 64) if (kp_matched[i]) atomicOr(&taken[i >> 5], 1u << (i & 31));
+    __syncthreads();
+    int n = 0;
+    for (int li = 0; li < L; li++) {
+        const float r = geo[3 * li + 2];
+        int out = -1;
+        if (r >= 0.f) {                                                      // a negative or NaN radius finds no candidate in the reference either
+            const unsigned long long best = best_in_area(F, geo[3 * li], geo[3 * li + 1], r, lms[li].desc, taken);
+            if (best != NO_KEY && (float)(int)(best >> 32) <= th_low) {
+                out = (int)(best & 0xFFFF);
+                if (lane == 0) { taken[out >> 5] |= 1u << (out & 31); kp_matched[out] = 1; }
+                n++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                              // the LDS write above is visible to the next landmark's reads
+        }
+        if (lane == 0) match_idx[li] = out;
+    }
+    if (lane == 0) *n_matches = n;
+}
+
+// SearchBySim3, one direction: landmark of source keypoint i -> best keypoint of the destination keyframe (no exclusion, <= th_high)
+__global__ __launch_bounds__(256) void k_sim3_direction(HsFrameDev Fsrc, HsFrameDev Fdst, const hs_landmark* __restrict__ lms, int n, HsSim3 S /*sR, t*/,
+                                                        float th, float th_high, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (i >= n) return;
+    const hs_landmark& lm = lms[i];
+    int res = -1;
+    if (!lm.skip) {
+        float ps[3], pd[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ps[k] = gemm3(&Fsrc.Rcw[3 * k], lm.pos[0], lm.pos[1], lm.pos[2], Fsrc.tcw[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pd[k] = gemm3(&S.R[3 * k], ps[0], ps[1], ps[2], S.t[k]);
+        float u, v, ur;
+        if (cam_project(Fdst, pd, u, v, ur)) {
+            const float d3 = (float)sqrt(__dadd_rn(__dadd_rn(__dmul_rn((double)pd[0], (double)pd[0]), __dmul_rn((double)pd[1], (double)pd[1])), __dmul_rn((double)pd[2], (double)pd[2])));
+            if (!(d3 < lm.min_dist || d3 > lm.max_dist)) {
+                const float radius = __fdiv_rn(__fmul_rn(th, landmark_size_px(Fdst, lm)), Fdst.size_ref);
+                const unsigned long long best = best_in_area(Fdst, u, v, radius, lm.desc, nullptr);
+                if (best != NO_KEY && (float)(int)(best >> 32) <= th_high) res = (int)(best & 0xFFFF);
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) out[i] = res;
+}
+__global__ void k_sim3_agree(int n1, const int32_t* __restrict__ m1, const int32_t* __restrict__ m2, int32_t* __restrict__ match12, int32_t* __restrict__ n_found)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const int idx2 = m1[i];
+    const bool ok = idx2 >= 0 && m2[idx2] == i;
+    match12[i] = ok ? idx2 : -1;
+    if (ok) atomicAdd(n_found, 1);
+}
+
 // ---------------------------------------------------------------- launchers (declared in hs_internal.h)
 // d_cell: hs_frame_grid_bytes(n) bytes: [n][2] cells, then (with_lists) the cell lists read by hs_launch_search_projection
 size_t hs_frame_grid_bytes(int n) { return (((size_t)n * 2 + 15) & ~(size_t)15) + ((size_t)GRID_ROWS * GRID_COLS + 1) * 4 + (size_t)n * 2 + 16; }
@@ -514,6 +667,46 @@ void hs_launch_knn2(const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int3
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_knn2, dim3((nq + 3) / 4), dim3(256), 0, s, d_q, nq, d_t, nt, d_bi, d_bd, d_sd);
+}
+
+static HsFrameDev frame_dev(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const float* d_uR, const int32_t* d_obs, const int8_t* d_cell)
+{
+    HsFrameDev D{};
+    for (int i = 0; i < 9; i++) D.Rcw[i] = F.Rcw[i];
+    for (int i = 0; i < 3; i++) { D.tcw[i] = F.tcw[i]; D.Ow[i] = F.Ow[i]; }
+    D.fx = F.fx; D.fy = F.fy; D.cx = F.cx; D.cy = F.cy; D.mbf = F.mbf; D.sensor = F.sensor;
+    D.min_x = F.min_x; D.max_x = F.max_x; D.min_y = F.min_y; D.max_y = F.max_y; D.size_ref = F.size_ref; D.n = F.n;
+    D.kps = d_kps; D.desc = d_desc; D.uR = d_uR; D.kp_lm_obs = d_obs; D.cell = d_cell;
+    if (F.n > 0) {
+        const int32_t* start = grid_lists_start(const_cast<int8_t*>(d_cell), F.n);
+        D.cell_start = start; D.cell_items = reinterpret_cast<const uint16_t*>(start + GRID_ROWS * GRID_COLS + 1);
+    }
+    return D;
+}
+
+void hs_launch_sim3_projection(const hs_frame_view& F, const hs_keypoint* d_kps, const uint8_t* d_desc, const int8_t* d_cell,
+                               const float* R9, const float* t3, const float* Ow3, const hs_landmark* d_lms, int L, float th, float th_low,
+                               float* d_geo, uint8_t* d_kp_matched, int32_t* d_match_idx, int32_t* d_n_matches, hipStream_t s)
+{
+    const HsFrameDev D = frame_dev(F, d_kps, d_desc, nullptr, nullptr, d_cell);
+    HsSim3 S; for (int i = 0; i < 9; i++) S.R[i] = R9[i]; for (int i = 0; i < 3; i++) { S.t[i] = t3[i]; S.Ow[i] = Ow3[i]; }
+    hipLaunchKernelGGL(k_sim3_project, dim3((L + 255) / 256), dim3(256), 0, s, D, S, d_lms, L, th, d_geo);
+    hipLaunchKernelGGL(k_sim3_assign, dim3(1), dim3(64), 0, s, D, d_lms, L, d_geo, th_low, d_kp_matched, d_match_idx, d_n_matches);
+}
+
+void hs_launch_sim3_search(const hs_frame_view& F1, const hs_keypoint* d_kps1, const uint8_t* d_desc1, const int8_t* d_cell1,
+                           const hs_frame_view& F2, const hs_keypoint* d_kps2, const uint8_t* d_desc2, const int8_t* d_cell2,
+                           const hs_landmark* d_lms1, const hs_landmark* d_lms2, const float* sR21, const float* t21, const float* sR12, const float* t12,
+                           float th, float th_high, int32_t* d_m1, int32_t* d_m2, int32_t* d_match12, int32_t* d_n_found, hipStream_t s)
+{
+    const HsFrameDev D1 = frame_dev(F1, d_kps1, d_desc1, nullptr, nullptr, d_cell1), D2 = frame_dev(F2, d_kps2, d_desc2, nullptr, nullptr, d_cell2);
+    HsSim3 S21{}, S12{};
+    for (int i = 0; i < 9; i++) { S21.R[i] = sR21[i]; S12.R[i] = sR12[i]; }
+    for (int i = 0; i < 3; i++) { S21.t[i] = t21[i]; S12.t[i] = t12[i]; }
+    hipMemsetAsync(d_n_found, 0, 4, s);
+    if (F1.n > 0) hipLaunchKernelGGL(k_sim3_direction, dim3((F1.n + 3) / 4), dim3(256), 0, s, D1, D2, d_lms1, F1.n, S21, th, th_high, d_m1);
+    if (F2.n > 0) hipLaunchKernelGGL(k_sim3_direction, dim3((F2.n + 3) / 4), dim3(256), 0, s, D2, D1, d_lms2, F2.n, S12, th, th_high, d_m2);
+    if (F1.n > 0) hipLaunchKernelGGL(k_sim3_agree, dim3((F1.n + 255) / 256), dim3(256), 0, s, F1.n, d_m1, d_m2, d_match12, d_n_found);
 }
 
 void hs_launch_knn2_records(const uint8_t* d_recs, size_t stride, int world, int rank, int cap, size_t off_desc,

@@ -93,3 +93,63 @@ def cross_camera_knn2(extractor, gathered, rank, cap, stream=0, out=None):
                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stream)
     counts = gathered[:, :4].view(torch.int32).view(-1) if gathered.shape[1] % 4 == 0 else gathered[:, :4].contiguous().view(torch.int32).view(-1)
     return out, counts
+
+
+class DeviceVocabulary:
+    """A vocabulary tree resident in HBM (hs_vocab_upload): Frame::ComputeBoW and the BoW matcher run on device-resident descriptors."""
+
+    def __init__(self, extractor, tree, levelsup=4, keepalive=None):
+        import ctypes as C
+        from . import _native as N
+        self._ex, self._keep, self.levelsup = extractor, keepalive, levelsup
+        self._v = C.c_void_p()
+        N.check(extractor._h, extractor._lib.hs_vocab_upload(extractor._h, C.byref(tree), levelsup, C.byref(self._v)))
+        self.groups = extractor._lib.hs_vocab_dev_groups(self._v)
+
+    def transform_device(self, d_desc, d_n, n_max, d_word, d_weight, d_node, stream=0):
+        import ctypes as C
+        from . import _native as N
+        ex = self._ex
+        N.check(ex._h, ex._lib.hs_bow_transform_device(ex._h, self._v, C.c_void_p(d_desc), C.c_void_p(d_n) if d_n else None, n_max,
+                                                       C.c_void_p(d_word), C.c_void_p(d_weight), C.c_void_p(d_node), C.c_void_p(stream) if stream else None))
+
+    def records_bow_match_device(self, d_records, record_stride, world, rank, cap, thr, ratio, check_rotation, d_match12, d_n_matches, stream=0):
+        import ctypes as C
+        from . import _native as N
+        ex = self._ex
+        N.check(ex._h, ex._lib.hs_records_bow_match_device(ex._h, self._v, C.c_void_p(d_records), record_stride, world, rank, cap, thr, ratio,
+                                                           int(check_rotation), C.c_void_p(d_match12), C.c_void_p(d_n_matches),
+                                                           C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if getattr(self, "_v", None) is not None and self._v.value:
+            self._ex._lib.hs_vocab_dev_destroy(self._v)
+            self._v.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BowCrossCamera:
+    """bench.py --config c5 --c5-match bow: vocabulary transform + BoW-grouped matching of this rank's frame against every peer's, on the
+    gathered records, without leaving the device.  The vocabulary is a seeded synthetic 10-ary tree (ORBvoc is not available)."""
+
+    def __init__(self, extractor, world, cap, seed=17, levels=4, levelsup=2, thr=50.0, ratio=0.6):
+        import torch
+        from .synth import synth_vocab_tree
+        tree, keep, self.n_words = synth_vocab_tree(10, levels, seed)
+        self.voc = DeviceVocabulary(extractor, tree, levelsup, keep)
+        dev = torch.device("cuda", extractor.device)
+        self.match12 = torch.full((world, cap), -1, dtype=torch.int32, device=dev)
+        self.n_matches = torch.zeros(world, dtype=torch.int32, device=dev)
+        self.world, self.cap, self.thr, self.ratio = world, cap, thr, ratio
+
+    def match(self, gathered, rank, stream=0):
+        self.voc.records_bow_match_device(gathered.data_ptr(), gathered.shape[1], self.world, rank, self.cap, self.thr, self.ratio, True,
+                                          self.match12.data_ptr(), self.n_matches.data_ptr(), stream)
+
+    def total_matches(self, rank):
+        return int(self.n_matches.sum().item())

@@ -283,6 +283,32 @@ class FeatureMatcher:
                                                                use_prev_matched=0, use_viewing_angle=1, max_view_angle=1.047,
                                                                use_reprojection=1, reproj_threshold=reprojection_err, sigma_ref=1.0, first_wins=1))
 
+    def SearchByProjectionSim3(self, keyframe, Scw, landmarks, vpMatched, th):
+        """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) — loop detection, legacy (FeatureMatcher.cc:628-737).  landmarks: min_dist / max_dist =
+        the invariance range, skip = bad or already found; vpMatched: uint8[n] (keypoint already has a loop match).  Returns (match per landmark,
+        updated vpMatched flags, nmatches)."""
+        ex = self._ex
+        lms = np.ascontiguousarray(landmarks, N.LM_DTYPE)
+        S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        taken = np.ascontiguousarray(vpMatched, np.uint8).copy()
+        midx = np.full(len(lms), -1, np.int32)
+        n = C.c_int32()
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_by_projection_sim3(ex._h, C.byref(keyframe), p(S), p(lms), len(lms), int(th), self.TH_LOW, p(taken), p(midx), C.byref(n)))
+        return midx, taken, n.value
+
+    def SearchBySim3(self, kf1, landmarks1, kf2, landmarks2, s12, R12, t12, th):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — loop closing, legacy (FeatureMatcher.cc:739-934).  landmarks1[n1] / landmarks2[n2]:
+        the landmark of every keypoint (skip = none / bad / already matched).  Returns (match12[n1], nFound)."""
+        ex = self._ex
+        l1 = np.ascontiguousarray(landmarks1, N.LM_DTYPE); l2 = np.ascontiguousarray(landmarks2, N.LM_DTYPE)
+        R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32).reshape(3)
+        m = np.full(kf1.n, -1, np.int32)
+        n = C.c_int32()
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_by_sim3(ex._h, C.byref(kf1), p(l1), C.byref(kf2), p(l2), float(s12), p(R), p(t), float(th), self.TH_HIGH, p(m), C.byref(n)))
+        return m, n.value
+
     def SearchForTriangulation(self, kps1, desc1, featvec1, kps2, desc2, featvec2, F12, keep1=None, keep2=None, size_ref=31.0, sigma_ref=1.0):
         """The matching core of SearchForTriangulation (FeatureMatcher.cc:373-402): keep1/keep2 = keypoints WITHOUT a landmark (and with a
         stereo observation when bOnlyStereo), epipolar gate with F12, best match under TH_LOW with ratio 1.0, rotation check."""
@@ -324,8 +350,36 @@ class ORBVocabulary:
     the BoW vector {word id: L1-normalised tf-idf weight} and the feature vector as CSR (node ids ascending, node_ptr, indices ascending)."""
 
     def __init__(self, tree, extractor=None):
+        """tree: a _native.VocabTree, or the path of a DBoW2 vocabulary file (".txt" = text format, else binary; ORBVocabulary.cpp:14-29)"""
+        self._vocab = None
+        if isinstance(tree, (str, bytes)):
+            L = N.lib()
+            v = C.c_void_p()
+            st = L.hs_vocab_load(tree.encode() if isinstance(tree, str) else tree, C.byref(v))
+            if st != N.HS_OK:
+                raise HsError(st, "Wrong path to vocabulary. Failed to open at: %s" % tree)       # the reference prints this and exits (ORBVocabulary.cpp:22-27)
+            self._vocab = v
+            tree = N.VocabTree()
+            L.hs_vocab_get_tree(v, C.byref(tree))
         self.tree = tree
         self._ex = extractor or ORBExtractor()
+
+    def size(self):
+        """ORBVocabulary::size(): number of words"""
+        if self._vocab is not None:
+            n = C.c_int32()
+            N.lib().hs_vocab_info(self._vocab, None, None, None, C.byref(n), None, None)
+            return n.value
+        cc = np.ctypeslib.as_array(C.cast(self.tree.child_count, C.POINTER(C.c_int32)), shape=(self.tree.n_nodes,))
+        return int((cc[1:] == 0).sum())
+
+    def __del__(self):
+        try:
+            if self._vocab is not None:
+                N.lib().hs_vocab_destroy(self._vocab)
+                self._vocab = None
+        except Exception:
+            pass
 
     def transform(self, descriptors, levelsup=4):
         ex = self._ex

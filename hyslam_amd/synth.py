@@ -121,3 +121,24 @@ def synth_local_map(kps, desc, depth, n_landmarks, seed, fx, fy, cx, cy, Rcw=Non
     lms["assoc_kp"] = -1
     lms["prev_angle"] = kps["angle"][src]
     return lms
+
+
+def synth_vocab_tree(k=10, levels=4, seed=17):
+    """A seeded synthetic k-ary vocabulary with `levels` levels below the root, as the flat tree of the C ABI (hs_vocab_tree): random node
+    descriptors, consecutive word ids and idf-like weights at the leaves.  ORBvoc (the reference's vocabulary) is a missing blob, so bench.py's
+    BoW variant of config 5 and the tests run on this stand-in.  Returns (VocabTree, keepalive arrays, number of words)."""
+    from ._native import VocabTree
+    r = splitmix64(seed, 8, stream=11)
+    rng = np.random.default_rng(int(r[0] % np.uint64(1 << 62)))
+    n_nodes = sum(k ** l for l in range(levels + 1))
+    first_leaf = sum(k ** l for l in range(levels))
+    cb = np.zeros(n_nodes, np.int32); cc = np.zeros(n_nodes, np.int32)
+    nxt = 1
+    for i in range(first_leaf):
+        cb[i], cc[i] = nxt, k
+        nxt += k
+    desc = rng.integers(0, 256, (n_nodes, 32), dtype=np.uint8)
+    word = np.full(n_nodes, -1, np.int32); word[first_leaf:] = np.arange(n_nodes - first_leaf)
+    weight = np.zeros(n_nodes, np.float32); weight[first_leaf:] = rng.uniform(0.5, 9.0, n_nodes - first_leaf)
+    T = VocabTree(n_nodes, levels, cb.ctypes.data, cc.ctypes.data, desc.ctypes.data, word.ctypes.data, weight.ctypes.data, None)
+    return T, [cb, cc, desc, word, weight], n_nodes - first_leaf

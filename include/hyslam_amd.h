@@ -201,6 +201,21 @@ int  hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmar
 int  hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,
                                     int32_t* d_match_idx, float* d_match_dist, int32_t* d_n_matches, void* stream);
 
+/* ---- legacy loop-closing matchers (the reference keeps them for LoopClosing, which is a stub: src/main/System.cc:149) ----
+ * FeatureMatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (FeatureMatcher.cc:628-737).  KF = the keyframe (its OWN pose is used by
+ * landMarkSizePixels, KeyFrame.cc:258-279 — reference quirk), Scw = the caller's Sim3 as a row-major 4x4.  lms[L] in vpPoints order with
+ * min_dist / max_dist = GetMin/MaxDistanceInvariance() and skip = pMP->isBad() || already in vpMatched.  kp_matched[KF->n] (in/out) =
+ * vpMatched[idx] != NULL.  The search is sequential by definition: a landmark cannot take a keypoint that an earlier landmark took (:713,731);
+ * everything that does not depend on vpMatched runs in parallel first, the assignment walks the landmarks in order on one wavefront.
+ * match_idx[L] = keypoint taken by landmark i or -1; *n_matches = nmatches.  Host pointers; synchronous. */
+int  hs_search_by_projection_sim3(hs_orb* h, const hs_frame_view* KF, const float* Scw, const hs_landmark* lms, int L, int th, float th_low,
+                                  uint8_t* kp_matched, int32_t* match_idx, int32_t* n_matches);
+/* FeatureMatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (FeatureMatcher.cc:739-934): lms1[KF1->n] / lms2[KF2->n] = the landmark
+ * of each keypoint (skip = none, bad or already matched; assoc_kp = its view in the OTHER keyframe; min_dist / max_dist = the invariance range).
+ * Both directions run in parallel, then the agreement check.  match12[KF1->n] = KF2 keypoint index or -1; *n_found = nFound. */
+int  hs_search_by_sim3(hs_orb* h, const hs_frame_view* KF1, const hs_landmark* lms1, const hs_frame_view* KF2, const hs_landmark* lms2,
+                       float s12, const float* R12, const float* t12, float th, float th_high, int32_t* match12, int32_t* n_found);
+
 /* the inner loops of SearchByBoW / SearchByBoW2 / _SearchByBoW_ (FeatureMatcher.cc:216-371): for every vocabulary node present in
  * both feature vectors, best / second-best Hamming of each side-1 index over the node's side-2 indices (BestMatchBoWCriterion,
  * MatchCriteria.cpp:601-635: d < threshold and d < ratio*d2, both strict), then RotationConsistencyBoW (:679-726).
@@ -244,7 +259,40 @@ typedef struct hs_vocab_tree {
     const uint8_t* desc;               /* [n_nodes][32] */
     const int32_t* word_id;            /* [n_nodes], valid at leaves */
     const float* weight;               /* [n_nodes], valid at leaves */
+    const int32_t* orig_id;            /* [n_nodes] or NULL: the DBoW2 NodeId of every flat node (reported as the feature-vector key) when a loader
+                                          had to renumber a vocabulary; NULL = the flat index IS the DBoW2 id */
 } hs_vocab_tree;
+/* Vocabulary files: what ORBVocabulary::ORBVocabulary(vocab_file) loads through DBoW2 (src/features/low_level/ORBVocabulary.cpp:14-29): a path ending
+ * in ".txt" is DBoW2's text format (loadFromTextFile, ORBvoc.txt), anything else the binary format (loadFromBinaryFile, the output of
+ * tools/bin_vocabulary.cc).  DBoW2 and the vocabulary file are external to the reference; the formats are restated from the published ORB-SLAM2
+ * DBoW2 sources (hs_vocab.hip).  Host only, no device needed.  hs_vocab_get_tree's arrays stay valid until hs_vocab_destroy. */
+typedef struct hs_vocab hs_vocab;
+int  hs_vocab_load(const char* path, hs_vocab** out);
+int  hs_vocab_from_tree(const hs_vocab_tree* tree, int k, hs_vocab** out);      /* deep copy of a caller-built flat tree (synthetic vocabularies) */
+int  hs_vocab_save(const hs_vocab* v, const char* path);                        /* ".txt" -> text, else binary: tools/bin_vocabulary.cc's conversion */
+void hs_vocab_destroy(hs_vocab* v);
+int  hs_vocab_get_tree(const hs_vocab* v, hs_vocab_tree* out);
+int  hs_vocab_info(const hs_vocab* v, int32_t* k, int32_t* L, int32_t* n_nodes, int32_t* n_words, int32_t* scoring, int32_t* weighting);
+
+/* A vocabulary resident in HBM of h's device, prepared for feature vectors `levelsup` levels above the leaves (Frame::ComputeBoW uses 4,
+ * src/core/Frame.cc:477).  Uploaded once; hs_vocab_dev_groups = number of distinct feature-vector nodes. */
+typedef struct hs_vocab_dev hs_vocab_dev;
+int  hs_vocab_upload(hs_orb* h, const hs_vocab_tree* tree, int levelsup, hs_vocab_dev** out);
+void hs_vocab_dev_destroy(hs_vocab_dev* v);
+int  hs_vocab_dev_groups(const hs_vocab_dev* v);
+/* hs_bow_transform on descriptors that already live in HBM (the extractor's outputs): d_n (may be NULL) = device count clamped to n_max.
+ * Asynchronous. */
+int  hs_bow_transform_device(hs_orb* h, const hs_vocab_dev* v, const uint8_t* d_desc, const int32_t* d_n, int n_max,
+                             int32_t* d_word, float* d_weight, int32_t* d_node, void* stream);
+/* Cross-camera BoW matching over `world` gathered frame records (BASELINE config 5): for every peer p != rank the matching core of SearchByBoW /
+ * _SearchByBoW_ (FeatureMatcher.cc:216-345: per shared vocabulary node, best / second-best Hamming of every side-1 feature over the node's side-2
+ * features, `d < score_threshold && d < ratio * d2`, then RotationConsistencyBoW) between record `rank` (side 1) and record p (side 2), with the
+ * vocabulary transform of all records done on the device.  d_match12 [world][cap] = side-2 index or -1 (row `rank`: all -1), d_n_matches [world].
+ * No host synchronisation.  Asynchronous. */
+int  hs_records_bow_match_device(hs_orb* h, hs_vocab_dev* v, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,
+                                 float score_threshold, float second_best_ratio, int check_rotation,
+                                 int32_t* d_match12, int32_t* d_n_matches, void* stream);
+
 int  hs_bow_transform(hs_orb* h, const hs_vocab_tree* tree, const uint8_t* desc, int n, int levelsup,
                       int32_t* word_id, float* weight, int32_t* node_id);
 

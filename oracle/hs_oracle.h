@@ -184,6 +184,16 @@ typedef struct hso_proj_params {
  * (:123-143, :145-176, :180-212).  match_idx[L] = keypoint index or -1, match_dist[L].  Returns matches.size(). */
 int hso_search_by_projection(const hso_frame_view* F, const hso_landmark* lms, int L, const hso_proj_params* pp,
                              int32_t* match_idx, float* match_dist);
+/* FeatureMatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) — loop detection, legacy (FeatureMatcher.cc:628-737).  KF = the keyframe
+ * (its own pose: landMarkSizePixels projects with it), Scw = 4x4 row-major Sim3, lms in vpPoints order with min_dist / max_dist = the
+ * invariance range and skip = isBad || already found; kp_matched[n] = vpMatched[idx] != NULL, in/out (SEQUENTIAL: a keypoint taken by an
+ * earlier landmark is invisible to the later ones).  match_idx[L] = keypoint taken or -1.  Returns nmatches. */
+int hso_search_by_projection_sim3(const hso_frame_view* KF, const float* Scw, const hso_landmark* lms, int L, int th, float th_low,
+                                  uint8_t* kp_matched, int32_t* match_idx);
+/* FeatureMatcher::SearchBySim3 (FeatureMatcher.cc:739-934): lms1[n1] / lms2[n2] = the landmark of each keypoint of KF1 / KF2 (skip = none, bad
+ * or already matched; assoc_kp = its view in the OTHER keyframe, for landMarkSizePixels); match12[n1] = agreed KF2 index or -1.  Returns nFound. */
+int hso_search_by_sim3(const hso_frame_view* KF1, const hso_landmark* lms1, const hso_frame_view* KF2, const hso_landmark* lms2,
+                       float s12, const float* R12, const float* t12, float th, float th_high, int32_t* match12);
 /* Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:137-153,459-469): cell_xy[2*i] = column or -1 (outside), cell_xy[2*i+1] = row */
 void hso_frame_grid(const hso_frame_view* F, int32_t* cell_xy);
 /* the inner loops of SearchByBoW / _SearchByBoW_ (FeatureMatcher.cc:216-345) + BestMatchBoWCriterion (MatchCriteria.cpp:601-635)
@@ -209,6 +219,7 @@ typedef struct hso_vocab_tree {
     const uint8_t* desc;               /* n_nodes x 32 (root's is unused) */
     const int32_t* word_id;            /* leaves */
     const float* weight;               /* leaves */
+    const int32_t* orig_id;            /* NULL or the DBoW2 NodeId of every flat node (renumbered vocabularies) */
 } hso_vocab_tree;
 void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight, int32_t* node_id);
 

@@ -65,6 +65,10 @@ struct Frame {
             for (int k = 0; k < 3; k++) s += (double)V.Rcw[3 * i + k] * (double)P[k];
             Pc[i] = (float)(s + (double)V.tcw[i]);
         }
+        return CameraProject(Pc, uv);
+    }
+    // Camera::Project(Pc, uv) (Camera.cpp:116-153) on a point already in camera coordinates
+    bool CameraProject(const float Pc[3], float uv[3]) const {
         float PcZ = Pc[2];
         float invz = 1.0f / PcZ;
         float Pch[3] = { Pc[0] / PcZ, Pc[1] / PcZ, Pc[2] / PcZ };
@@ -407,7 +411,7 @@ void hso_bow_transform(const hso_vocab_tree* T, const uint8_t* desc, int n, int 
             }
             if (current_level == nid_level) nid = final_id;
         } while (T->child_count[final_id] != 0);
-        word_id[i] = T->word_id[final_id]; weight[i] = T->weight[final_id]; node_id[i] = nid;
+        word_id[i] = T->word_id[final_id]; weight[i] = T->weight[final_id]; node_id[i] = T->orig_id ? T->orig_id[nid] : nid;
     }
 }
 
@@ -433,6 +437,109 @@ void hso_rotation_consistency(const float* angle_a, const float* angle_b, int n,
     for (int i = 0; i < n; i++) m[i] = i;
     MatchesIdx p = RotationConsistency(m, [&](size_t i) { return angle_a[i]; }, [&](size_t i) { return angle_b[i]; });
     for (int i = 0; i < n; i++) keep[i] = p.count(i) ? 1 : 0;
+}
+
+
+/* ---- legacy loop-closing matchers (FeatureMatcher.cc:628-934).  cv::Mat expressions restated operation by operation:
+ *   A*B+C / -A*B      one gemm: float inputs, double accumulation (alpha, beta applied in double), one rounding to float
+ *   M/s, s*M          Mat scaled through convertTo: every element multiplied by (float)alpha in FLOAT arithmetic (cvtScale_<float,float,float>)
+ *   row.dot(row), cv::norm   double accumulation */
+namespace {
+inline float gemm3(const float* A /*row of 3*/, const float* B, float c, double alpha = 1.0)
+{
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)A[k] * (double)B[k];
+    return (float)(alpha * s + (double)c);
+}
+}
+
+int hso_search_by_projection_sim3(const hso_frame_view* KF, const float* Scw, const hso_landmark* lms, int L, int th, float th_low,
+                                  uint8_t* kp_matched, int32_t* match_idx)
+{
+    Frame kf(*KF);
+    for (int i = 0; i < L; i++) match_idx[i] = -1;
+    // Decompose Scw (:641-646)
+    float sRcw[9], sT[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sRcw[3 * r + c] = Scw[4 * r + c]; sT[r] = Scw[4 * r + 3]; }
+    const float scw = (float)std::sqrt((double)sRcw[0] * sRcw[0] + (double)sRcw[1] * sRcw[1] + (double)sRcw[2] * sRcw[2]);
+    const float inv = (float)(1.0 / (double)scw);
+    float Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 9; i++) Rcw[i] = sRcw[i] * inv + 0.0f;
+    for (int i = 0; i < 3; i++) tcw[i] = sT[i] * inv + 0.0f;
+    for (int i = 0; i < 3; i++) { const float col[3] = { Rcw[i], Rcw[3 + i], Rcw[6 + i] }; Ow[i] = gemm3(col, tcw, 0.f, -1.0); }      // Ow = -Rcw.t()*tcw
+    int nmatches = 0;
+    for (int iMP = 0; iMP < L; iMP++) {
+        const hso_landmark& lm = lms[iMP];
+        if (lm.skip) continue;                                              // pMP->isBad() || spAlreadyFound.count(pMP)
+        float p3Dc[3];
+        for (int i = 0; i < 3; i++) p3Dc[i] = gemm3(&Rcw[3 * i], lm.pos, tcw[i]);
+        if (p3Dc[2] < 0.0) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = KF->fx * x + KF->cx, v = KF->fy * y + KF->cy;
+        if (!(u >= KF->min_x && u < KF->max_x && v >= KF->min_y && v < KF->max_y)) continue;        // KeyFrame::IsInImage (KeyFrame.cc:371-374)
+        const float maxDistance = lm.max_dist, minDistance = lm.min_dist;   // the invariance range (already 0.8 / 1.2 scaled: dist_is_invariance_range semantics)
+        const float PO[3] = { lm.pos[0] - Ow[0], lm.pos[1] - Ow[1], lm.pos[2] - Ow[2] };
+        const float dist = (float)std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const double dot = (double)PO[0] * lm.normal[0] + (double)PO[1] * lm.normal[1] + (double)PO[2] * lm.normal[2];
+        if (dot < 0.5 * dist) continue;
+        const float radius = th * kf.landMarkSizePixels(lm) / KF->size_ref;   // KeyFrame::landMarkSizePixels projects with the KEYFRAME's pose (KeyFrame.cc:258-279)
+        const std::vector<size_t> vIndices = kf.GetFeaturesInAreaNEW(u, v, radius);                 // KeyFrame::GetFeaturesInArea (KeyFrame.cc:329-368): same walk
+        if (vIndices.empty()) continue;
+        float bestDist = std::numeric_limits<float>::max(); int bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (kp_matched[idx]) continue;
+            const float d = ORBDistance(lm.desc, KF->desc + idx * 32);
+            if (d < bestDist) { bestDist = d; bestIdx = (int)idx; }
+        }
+        if (bestDist <= th_low) { kp_matched[bestIdx] = 1; match_idx[iMP] = bestIdx; nmatches++; }
+    }
+    return nmatches;
+}
+
+int hso_search_by_sim3(const hso_frame_view* KF1, const hso_landmark* lms1, const hso_frame_view* KF2, const hso_landmark* lms2,
+                       float s12, const float* R12, const float* t12, float th, float th_high, int32_t* match12)
+{
+    Frame kf1(*KF1), kf2(*KF2);
+    const int N1 = KF1->n, N2 = KF2->n;
+    // Transformation between cameras (:757-760)
+    float sR12[9], sR21[9], t21[3];
+    const float a12 = (float)(double)s12, a21 = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12[3 * r + c] = R12[3 * r + c] * a12 + 0.0f; sR21[3 * r + c] = R12[3 * c + r] * a21 + 0.0f; }
+    for (int i = 0; i < 3; i++) t21[i] = gemm3(&sR21[3 * i], t12, 0.f, -1.0);
+    std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    auto direction = [&](const hso_frame_view* Fsrc, const hso_landmark* lms, int n, const hso_frame_view* Fdst, Frame& dst, const float* sR, const float* tt, std::vector<int>& out) {
+        for (int i = 0; i < n; i++) {
+            const hso_landmark& lm = lms[i];
+            if (lm.skip) continue;                                          // !pMP || vbAlreadyMatched || isBad
+            float pc_src[3], pc_dst[3];
+            for (int k = 0; k < 3; k++) pc_src[k] = gemm3(&Fsrc->Rcw[3 * k], lm.pos, Fsrc->tcw[k]);
+            for (int k = 0; k < 3; k++) pc_dst[k] = gemm3(&sR[3 * k], pc_src, tt[k]);
+            float uv[3];
+            if (!dst.CameraProject(pc_dst, uv)) continue;
+            const float dist3D = (float)std::sqrt((double)pc_dst[0] * pc_dst[0] + (double)pc_dst[1] * pc_dst[1] + (double)pc_dst[2] * pc_dst[2]);
+            if (dist3D < lm.min_dist || dist3D > lm.max_dist) continue;
+            const float radius = th * dst.landMarkSizePixels(lm) / Fdst->size_ref;
+            const std::vector<size_t> vIndices = dst.GetFeaturesInAreaNEW(uv[0], uv[1], radius);
+            if (vIndices.empty()) continue;
+            float bestDist = std::numeric_limits<float>::max(); int bestIdx = -1;
+            for (size_t idx : vIndices) {
+                const float d = ORBDistance(lm.desc, Fdst->desc + idx * 32);
+                if (d < bestDist) { bestDist = d; bestIdx = (int)idx; }
+            }
+            if (bestDist <= th_high) out[i] = bestIdx;
+        }
+    };
+    direction(KF1, lms1, N1, KF2, kf2, sR21, t21, vnMatch1);
+    direction(KF2, lms2, N2, KF1, kf1, sR12, t12, vnMatch2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    return nFound;
 }
 
 } // extern "C"

@@ -249,7 +249,7 @@ class FrameView(C.Structure):
 
 class VocabTree(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("levels", C.c_int32), ("child_begin", C.c_void_p), ("child_count", C.c_void_p),
-                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
+                ("desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p), ("orig_id", C.c_void_p)]
 
 
 class ProjParams(C.Structure):
@@ -296,6 +296,26 @@ def search_by_projection(F, lms, pp):
     n = lib().hso_search_by_projection(C.byref(F), lms.ctypes.data_as(C.c_void_p), L, C.byref(pp),
                                        midx.ctypes.data_as(C.c_void_p), mdist.ctypes.data_as(C.c_void_p))
     return midx, mdist, n
+
+
+def search_by_projection_sim3(KF, Scw, lms, th, th_low, kp_matched):
+    """-> (match_idx[L], kp_matched' [n], nmatches); lms carry the invariance range in min_dist / max_dist"""
+    lms = np.ascontiguousarray(lms, LM_DTYPE)
+    S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+    taken = np.ascontiguousarray(kp_matched, np.uint8).copy()
+    midx = np.full(len(lms), -1, np.int32)
+    n = lib().hso_search_by_projection_sim3(C.byref(KF), S.ctypes.data_as(C.c_void_p), lms.ctypes.data_as(C.c_void_p), len(lms), int(th), C.c_float(th_low),
+                                            taken.ctypes.data_as(C.c_void_p), midx.ctypes.data_as(C.c_void_p))
+    return midx, taken, n
+
+
+def search_by_sim3(KF1, lms1, KF2, lms2, s12, R12, t12, th, th_high):
+    l1 = np.ascontiguousarray(lms1, LM_DTYPE); l2 = np.ascontiguousarray(lms2, LM_DTYPE)
+    R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32).reshape(3)
+    m = np.full(KF1.n, -1, np.int32)
+    n = lib().hso_search_by_sim3(C.byref(KF1), l1.ctypes.data_as(C.c_void_p), C.byref(KF2), l2.ctypes.data_as(C.c_void_p), C.c_float(s12),
+                                 R.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), C.c_float(th), C.c_float(th_high), m.ctypes.data_as(C.c_void_p))
+    return m, n
 
 
 def frame_grid(F):

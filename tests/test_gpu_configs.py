@@ -235,3 +235,61 @@ def test_reserve_failure_leaves_handle_usable(gpu):
     ex.reserve(640, 480, 3)                                      # a larger batch of the old size after a failure
     ks, ds = ex.extract_batch([img, img[::-1].copy(), img])
     assert ks[0].tobytes() == ok.tobytes() and ks[2].tobytes() == ok.tobytes() and np.array_equal(ds[2], od)
+
+
+def test_c5_device_vocabulary_and_cross_camera_bow(gpu):
+    """BASELINE config 5, BoW variant at world size 1 with four locally built records: vocabulary transform on device-resident descriptors ==
+    oracle transform; hs_records_bow_match_device == (oracle transform -> DBoW2 feature vectors -> oracle.search_by_bow) per peer."""
+    from hyslam_amd.synth import synth_vocab_tree
+    W, H, NF, world = 640, 480, 1000, 4
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    ex.reserve(W, H, 1)
+    cap = ex.max_keypoints()
+    rb = D.record_bytes(cap)
+    o_n, o_k, o_d = D.record_offsets(cap)
+    base = synth_image(300, W, H)
+    frames = [base, synth_image(301, W, H), base.copy(), base[:, ::-1].copy()]
+    rng = np.random.default_rng(4)
+    noisy = frames[2].astype(np.int16) + rng.integers(-3, 4, frames[2].shape)          # a second view of frame 0: most features re-found
+    frames[2] = np.clip(noisy, 0, 255).astype(np.uint8)
+    recs = hipmem.DevBuf(world * rb)
+    for i, f in enumerate(frames):
+        d_f = hipmem.DevBuf.from_numpy(f)
+        b = recs.ptr + i * rb
+        ex.extract_batch_device(d_f.ptr, 1, W, H, W, W * H, b + o_k, b + o_d, b + o_n, cap, 0)
+        ex.synchronize()
+    host = recs.to_numpy(np.uint8, world * rb).reshape(world, rb)
+    feats = [D.unpack_record(host[i], cap) for i in range(world)]
+    Tg, keep, n_words = synth_vocab_tree(10, 4, 17)
+    To = oracle.VocabTree(Tg.n_nodes, Tg.levels, Tg.child_begin, Tg.child_count, Tg.desc, Tg.word_id, Tg.weight, None)
+    for levelsup in (2, 3, 4, 6):
+        voc = D.DeviceVocabulary(ex, Tg, levelsup, keep)
+        assert voc.groups == (10 ** max(4 - levelsup, 0))
+        # ---- transform of record 0's descriptors straight from the record
+        n0 = len(feats[0][0])
+        d_w, d_wt, d_nd = hipmem.DevBuf(cap * 4), hipmem.DevBuf(cap * 4), hipmem.DevBuf(cap * 4)
+        voc.transform_device(recs.ptr + o_d, recs.ptr + o_n, cap, d_w.ptr, d_wt.ptr, d_nd.ptr, 0)
+        ex.synchronize()
+        ow, owt, ond = oracle.bow_transform(To, feats[0][1], levelsup)
+        assert np.array_equal(d_w.to_numpy(np.int32, n0), ow) and np.array_equal(d_wt.to_numpy(np.float32, n0), owt) and np.array_equal(d_nd.to_numpy(np.int32, n0), ond)
+        # ---- cross-camera BoW match of record `rank` against the others
+        for rank, rot in ((0, True), (2, False)):
+            d_m, d_nm = hipmem.DevBuf(world * cap * 4), hipmem.DevBuf(world * 4)
+            voc.records_bow_match_device(recs.ptr, rb, world, rank, cap, 50.0, 0.8, rot, d_m.ptr, d_nm.ptr, 0)
+            ex.synchronize()
+            gm = d_m.to_numpy(np.int32, world * cap).reshape(world, cap)
+            gn = d_nm.to_numpy(np.int32, world)
+            k1, d1 = feats[rank]
+            fv1 = HS.ORBVocabulary.containers(*oracle.bow_transform(To, d1, levelsup))[1]
+            for peer in range(world):
+                if peer == rank:
+                    assert gn[peer] == 0 and (gm[peer] == -1).all()
+                    continue
+                k2, d2 = feats[peer]
+                fv2 = HS.ORBVocabulary.containers(*oracle.bow_transform(To, d2, levelsup))[1]
+                om, on = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, None, 50.0, 0.8, rot)
+                assert gn[peer] == on and np.array_equal(gm[peer, :len(k1)], om), (levelsup, rank, peer)
+                assert (gm[peer, len(k1):] == -1).all()
+            if levelsup >= 3 and rank == 0:
+                assert gn[2] > 300                                                   # the noisy second view of frame 0
+        voc.close()

@@ -175,3 +175,71 @@ def test_knn2(matcher):
     assert g[0].tolist() == [0, 0, 0] and g[2].tolist() == [-1, -1, -1]
     g = matcher.HammingKnn2(q[:3], t[:0])
     assert g[0].tolist() == [-1, -1, -1]
+
+
+def sim3_scene(seed):
+    """two keyframes looking at the same landmarks: KF2 = KF1 moved by a small Sim3 (scale 1.1); every keypoint of each keyframe owns a landmark"""
+    sc = scenes.projection_scene(seed, 640, 480, nfeat=800, copies=1)
+    fa = sc["frame_args"]
+    n = len(fa["kps"])
+    rng = np.random.default_rng(seed)
+    lms = sc["lms"][:0].copy()
+    # landmarks of KF1's keypoints: back-project at seeded depths with the keyframe's own pose
+    fx, cx, cy = fa["fx"], fa["cx"], fa["cy"]
+    Rcw, tcw = np.asarray(fa["Rcw"], np.float64), np.asarray(fa["tcw"], np.float64)
+    d = rng.uniform(3.0, 20.0, n)
+    Pc = np.stack([(fa["kps"]["x"] - cx) * d / fx, (fa["kps"]["y"] - cy) * d / fx, d], 1)
+    Pw = (Rcw.T @ (Pc - tcw).T).T
+    l1 = np.zeros(n, oracle.LM_DTYPE)
+    l1["pos"] = Pw.astype(np.float32); l1["size"] = (fa["kps"]["size"] * d / fx).astype(np.float32)
+    dist = np.linalg.norm(Pw + (Rcw.T @ tcw), axis=1)
+    l1["min_dist"] = (0.8 * dist * rng.uniform(0.4, 1.15, n)).astype(np.float32)        # invariance range; some landmarks fall outside
+    l1["max_dist"] = (1.2 * dist * rng.uniform(0.9, 2.5, n)).astype(np.float32)
+    l1["normal"] = ((Pw + (Rcw.T @ tcw)) / dist[:, None]).astype(np.float32)
+    l1["desc"] = fa["desc"]; l1["assoc_kp"] = -1
+    l1["skip"][rng.choice(n, n // 12, replace=False)] = 1
+    return sc, fa, l1
+
+
+def test_sim3_projection_and_search(matcher):
+    sc, fa, l1 = sim3_scene(81)
+    n = len(fa["kps"])
+    KFo, k1 = oracle.make_frame_view(oracle.FrameView, **fa)
+    KFg, k2 = oracle.make_frame_view(N.FrameView, **fa)
+    rng = np.random.default_rng(3)
+    # ---- SearchByProjection(pKF, Scw, ...): Scw = 1.07 * [R|t] close to the keyframe's pose; landmarks in shuffled order so that several compete
+    #      for the same keypoint (sequential semantics), some keypoints already matched
+    s = np.float32(1.07)
+    Scw = np.eye(4, dtype=np.float32)
+    Scw[:3, :3] = s * scenes.small_rotation(0.002, -0.003, 0.001) @ np.asarray(fa["Rcw"], np.float32)
+    Scw[:3, 3] = s * (np.asarray(fa["tcw"], np.float32) + np.array([0.01, -0.02, 0.015], np.float32))
+    lms = np.concatenate([l1, l1[rng.choice(n, n // 2, replace=False)]])               # duplicates: the second copy must lose its keypoint
+    lms = lms[rng.permutation(len(lms))]
+    taken = (rng.random(n) < 0.1).astype(np.uint8)
+    gi, gt, gn = matcher.SearchByProjectionSim3(KFg, Scw, lms, taken, 4)
+    oi, ot, on = oracle.search_by_projection_sim3(KFo, Scw, lms, 4, 50.0, taken)
+    assert on > 150 and gn == on and np.array_equal(gi, oi) and np.array_equal(gt, ot)
+    m = gi[gi >= 0]
+    assert len(np.unique(m)) == len(m) and not taken[m].any()                            # one landmark per keypoint, never a pre-matched one
+    # ---- SearchBySim3: KF2 sees the same landmarks from a pose related by [s12 R12 | t12]
+    fb = dict(fa)
+    perm = rng.permutation(n)
+    fb["kps"] = fa["kps"][perm].copy(); fb["desc"] = fa["desc"][perm].copy(); fb["uR"] = fa["uR"][perm].copy(); fb["kp_lm_obs"] = fa["kp_lm_obs"][perm].copy()
+    fb["kps"]["x"] += rng.normal(0, 0.7, n).astype(np.float32); fb["kps"]["y"] += rng.normal(0, 0.7, n).astype(np.float32)
+    fb["desc"][::3, 11] ^= 0x18
+    s12 = 1.0 / 1.1
+    R12 = scenes.small_rotation(0.001, 0.002, -0.001)
+    t12 = np.array([0.02, -0.01, 0.03], np.float32)
+    # KF2 pose: x_c1 = s12 R12 x_c2 + t12  =>  T2w = (1/s12) R12^T (T1w - t12)
+    R2w = (R12.T @ np.asarray(fa["Rcw"], np.float32)).astype(np.float32)
+    t2w = ((R12.T @ (np.asarray(fa["tcw"], np.float32) - t12)) / np.float32(s12)).astype(np.float32)
+    fb["Rcw"], fb["tcw"] = R2w, t2w
+    K2o, k3 = oracle.make_frame_view(oracle.FrameView, **fb)
+    K2g, k4 = oracle.make_frame_view(N.FrameView, **fb)
+    l2 = l1[perm].copy()
+    l2["pos"] = (l2["pos"] * np.float32(1.0))                                           # the same world points, owned by KF2's keypoints
+    l2["skip"] = 0; l2["skip"][rng.choice(n, n // 10, replace=False)] = 1
+    l1b = l1.copy(); l1b["assoc_kp"] = -1
+    gm, gn = matcher.SearchBySim3(KFg, l1b, K2g, l2, s12, R12, t12, 7.5)
+    om, on = oracle.search_by_sim3(KFo, l1b, K2o, l2, s12, R12, t12, 7.5, 100.0)
+    assert on > 100 and gn == on and np.array_equal(gm, om)
