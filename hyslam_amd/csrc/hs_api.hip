@@ -40,6 +40,7 @@ struct hs_orb {
     uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr, *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
     int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
     uint32_t* d_sel = nullptr;
+    uint16_t* d_sel_perm = nullptr;    // spatial order of every level's selection (describe stage)
     uint16_t* d_taps = nullptr;
     // staging for the host-pointer entry points
     uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
@@ -92,6 +93,7 @@ void free_geometry(hs_orb* h)
     h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
     hipFree(h->d_sel); h->d_sel = nullptr;
+    hipFree(h->d_sel_perm); h->d_sel_perm = nullptr;
     // nothing is configured any more: a failed configure() must not leave a geometry that the early exit would accept
     h->w = h->h = h->batch_cap = 0; h->max_kp = 0; h->total_cells = 0; h->fast_items = 0;
 }
@@ -202,6 +204,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     HIP_TRY(h, hipMalloc(&h->d_cand_count, (size_t)batch * L * 4));
     HIP_TRY(h, hipMalloc(&h->d_sel_count, (size_t)batch * L * 4));
     HIP_TRY(h, hipMalloc(&h->d_sel, std::max<size_t>((size_t)sel * batch * 12, 64)));
+    HIP_TRY(h, hipMalloc(&h->d_sel_perm, std::max<size_t>((size_t)sel * batch * 2, 64)));
     for (int l = 0; l < L; l++) {
         HsLevel& V = h->lv[l];
         V.img_stride = pyr_per_img;
@@ -280,9 +283,9 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
                    h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_knobs, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
-                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, s);
+                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, s);
     mark(h, 3, s);
-    hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->sel_img_stride, h->max_kp,
+    hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->d_sel_perm, h->sel_img_stride, h->max_kp,
                        h->d_taps, out, s, h->fast_taps);
     mark(h, -1, s);
     HIP_TRY(h, hipGetLastError());

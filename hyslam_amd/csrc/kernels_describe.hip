@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)   
 template <bool FT>
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0,
                                                                  const uint32_t* __restrict__ sel_xys, const int32_t* __restrict__ sel_count,
-                                                                 int sel_img_stride, const uint16_t* __restrict__ taps7,
+                                                                 const uint16_t* __restrict__ sel_perm, int sel_img_stride, const uint16_t* __restrict__ taps7,
                                                                  HsOut O)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
@@ -102,13 +102,20 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index: uniform, so everything derived from the
     const int img = blockIdx.y;                                                                // keypoint record stays in SGPRs / scalar loads
-    const int g = blockIdx.x * KP_PER_BLOCK + wv;          // keypoint index inside the image (levels concatenated)
+    // Which keypoint: the image's keypoints are walked in SPATIAL order (level, 64-px tile; sel_perm from the quadtree kernel), and the
+    // block -> position map gives each residue class of blockIdx.x % 8 — the blocks that share an XCD under round-robin placement — one
+    // contiguous eighth of that order, so patches that overlap are fetched into one L2 at about the same time (k_describe used to read
+    // 3.9x its compulsory bytes).  Results still go to the keypoint's list-order slot.  Placement only affects speed.
+    const int gx = gridDim.x, cls = blockIdx.x & 7, jcls = blockIdx.x >> 3;
+    int before = 0;                                        // blocks in the classes below `cls`
+    for (int c = 0; c < cls; c++) before += (gx - c + 7) >> 3;
+    const int gs = (before + jcls) * KP_PER_BLOCK + wv;    // position in the spatial order (levels concatenated)
 
     // locate the level: prefix over the per-level selection counts (wave-uniform scalar loop)
     int level = -1, first = 0, total = 0;
     for (int l = 0; l < nlevels; l++) {
         int c = hs_cload<int32_t>(sel_count + img * nlevels + l);
-        if (level < 0 && g < total + c) { level = l; first = total; }
+        if (level < 0 && gs < total + c) { level = l; first = total; }
         total += c;
     }
     const int cap = O.cap;
@@ -117,9 +124,11 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     hs_keypoint* kps = second ? O.kps2 : O.kps;
     uint8_t* desc = second ? O.desc2 : O.desc;
     if (blockIdx.x == 0 && threadIdx.x == 0) (second ? O.n2 : O.n)[oimg] = min(total, cap);
-    if (level < 0 || g >= cap) return;                      // wave-uniform
-
+    if (level < 0) return;                                  // wave-uniform
     const HsLevel& L = lv[level];
+    const int li = (int)hs_gload<uint16_t>(sel_perm + (size_t)img * sel_img_stride + L.sel_off + (gs - first));      // index in the level's list
+    const int g = first + __builtin_amdgcn_readfirstlane(li);                                                          // list-order slot of the keypoint
+    if (g >= cap) return;
     const uint32_t* sel = sel_xys + ((size_t)img * sel_img_stride + L.sel_off + (g - first)) * 3;
     const int cx = (int)hs_cload<uint32_t>(sel), cy = (int)hs_cload<uint32_t>(sel + 1);
     const int score = (int)hs_cload<uint32_t>(sel + 2);
@@ -272,14 +281,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 }
 
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
-                        const uint32_t* sel_xys, const int32_t* sel_count, int sel_img_stride, int max_sel,
+                        const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
                         const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps)
 {
     int per_img = max_sel < out.cap ? max_sel : out.cap;
     dim3 grid((per_img + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch, 1);
     if (grid.x == 0) grid.x = 1;
     if (fast_taps)
-        hipLaunchKernelGGL(k_describe<true>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride, taps7, out);
+        hipLaunchKernelGGL(k_describe<true>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out);
     else
-        hipLaunchKernelGGL(k_describe<false>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_img_stride, taps7, out);
+        hipLaunchKernelGGL(k_describe<false>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out);
 }

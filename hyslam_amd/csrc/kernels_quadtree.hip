@@ -88,7 +88,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
-                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride)
+                                                   uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride,
+                                                   uint16_t* __restrict__ sel_perm)
 {
     __shared__ QtNodes nodes[2];
     __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
@@ -472,6 +473,47 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
     }
     if (tid == 0) *out_n = min(S, L.sel_cap);
+    // ---- spatial order of the kept keypoints for the describe stage: perm[rank] = list index, ranked by 64-px tile (row-major) and list
+    //      index.  The describe kernel walks the keypoints of an image in this order (neighbouring patches share their 128-byte lines in one
+    //      XCD's L2) but writes every result to its list-order slot, so the output order stays the reference's.
+    //      A counting sort over the tiles (the order inside a tile is irrelevant): histogram, block scan, scatter.
+    {
+        const int Sc = min(S, L.sel_cap);
+        uint16_t* const perm = sel_perm + (size_t)img * sel_img_stride + L.sel_off;
+        constexpr int MAXT = 2 * QT_M;                                 // tile counters live in the upper half of ccount (best[] occupies the lower half)
+        uint32_t* const tcnt = ccount + 2 * QT_M;
+        static_assert(sizeof(ccount) >= (2 * QT_M + MAXT) * 4, "tile counters");
+        const int ntx = (L.w + 63) >> 6, ntiles = ntx * ((L.h + 63) >> 6);
+        if (ntiles <= MAXT) {
+            constexpr int TPT = MAXT / QT_T;                           // tiles per thread in the scan
+            for (int t = tid; t < ntiles; t += QT_T) tcnt[t] = 0;
+            __syncthreads();
+            int tile[(QT_M + QT_T - 1) / QT_T];
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
+                const int i = tid + k * QT_T;
+                tile[k] = -1;
+                if (i < Sc) {
+                    const uint32_t xy = (uint32_t)(0x00FFFFFFFFFFFFFFull - (best[i] & 0x00FFFFFFFFFFFFFFull));
+                    tile[k] = (int)((((xy >> 16) + HS_BORDER) >> 6) * ntx + (((xy & 0xFFFF) + HS_BORDER) >> 6));
+                    atomicAdd(&tcnt[tile[k]], 1u);
+                }
+            }
+            __syncthreads();
+            int c[TPT], local = 0;
+#pragma unroll
+            for (int k = 0; k < TPT; k++) { const int t = tid * TPT + k; c[k] = t < ntiles ? (int)tcnt[t] : 0; local += c[k]; }
+            int tot; int pre = block_scan_excl(local, s_wave, tot);
+#pragma unroll
+            for (int k = 0; k < TPT; k++) { const int t = tid * TPT + k; if (t < ntiles) tcnt[t] = (uint32_t)pre; pre += c[k]; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++)
+                if (tile[k] >= 0) perm[atomicAdd(&tcnt[tile[k]], 1u)] = (uint16_t)(tid + k * QT_T);
+        } else {
+            for (int i = tid; i < Sc; i += QT_T) perm[i] = (uint16_t)i;       // levels beyond 4096 tiles: list order
+        }
+    }
     QT_MARK(4);
 #ifdef HS_QT_PROFILE
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qt_prof[127] = qt_k;
@@ -481,9 +523,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, hipStream_t s)
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, hipStream_t s)
 {
     dim3 grid(nlevels, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm);
 }

@@ -3,12 +3,12 @@
 // Replaces Stereomatcher::computeStereoMatches (src/features/Stereomatcher.cpp:36-156) and the
 // ORBDistance bit-hack it calls per pair (src/features/low_level/DescriptorDistance.cpp:9-25).
 // The reference builds a per-row table of right keypoints (iR listed in rows floor(y-r)..ceil(y+r),
-// r = 2*size/size_ref) and scans vRowIndices[(int)vL] in ascending iR.  Here one wavefront owns one left
-// keypoint and tests *every* right keypoint against the same predicate (row band, |octave diff| <= 1,
-// uL-maxD <= uR <= uL): 2000 x 2000 predicate evaluations per pair are noise for the GPU and no table
-// is materialised.  The running minimum uses the key dist<<16 | iR, which reproduces the reference's
-// strict `dist < bestDist` over ascending iR (first minimum wins).  Descriptors are XORed as 4 x u64 and
-// counted with v_bcnt (__popcll) — equal to the reference's 32-bit parallel bit count.
+// r = 2*size/size_ref) and scans vRowIndices[(int)vL] in ascending iR.  Here the right keypoints are binned once per pair into 32-row
+// STRIPS (k_stereo_strips: the reference's table at 1/32 of its size); one wavefront owns one left keypoint, scans the strip of its row
+// (~100 candidates instead of all 2000) and re-applies the exact predicate (row band, |octave diff| <= 1, uL-maxD <= uR <= uL) to every
+// candidate.  The running minimum uses the key dist<<16 | iR, which reproduces the reference's strict `dist < bestDist` over ascending iR
+// (first minimum wins) whatever the order inside a strip.  Descriptors are XORed as 4 x u64 and counted with v_bcnt (__popcll) — equal
+// to the reference's 32-bit parallel bit count.
 //
 // Second kernel: the reference's sort + median + 2.1*median rejection (:142-155) is a histogram of the
 // accepted integer distances, one workgroup per pair.
