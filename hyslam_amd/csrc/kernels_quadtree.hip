@@ -230,10 +230,137 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     __syncthreads();
 
     QT_MARK(2);
-    // ---- main loop
     bool phase2 = false;     // uniform across the block
     int T_prev = 0;          // number of children created by the previous pass (they sit at list indices [0,T_prev))
-    for (int iter = 0; iter < 64; iter++) {
+    bool finished = false;   // the distribution ended inside the fast-forward below
+
+    // ---- fast-forward of the first (up to three) breadth-first passes.  While the reference is in its first phase EVERY multi-point node
+    //      is split, so where a point ends up depends on geometry alone: its path through DivideNode's midpoints.  One sweep computes every
+    //      point's depth-3 cell and a histogram of those cells; the per-depth counts are sums of it; a single wavefront then replays the list
+    //      bookkeeping of the passes on those counts (a lane per node: which nodes split, which children exist, where they land in the
+    //      list, when the reference would stop or switch to its second phase), and a second sweep labels the points with their node.  The
+    //      generic pass below (a dozen block-wide steps with LDS atomics per pass) then only runs for what is left — normally the single
+    //      size-ordered pass of the second phase.  Applies when the list still fits a wavefront (<= 4 root nodes).
+    if (S <= 4) {
+        uint32_t* const hist3 = ccount;                    // [S*64] points per depth-3 cell
+        uint32_t* const cnt2 = ccount + 256;               // [S*16]
+        uint32_t* const cnt1 = ccount + 320;               // [S*4]
+        uint16_t* const idx_tab = child_index;             // [340] (depth, key) -> index in the final list, 0xFFFF = not a node of it
+        constexpr int TAB0 = 0, TAB1 = 4, TAB2 = 20, TAB3 = 84;
+        int16_t* const nkey = order_node;                  // per list entry: depth<<12 | key
+        __shared__ int16_t s_rootb[16];                    // the roots' rectangles (the node arrays are overwritten by the replay)
+        for (int i = tid; i < 340; i += QT_T) { ccount[i] = 0; idx_tab[i] = 0xFFFF; }
+        if (tid < S) { s_rootb[4 * tid] = nodes[0].x0[tid]; s_rootb[4 * tid + 1] = nodes[0].x1[tid]; s_rootb[4 * tid + 2] = nodes[0].y0[tid]; s_rootb[4 * tid + 3] = nodes[0].y1[tid]; }
+        __syncthreads();
+        // path of a point below root s: three DivideNode decisions
+        auto path_of = [&](int s, int x, int y) {
+            int x0 = s_rootb[4 * s], x1 = s_rootb[4 * s + 1], y0 = s_rootb[4 * s + 2], y1 = s_rootb[4 * s + 3];
+            int path = 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                const int c = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+                if (c & 1) x0 = mx; else x1 = mx;
+                if (c & 2) y0 = my; else y1 = my;
+                path = path * 4 + c;
+            }
+            return path;
+        };
+        for (int p = tid; p < n; p += QT_T) {
+            const uint32_t xy = ld_xy(p);
+            const int s = ld_node(p);
+            atomicAdd(&hist3[s * 64 + path_of(s, xy & 0xFFFF, xy >> 16)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid;
+            if (lane < S * 16) cnt2[lane] = hist3[4 * lane] + hist3[4 * lane + 1] + hist3[4 * lane + 2] + hist3[4 * lane + 3];
+            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane < S * 4) cnt1[lane] = cnt2[4 * lane] + cnt2[4 * lane + 1] + cnt2[4 * lane + 2] + cnt2[4 * lane + 3];
+            if (lane < S) nkey[lane] = (int16_t)lane;                                     // depth 0, key = root list index
+            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
+            int Sw = S, Tw = 0, ph2 = 0, fin = 0, curw = 0, passes = 0;
+            for (int pass = 1; pass <= 3; pass++) {
+                if (Sw > 64) break;                                                         // the list no longer fits a lane per node
+                QtNodes& Cw = nodes[curw]; QtNodes& Xw = nodes[curw ^ 1];
+                const bool have = lane < Sw;
+                const int cntv = have ? (int)Cw.cnt[lane] : 0;
+                const bool split = have && cntv > 1;
+                const int kd = have ? (int)(uint16_t)nkey[lane] : 0, key = kd & 0xFFF;
+                const uint32_t* ctab = pass == 1 ? cnt1 : (pass == 2 ? cnt2 : hist3);
+                int cc[4] = { 0, 0, 0, 0 };
+                if (split) { cc[0] = (int)ctab[4 * key]; cc[1] = (int)ctab[4 * key + 1]; cc[2] = (int)ctab[4 * key + 2]; cc[3] = (int)ctab[4 * key + 3]; }
+                const int nchild = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0);
+                const int nexp = (cc[0] > 1) + (cc[1] > 1) + (cc[2] > 1) + (cc[3] > 1);
+                int incl_c = nchild, incl_s = (have && !split) ? 1 : 0, sum_e = nexp;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int a = __shfl_up(incl_c, o, 64), b = __shfl_up(incl_s, o, 64);
+                    if (lane >= o) { incl_c += a; incl_s += b; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum_e += __shfl_xor(sum_e, o, 64);
+                const int T = __builtin_amdgcn_readlane(incl_c, 63), nsurv = __builtin_amdgcn_readlane(incl_s, 63);
+                if (T == 0) { fin = 1; break; }                                             // nothing can be split: size == prevSize (:309)
+                if (T + nsurv > QT_M) { fin = 2; break; }
+                if (split) {
+                    const int x0 = Cw.x0[lane], x1 = Cw.x1[lane], y0 = Cw.y0[lane], y1 = Cw.y1[lane];
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                    int ci = incl_c - nchild;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (cc[c] > 0) {
+                            const int pos = T - 1 - ci; ci++;
+                            Xw.x0[pos] = (int16_t)((c & 1) ? mx : x0); Xw.x1[pos] = (int16_t)((c & 1) ? x1 : mx);
+                            Xw.y0[pos] = (int16_t)((c & 2) ? my : y0); Xw.y1[pos] = (int16_t)((c & 2) ? y1 : my);
+                            Xw.cnt[pos] = (uint32_t)cc[c];
+                            new_index[pos] = (uint16_t)((pass << 12) | (4 * key + c));      // the next list's keys are staged here (nkey is still being read)
+                        }
+                    }
+                } else if (have) {
+                    const int pos = T + incl_s - 1;
+                    Xw.x0[pos] = Cw.x0[lane]; Xw.x1[pos] = Cw.x1[lane]; Xw.y0[pos] = Cw.y0[lane]; Xw.y1[pos] = Cw.y1[lane]; Xw.cnt[pos] = Cw.cnt[lane];
+                    new_index[pos] = (uint16_t)kd;
+                }
+                __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
+                const int prevS = Sw;
+                Sw = T + nsurv; Tw = T; curw ^= 1; passes = pass;
+                for (int i = lane; i < Sw; i += 64) nkey[i] = (int16_t)new_index[i];
+                __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (Sw >= N || Sw == prevS) { fin = 1; break; }                            // (:307-313)
+                if (Sw + sum_e * 3 > N) { ph2 = 1; break; }
+            }
+            // (depth, key) -> list index of every node of the resulting list
+            if (passes > 0 && fin != 2)
+                for (int i = lane; i < Sw; i += 64) {
+                    const int kd = (int)(uint16_t)nkey[i], d = kd >> 12, key = kd & 0xFFF;
+                    idx_tab[(d == 0 ? TAB0 : d == 1 ? TAB1 : d == 2 ? TAB2 : TAB3) + key] = (uint16_t)i;
+                }
+            if (lane == 0) { s_misc[2] = Sw; s_misc[3] = Tw; s_misc[4] = ph2; s_misc[5] = fin; s_misc[6] = curw; s_misc[7] = passes; }
+        }
+        __syncthreads();
+        const int passes = s_misc[7];
+        if (s_misc[5] == 2) { if (tid == 0) *out_n = 0; return; }                          // cannot happen for quota + 8 <= QT_M (host checks)
+        if (passes > 0) {
+            for (int p = tid; p < n; p += QT_T) {
+                const uint32_t xy = ld_xy(p);
+                const int s = ld_node(p);
+                const int path = path_of(s, xy & 0xFFFF, xy >> 16);
+                int e = idx_tab[TAB0 + s];
+                if (e == 0xFFFF) e = idx_tab[TAB1 + s * 4 + (path >> 4)];
+                if (e == 0xFFFF) e = idx_tab[TAB2 + s * 16 + (path >> 2)];
+                if (e == 0xFFFF) e = idx_tab[TAB3 + s * 64 + path];
+                st_node(p, e);
+            }
+            S = s_misc[2]; T_prev = s_misc[3]; phase2 = s_misc[4] != 0; finished = s_misc[5] == 1; cur = s_misc[6];
+        } else {
+            finished = s_misc[5] == 1;                                                      // no root can be split
+        }
+        __syncthreads();
+    }
+    QT_MARK(5);
+    // ---- main loop
+    for (int iter = 0; iter < 64 && !finished; iter++) {
         QtNodes& C = nodes[cur];
         QtNodes& X = nodes[cur ^ 1];
         const int prevSize = S;
