@@ -19,6 +19,7 @@ struct hs_orb {
     std::string err;
     uint16_t taps[7];
     HsFastKnobs fast_knobs{};          // HS_FAST_* environment knobs, read once in hs_orb_create
+    bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
@@ -216,6 +217,12 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
             V.yofs = h->d_tables + tab_off[4 * l + 2]; V.ibeta = h->d_tables + tab_off[4 * l + 3];
         }
     }
+    {   // which level pairs the fused pyramid kernel can produce (decided on the host copies of the tables)
+        std::vector<const int16_t*> xt(L, nullptr), yo(L, nullptr);
+        for (int l = 1; l < L; l++) { xt[l] = tables.data() + tab_off[4 * l]; yo[l] = tables.data() + tab_off[4 * l + 2]; }
+        hs_pyramid_plan_fusion(h->lv.data(), L, xt.data(), yo.data());
+        if (h->no_fuse) for (int l = 0; l < L; l++) h->lv[l].fuse_tbx = 0;
+    }
     HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
     {
         std::vector<HsFastItem> fi(std::max(items, 1));
@@ -394,6 +401,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     hs_orb* h = new hs_orb();
     h->p = *p; h->device = device;
     h->fast_knobs = hs_fast_read_knobs();
+    { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
     static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
     for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];
@@ -1071,7 +1079,7 @@ int hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes
 int hs_orb_stage_launches(const hs_orb* h, int stage)
 {
     if (!h || stage < 0 || stage >= HS_NUM_STAGES) return 0;
-    if (stage == 0) return hs_pyramid_launch_count(h->p.nlevels);
+    if (stage == 0) return h->lv.empty() ? std::max(h->p.nlevels - 1, 0) : hs_pyramid_launch_count(h->lv.data(), h->p.nlevels);
     return stage == 4 ? 2 : 1;
 }
 

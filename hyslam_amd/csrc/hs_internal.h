@@ -46,6 +46,9 @@ struct HsLevel {
     const int16_t* ibeta;          // [h][2]
     float scale;                   // mvScaleFactor[level]
     float kp_size;                 // (int)(31*scale)
+    // two-levels-per-launch pyramid kernel (kernels_pyramid.hip): this level and the next one are produced by one workgroup per tile of the NEXT
+    // level; 0 = this pair is not fused.  Tile width of the next level, LDS rows for this level's region / the source rectangle, source pitch.
+    int32_t fuse_tbx, fuse_ar, fuse_sr, fuse_pitch;
 };
 
 // One work item of the FAST kernel (kernels_fast.hip): `ncell` horizontally adjacent cells of one cell row.  Everything that does not
@@ -120,7 +123,9 @@ struct HsOut {                     // extractor outputs, split the same way
 
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
-int hs_pyramid_launch_count(int nlevels);          // kernel launches of one hs_launch_pyramid call
+// decides, from the host copies of the resize tables, whether levels (l, l+1) can be produced by the fused kernel and with which tile geometry
+void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/);
+int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kernel launches of one hs_launch_pyramid call
 int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
 int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);

@@ -13,6 +13,7 @@
 // four aligned dwords and the taps are picked out with v_alignbyte instead of 16 byte loads; the x table is one
 // 8-byte record {sx, a0, a1, -} per output.
 #include "hs_internal.h"
+#include <algorithm>
 
 struct HsXTab { int16_t sx, a0, a1, pad; };
 
@@ -183,10 +184,205 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two levels per launch.  A workgroup owns one tile of level B = l+1 (TBX x 16 px) and everything above it: it stages the rectangle of level
+// S = l-1 that the tile's region of level A = l needs, makes that region of A (horizontal sums per source row, vertical combine), keeps it in
+// LDS, writes the part of it that the workgroup OWNS to HBM (ownership = the partition of A induced by the first source column / row of
+// every B tile, so every pixel of A is written exactly once; the 1-2 px halo a tile needs from its neighbours' parts is recomputed, with
+// identical bits), and then makes its tile of B from the LDS copy.  The chain of launches shrinks from L-1 to ceil((L-1)/2), level A is
+// never re-read from memory, and the source rectangle is shared by both levels.  Same arithmetic as k_resize_level_lds.
+#define FZ_ROWS 16
+#define FZ_APITCH 272             // LDS pitch of the level-A region: 256 columns + the 3-dword window over-read of the last lane
+__global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __restrict__ lv, int levelA, HsImg0 img0)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const HsLevel& A = lv[levelA];
+    const HsLevel& B = lv[levelA + 1];
+    const int TBX = A.fuse_tbx, SR = A.fuse_sr, lds_pitch = A.fuse_pitch;
+    uint8_t* const s_src = smem;                                                         // [SR][lds_pitch] source rectangle, later the level-A region
+    uint8_t* const s_a = smem;                                                           // [AR][FZ_APITCH]
+    uint16_t* const s_h = reinterpret_cast<uint16_t*>(smem + (size_t)lds_pitch * SR);    // [SR][256] (H >> 4) for level A, later [AR][256] for level B
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint8_t* sbase; size_t spitch;
+    if (levelA == 1) { sbase = hs_img0_ptr(img0, img); spitch = img0.row_stride; }
+    else { const HsLevel& S = lv[levelA - 1]; sbase = S.base + (size_t)img * S.img_stride; spitch = S.pitch; }
+    const int sw = lv[levelA - 1].w, sh = lv[levelA - 1].h;
+    const HsXTab* xtA = reinterpret_cast<const HsXTab*>(A.xofs);
+    const HsXTab* xtB = reinterpret_cast<const HsXTab*>(B.xofs);
+    auto sxB = [&](int x) { return (int)(int16_t)hs_cload<uint32_t>(&xtB[x]); };        // .sx = low half of the record's first dword
+    auto sxA = [&](int x) { return (int)(int16_t)hs_cload<uint32_t>(&xtA[x]); };
+
+    // ---- geometry (wave-uniform)
+    const int bx0 = blockIdx.x * TBX, by0 = blockIdx.y * FZ_ROWS;
+    const int by_last = min(by0 + FZ_ROWS, B.h) - 1;
+    const bool last_x = bx0 + TBX >= B.w, last_y = by0 + FZ_ROWS >= B.h;
+    const int ax0 = blockIdx.x == 0 ? 0 : (sxB(bx0) & ~3);                                // first column of the level-A region = first owned column
+    const int own_x1 = last_x ? ((A.w + 3) & ~3) : (sxB(bx0 + TBX) & ~3);
+    const int ay0 = blockIdx.y == 0 ? 0 : min(max(hs_cload_i16(B.yofs, by0), 0), A.h - 1);
+    const int own_y1 = last_y ? A.h : min(max(hs_cload_i16(B.yofs, by0 + FZ_ROWS), 0), A.h - 1);
+    const int ay_last = max(min(max(hs_cload_i16(B.yofs, by_last) + 1, 0), A.h - 1), own_y1 - 1);
+    const int nAr = ay_last - ay0 + 1;                                                    // <= AR (host-verified)
+    const int ax_lastcol = min(ax0 + 255, A.w - 1);
+    const int col0 = sxA(ax0) & ~15;
+    const int col_last = min(sxA(ax_lastcol) + 1, sw - 1);
+    const int sy_first = min(max(hs_cload_i16(A.yofs, ay0), 0), sh - 1);
+    const int sy_last = min(max(hs_cload_i16(A.yofs, ay_last) + 1, 0), sh - 1);
+    const int nvec = ((col_last - col0) >> 4) + 1, nSr = sy_last - sy_first + 1;          // nvec*16 <= lds_pitch - 16, nSr <= SR (host-verified)
+
+    // ---- 1: the source rectangle
+    {
+        const int lane = threadIdx.x & 63;
+        const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
+        const int rl = (lane >= nvec) + (lane >= 2 * nvec) + (lane >= 3 * nvec), q = lane - rl * nvec;
+        if (lane < rpw * nvec) {
+            for (int r = wave * rpw + rl; r < nSr; r += 4 * rpw) {
+                const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
+                *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
+            }
+        }
+    }
+    // per-lane column data of one horizontal pass: window position, byte-pair selectors, coefficient pairs
+    struct ColData { int wbase, wshift; uint32_t sel[4], coef[4]; };
+    auto col_data = [&](const HsXTab* xt, int dx0, int wmax, int origin) {
+        HsXTab t[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, hs_gload<uint64_t>(&xt[min(dx0 + i, wmax)]));
+        ColData c;
+        const int o0 = t[0].sx - origin;
+        c.wbase = o0 & ~3; c.wshift = o0 & 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t q = (uint32_t)(t[i].sx - t[0].sx);
+            c.sel[i] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
+            c.coef[i] = (uint32_t)(uint16_t)t[i].a0 | ((uint32_t)(uint16_t)t[i].a1 << 16);
+        }
+        return c;
+    };
+    auto h_pass = [&](const uint8_t* src, int pitch, int nrow, const ColData& c) {
+        for (int r = wave; r < nrow; r += 4) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&src[r * pitch + c.wbase]);
+            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+            const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, c.wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, c.wshift);
+            uint32_t h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, c.sel[i])), __builtin_bit_cast(hs_us2, c.coef[i]), 0u, false) >> 4;
+            *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        }
+    };
+    auto v_combine = [&](int r0, int r1, uint32_t b0, uint32_t b1) -> uint32_t {
+        const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
+        const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
+        const uint32_t v0 = (((b0 * (H0.x & 0xFFFFu)) >> 16) + ((b1 * (H1.x & 0xFFFFu)) >> 16) + 2) >> 2;
+        const uint32_t v1 = (((b0 * (H0.x >> 16)) >> 16) + ((b1 * (H1.x >> 16)) >> 16) + 2) >> 2;
+        const uint32_t v2 = (((b0 * (H0.y & 0xFFFFu)) >> 16) + ((b1 * (H1.y & 0xFFFFu)) >> 16) + 2) >> 2;
+        const uint32_t v3 = (((b0 * (H0.y >> 16)) >> 16) + ((b1 * (H1.y >> 16)) >> 16) + 2) >> 2;
+        return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+    };
+    const ColData cA = col_data(xtA, ax0 + 4 * tx, A.w - 1, col0);
+    __syncthreads();
+    // ---- 2: horizontal sums of the source rows for the level-A columns
+    h_pass(s_src, lds_pitch, nSr, cA);
+    __syncthreads();
+    // ---- 3: level-A region -> LDS (it overlays the source rectangle, which is dead now) and, for the owned part, HBM
+    {
+        uint8_t* const aimg = A.base + (size_t)img * A.img_stride;
+        const int acol = ax0 + 4 * tx;
+        const bool own_col = acol < own_x1;
+        for (int ay = ay0 + wave; ay <= ay_last; ay += 4) {
+            const int sy = hs_cload_i16(A.yofs, ay);
+            const uint32_t b01 = hs_cload<uint32_t>(A.ibeta + 2 * ay);
+            const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
+            const uint32_t px = v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16);
+            *reinterpret_cast<uint32_t*>(&s_a[(ay - ay0) * FZ_APITCH + 4 * tx]) = px;
+            if (own_col && ay < own_y1) hs_gstore<uint32_t>(aimg + (size_t)ay * A.pitch + acol, px);
+        }
+    }
+    const ColData cB = col_data(xtB, bx0 + 4 * tx, B.w - 1, ax0);
+    __syncthreads();
+    // ---- 4: horizontal sums of the level-A rows for the tile's level-B columns (the sums overlay the level-A sums)
+    if (4 * tx < TBX) h_pass(s_a, FZ_APITCH, nAr, cB);
+    __syncthreads();
+    // ---- 5: the level-B tile
+    if (4 * tx < TBX && bx0 + 4 * tx < B.w) {
+        uint8_t* const bimg = B.base + (size_t)img * B.img_stride;
+#pragma unroll
+        for (int rr = 0; rr < FZ_ROWS / 4; rr++) {
+            const int by = by0 + wave + 4 * rr;
+            if (by >= B.h) break;
+            const int sy = hs_cload_i16(B.yofs, by);
+            const uint32_t b01 = hs_cload<uint32_t>(B.ibeta + 2 * by);
+            const int r0 = min(max(sy, 0), A.h - 1) - ay0, r1 = min(max(sy + 1, 0), A.h - 1) - ay0;
+            hs_gstore<uint32_t>(bimg + (size_t)by * B.pitch + bx0 + 4 * tx, v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16));
+        }
+    }
+}
+
+// Can levels (l, l+1) be fused?  Walks every tile with the host copies of the tables and checks what the kernel assumes: the level-A region of
+// a tile (owned part + halo) fits 256 columns / fuse_ar rows, its source rectangle fits the LDS rectangle, all LDS fits.
+void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs)
+{
+    for (int l = 1; l < nlevels; l++) h_lv[l].fuse_tbx = h_lv[l].fuse_ar = h_lv[l].fuse_sr = h_lv[l].fuse_pitch = 0;
+    for (int l = 1; l + 1 < nlevels; l += 2) {
+        HsLevel& A = h_lv[l]; const HsLevel& B = h_lv[l + 1]; const HsLevel& S = h_lv[l - 1];
+        const double scxA = (double)S.w / A.w, scyA = (double)S.h / A.h, scxB = (double)A.w / B.w, scyB = (double)A.h / B.h;
+        if (scxA > 2.0 || scxB > 2.0 || scyA > 2.0 || scyB > 2.0 || B.w < 8 || B.h < 1) continue;
+        const int tbx = std::min(256, ((int)(250.0 / scxB)) & ~3);
+        if (tbx < 64) continue;
+        const int16_t* xA = xtab[l]; const int16_t* xB = xtab[l + 1]; const int16_t* yA = yofs[l]; const int16_t* yB = yofs[l + 1];
+        auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        int ar = 0, sr = 0, pitch = 0; bool ok = true;
+        for (int by0 = 0; by0 < B.h && ok; by0 += FZ_ROWS) {
+            const int by_last = std::min(by0 + FZ_ROWS, B.h) - 1; const bool last_y = by0 + FZ_ROWS >= B.h;
+            const int ay0 = by0 == 0 ? 0 : clampi(yB[by0], 0, A.h - 1);
+            const int own_y1 = last_y ? A.h : clampi(yB[by0 + FZ_ROWS], 0, A.h - 1);
+            const int ay_last = std::max(clampi(yB[by_last] + 1, 0, A.h - 1), own_y1 - 1);
+            if (own_y1 <= ay0 && !last_y) { /* empty owned range is fine */ }
+            if (clampi(yB[by0], 0, A.h - 1) < ay0) ok = false;                    // rows the tile needs lie at or below its first row
+            ar = std::max(ar, ay_last - ay0 + 1);
+            const int sy_first = clampi(yA[ay0], 0, S.h - 1), sy_last = clampi(yA[ay_last] + 1, 0, S.h - 1);
+            sr = std::max(sr, sy_last - sy_first + 1);
+        }
+        for (int bx0 = 0; bx0 < B.w && ok; bx0 += tbx) {
+            const int bx_last = std::min(bx0 + tbx, B.w) - 1; const bool last_x = bx0 + tbx >= B.w;
+            const int ax0 = bx0 == 0 ? 0 : (xB[4 * bx0] & ~3);
+            const int own_x1 = last_x ? ((A.w + 3) & ~3) : (xB[4 * (bx0 + tbx)] & ~3);
+            const int need_last = std::min(xB[4 * bx_last] + 1, A.w - 1);
+            if (xB[4 * bx0] < ax0 || own_x1 - ax0 > 256 || need_last - ax0 > 255 || own_x1 < ax0) ok = false;
+            // window of the last lane: offset of its first column + 11 bytes must stay inside the LDS row
+            if (xB[4 * std::min(bx0 + tbx - 4, B.w - 1)] - ax0 + 12 > FZ_APITCH) ok = false;
+            const int ax_lastcol = std::min(ax0 + 255, A.w - 1);
+            const int col0 = xA[4 * ax0] & ~15, col_last = std::min(xA[4 * ax_lastcol] + 1, S.w - 1);
+            pitch = std::max(pitch, ((col_last - col0) >> 4) * 16 + 16 + 16);
+            if (xA[4 * ax0] < col0) ok = false;
+        }
+        if (!ok) continue;
+        pitch = (pitch + 15) & ~15;
+        const size_t lds = (size_t)pitch * sr + (size_t)std::max(sr, ar) * 256 * 2;
+        if ((size_t)FZ_APITCH * ar > (size_t)pitch * sr || lds > 60 * 1024) continue;
+        A.fuse_tbx = tbx; A.fuse_ar = ar; A.fuse_sr = sr; A.fuse_pitch = pitch;
+    }
+}
+
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s)
 {
     for (int l = 1; l < nlevels; l++) {
         const HsLevel& D = h_lv[l];
+        if (D.fuse_tbx > 0 && l + 1 < nlevels) {
+            // 16-byte source vectors: always fine for our own levels (pitch % 64 == 0), checked for the caller's frames
+            bool vec16 = true;
+            if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((h_lv[0].w + 15) & ~15) <= (int)img0.row_stride;
+            if (vec16) {
+                const HsLevel& B = h_lv[l + 1];
+                const size_t lds = (size_t)D.fuse_pitch * D.fuse_sr + (size_t)std::max(D.fuse_sr, D.fuse_ar) * 256 * 2;
+                dim3 grid((B.w + D.fuse_tbx - 1) / D.fuse_tbx, (B.h + FZ_ROWS - 1) / FZ_ROWS, batch);
+                hipLaunchKernelGGL(k_resize_two_levels, grid, dim3(256), lds, s, d_lv, l, img0);
+                l++;                                           // level l+1 is done too
+                continue;
+            }
+        }
         const int sw = h_lv[l - 1].w, sh = h_lv[l - 1].h;
         // 16-byte source vectors: always fine for our own levels (pitch % 64 == 0), checked for the caller's frames;
         // a vector may run past the last source column only inside the row's own pitch
@@ -212,7 +408,13 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
     }
 }
 
-int hs_pyramid_launch_count(int nlevels) { return nlevels > 1 ? nlevels - 1 : 0; }
+// launches of one hs_launch_pyramid call when every eligible pair is fused (the caller-frame alignment fallback adds one)
+int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels)
+{
+    int n = 0;
+    for (int l = 1; l < nlevels; l++) { n++; if (h_lv[l].fuse_tbx > 0 && l + 1 < nlevels) l++; }
+    return n;
+}
 
 // ---- calibration kernels of known HBM traffic (hs_debug_stream_copy): one dword / one 16-byte vector per lane, grid-stride
 __global__ __launch_bounds__(256) void k_copy_u32(uint32_t* __restrict__ d, const uint32_t* __restrict__ s, size_t n)

@@ -192,7 +192,7 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
-@pytest.mark.parametrize("env", [{}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
+@pytest.mark.parametrize("env", [{}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
     """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, and NMS driven from the score

@@ -23,3 +23,5 @@ tail -3 $OUT/bench.err
 for v in nostore x1 x2; do
   [ -f hyslam_amd/libhyslam_amd_$v.so ] && HYSLAM_AMD_LIB=$PWD/hyslam_amd/libhyslam_amd_$v.so timeout 300 python3 bench.py --cpu-seconds 0 --handles 1 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('variant $v (1 handle):', d['value'], d['stage_ms_per_step'])"
 done
+HS_PYRAMID_NO_FUSE=1 timeout 300 python3 bench.py --cpu-seconds 0 --handles 1 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unfused pyramid (1 handle):', d['value'], d['stage_ms_per_step'])"
+HS_PYRAMID_NO_FUSE=1 timeout 300 python3 bench.py --cpu-seconds 0 --pairs 1 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unfused pyramid (pairs 1):', d['value'], d['stage_ms_per_step'])"
