@@ -198,8 +198,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     const int col = tid & (COLS - 1), sub = tid >> LC;
     const int ld_row = tid / LPR, ld_c16 = tid % LPR;
     const int t = min(max(fast_th, 0), 255);
-    const us2 t16 = as_us2((uint32_t)(t << 8) * 0x00010001u);
-    const uint32_t ones = 0x00010001u;
+    const uint32_t kbias = (0x80u - (uint32_t)((t + 1) >> 2)) * 0x01010101u;     // see scan A
     constexpr int RO[16] = { 3 * PITCH + 0, 3 * PITCH + 1, 2 * PITCH + 2, 1 * PITCH + 3, 0 * PITCH + 3, -1 * PITCH + 3, -2 * PITCH + 2, -3 * PITCH + 1,
                              -3 * PITCH + 0, -3 * PITCH - 1, -2 * PITCH - 2, -1 * PITCH - 3, 0 * PITCH - 3, 1 * PITCH - 3, 2 * PITCH - 2, 3 * PITCH - 1 };
 
@@ -302,13 +301,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_ACC(1, t1, t2);
 
         const int c_first = cur.off + 3;                         // tile column of the first interior pixel
-        uint32_t vmask = 0;                                      // this lane's pixels that are interior columns: bits 0,1,16,17 = pixel 0,1,2,3
+        uint32_t vmask8 = 0;                                     // this lane's pixels that are interior columns: byte j = pixel j, one bit per row of a scan block
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int px = 4 * col + j - c_first;
-            if (px >= 0 && px < cur.iw) vmask |= 1u << ((j & 1) + 16 * (j >> 1));
+            if (px >= 0 && px < cur.iw) vmask8 |= 0xFFu << (8 * j);
         }
-        const uint32_t vmask8 = vmask * 0x5555u;                 // the same for the 8 rows of a scan block (row r at << 2r)
         int npx = 0;                                             // wave-uniform list length
         int n_done = 0, n_ovf = 0;                               // scored corners at the head of the list (entries [n_done, npx) are scan codes); corners spilled
 
@@ -322,9 +320,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int i = i0 + tid;
                 const bool act = i < npx;
                 const int code = plist[act ? i : 0];
-                const int eb = code & 31, el = (code >> 5) & 63;                 // bit of the scan mask, lane that found it
-                const int py = BR * (RS * (code >> 11) + (el >> LC)) + ((eb >> 1) & 7);
-                const int px = 4 * (el & (COLS - 1)) + ((eb & 1) | ((eb >> 4) << 1)) - c_first;
+                const int eb = code & 31, el = (code >> 5) & 63;                 // bit of the scan mask (8 * pixel + row), lane that found it
+                const int py = BR * (RS * (code >> 11) + (el >> LC)) + (eb & 7);
+                const int px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
                 const int pos = (py << 8) | px;
                 const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
                 const int v = ctr[0];
@@ -408,7 +406,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         };
 
         // ---- the set bits of M (one per pixel of this lane's scan block) -> pixel list.  SCORES: bit 4r+j, entries in score tile
-        //      coordinates; otherwise bit 2r + (j&1) + 16*(j>>1), entries relative to the interior.  `row0`: tile/score row of r = 0.
+        //      coordinates; otherwise bit 8j + r, entries relative to the interior.  `row0`: tile/score row of r = 0.
         // Scan A entries are CODES (block<<11 | lane<<5 | bit of M), decoded on dense lanes by corners_and_scores: the per-lane bit loop
         // below runs for as many rounds as the busiest lane has hits, so every instruction in it counts ~10x.
         auto emit_mask = [&](uint32_t M, int row0, bool scores, int blk) {
@@ -427,7 +425,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 npx += total;
             } else {                                             // a block alone overflows the list (saturated image): one row at a time
                 for (int r = 0; r < BR; r++) {
-                    uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x00030003u << (2 * r)));
+                    uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x01010101u << r));
                     const int incl_r = wave_scan_incl((int)__popc(Mr));
                     const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 4*COLS <= pcap
                     if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else make_room(total_r); }
@@ -452,23 +450,29 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int y0 = 3 + BR * (RS * b + sub);
                 uint32_t M = 0;
                 {
+                    // Four pixels per 32-bit operation: every byte holds a pixel reduced to 6 bits (q = v >> 2), which leaves two guard bits per
+                    // byte, so byte-wise differences never borrow across bytes.  g = q + (0x80 - k) per byte; bit 7 of (g_a - q_b) is set
+                    // exactly when q_a - q_b >= k.  With k = (t + 1) / 4, "b darker than a by more than t" implies q_a - q_b >= k (floor((a - m) / 4)
+                    // <= floor(a / 4) - floor(m / 4)), so the byte test is a NECESSARY condition for the exact compass test of the 16-bit version it
+                    // replaces (measured: 3.7 % of the pixels pass instead of 3.6 %); the segment test on the full bytes follows as before.
+                    // ~26 plain 32-bit ALU operations per row of 4 pixels instead of ~34 packed-16-bit ones, which also issue slower.
                     const uint32_t* tp = tile32 + (y0 - 3) * PD + col;
-                    uint32_t R[BR + 6]; us2 E[BR + 6];
+                    uint32_t Q[BR + 6], G[BR + 6];
 #pragma unroll
-                    for (int k = 0; k < BR + 6; k++) { R[k] = tp[k * PD]; E[k] = as_us2(R[k]) << 8; }
+                    for (int k = 0; k < BR + 6; k++) { Q[k] = (tp[k * PD] >> 2) & 0x3F3F3F3Fu; G[k] = Q[k] + kbias; }
 #pragma unroll
                     for (int r = 0; r < BR; r++) {
-                        const uint32_t C = R[r + 3];
-                        const uint32_t Cm = lane_from_below(C), Cp = lane_from_above(C);
-                        // even pixels (bytes 0,2): T, C, B shifted into the high bytes; ring 12 = bytes 1,3 of the lane below
-                        const us2 se = fr_pretest(E[r], E[r + 3], E[r + 6], as_us2(Cm), as_us2(__builtin_amdgcn_alignbyte(Cp, C, 2)), t16);
-                        // odd pixels (bytes 1,3) already sit in the high bytes
-                        const us2 so = fr_pretest(as_us2(R[r]), as_us2(C), as_us2(R[r + 6]),
-                                                  as_us2(__builtin_amdgcn_alignbyte(C, Cm, 1)), as_us2(__builtin_amdgcn_alignbyte(Cp, C, 3)), t16);
-                        M |= (fr_field_flags(se, ones) | (fr_field_flags(so, ones) << 1)) << (2 * r);
+                        const uint32_t qC = Q[r + 3], gC = G[r + 3];
+                        const uint32_t qCm = lane_from_below(qC), qCp = lane_from_above(qC);
+                        const uint32_t qL = __builtin_amdgcn_alignbyte(qC, qCm, 1);          // the pixels 3 columns to the left / right of this lane's four
+                        const uint32_t qR = __builtin_amdgcn_alignbyte(qCp, qC, 3);
+                        const uint32_t gL = qL + kbias, gR = qR + kbias;
+                        const uint32_t dark = ((gC - Q[r]) | (gC - Q[r + 6])) & ((gC - qL) | (gC - qR));       // (top or bottom darker) and (left or right darker)
+                        const uint32_t bright = ((G[r] - qC) | (G[r + 6] - qC)) & ((gL - qC) | (gR - qC));
+                        M = (M >> 1) | ((dark | bright) & 0x80808080u);                      // row r ends up at bit r of its pixel's byte
                     }
                     const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior
-                    M &= vmask8 & (((1u << (2 * nrow)) - 1u) * 0x00010001u);
+                    M &= vmask8 & (((1u << nrow) - 1u) * 0x01010101u);
                 }
                 emit_mask(M, y0, false, b);
             }
