@@ -144,22 +144,22 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
     reported when the profiled launch shape matches; otherwise null."""
     traffic = valu = None
     src = []
-    try:
+    try:       # a stage can be several kernels (the pyramid): per-launch averages x launches per launch sequence, summed
         t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")))
         if t["pairs_per_step"] == pairs_per_step:
-            for k, e in t["kernels"].items():
-                if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch:
-                    traffic = int((e["read_MB"] + e["written_MB"]) * 1e6 * e.get("launches_per_stage", 1))
-                    src.append("profiles/%s_hbm_traffic.json" % PROFILE_TAG)
+            m = [e for k, e in t["kernels"].items() if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch]
+            if m:
+                traffic = int(sum((e["read_MB"] + e["written_MB"]) * 1e6 * e.get("launches_per_sequence", 1) for e in m))
+                src.append("profiles/%s_hbm_traffic.json" % PROFILE_TAG)
     except Exception:
         pass
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.json")))
         if t["pairs_per_step"] == pairs_per_step:
-            for k, e in t["kernels"].items():
-                if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch:
-                    valu = float(e["SQ_INSTS_VALU"]) * e.get("launches_per_stage", 1)
-                    src.append("profiles/%s_sq_counters.json" % PROFILE_TAG)
+            m = [e for k, e in t["kernels"].items() if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch]
+            if m:
+                valu = float(sum(e["SQ_INSTS_VALU"] * e.get("launches_per_sequence", 1) for e in m))
+                src.append("profiles/%s_sq_counters.json" % PROFILE_TAG)
     except Exception:
         pass
     return traffic, valu, src
@@ -174,7 +174,7 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
     achieved = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic, valu, src = committed_counters(stage, pairs_per_step, frames_per_launch)
     rl = {"bound": "hbm", "kernel": stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "counter_source": src or None,
+          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if traffic is None else int(traffic / launches), "counter_source": src or None,
           "algorithmic_bytes_per_launch": int(algo / launches), "launch_ms": round(ms / launches, 5), "launches_per_step_and_handle": launches,
           "frames_per_launch": frames_per_launch}
     if moved_bytes is not None:       # describe: the kernel does not move the reference's full-level blur; GB/s on the bytes it requests

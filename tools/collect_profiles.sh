@@ -5,15 +5,19 @@ TAG=${1:-x}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $OUT/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
+timeout 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $OUT/bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
 python3 tools/pmc_traffic.py report $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.csv
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1
-python3 tools/bench_matchers.py > $OUT/matchers.json 2>/dev/null
-python3 tools/bench_pcie.py > $OUT/pcie.json 2>/dev/null
-python3 bench.py --config c3 --steps 20 --warmup 3 > $OUT/c3.json 2>/dev/null
-python3 bench.py --config c5 --steps 50 --warmup 5 > $OUT/c5.json 2>/dev/null
-for b in 1 4 64; do python3 bench.py --pairs $b --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_pairs$b.json; done
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1
+timeout 300 python3 tools/bench_matchers.py > $OUT/matchers.json 2>/dev/null
+timeout 300 python3 tools/bench_pcie.py > $OUT/pcie.json 2>/dev/null
+timeout 300 python3 bench.py --config c3 --steps 20 --warmup 3 > $OUT/c3.json 2>/dev/null
+timeout 300 python3 bench.py --config c4 --steps 30 --warmup 3 > $OUT/c4.json 2>/dev/null
+timeout 300 python3 bench.py --config c5 --steps 50 --warmup 5 > $OUT/c5.json 2>/dev/null
+timeout 300 python3 bench.py --config c5 --c5-match bow --steps 50 --warmup 5 > $OUT/c5_bow.json 2>/dev/null
+for b in 1 4 64; do timeout 300 python3 bench.py --pairs $b --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_pairs$b.json; done
+for hn in 1 3; do timeout 300 python3 bench.py --handles $hn --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_handles$hn.json; done
+timeout 120 tools/micro/valu_peak > $OUT/valu_issue_rates.txt 2>&1
 tail -1 $OUT/bench.json | cut -c1-400

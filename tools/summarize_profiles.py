@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_TAG (made by tools/collect_profiles.sh on the GPU box) into the committed files under profiles/."""
+"""Turns gpurun_out/prof_TAG (made by tools/collect_profiles.sh on the GPU box) into the committed files under profiles/.
+usage: python tools/summarize_profiles.py TAG PREFIX          e.g.  a r02"""
 import collections
 import csv
 import glob
@@ -7,9 +8,10 @@ import json
 import os
 import sys
 
-tag, rnd = sys.argv[1], sys.argv[2]          # e.g. final r01_e
+tag, rnd = sys.argv[1], sys.argv[2]
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
+PAIRS, HANDLES = 16, 2          # bench.py defaults: 16 pairs per step dealt over 2 handles -> every launch sequence covers 16 frames
 
 
 def first(pattern):
@@ -17,44 +19,74 @@ def first(pattern):
     return g[0] if g else None
 
 
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
 f = first("stats/**/*kernel_stats.csv")
 rows = list(csv.reader(open(f)))
 with open("profiles/%s_kernel_stats.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0\n")
-    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step dealt over 2 handles -> every kernel launch covers 16 frames; MI355X; tag %s\n" % tag)
+    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step dealt over 2 handles -> every launch sequence covers 16 frames; MI355X; tag %s\n" % tag)
     w = csv.writer(o)
     for r in rows:
-        r[0] = r[0].split("(")[0][:60]
+        r[0] = short(r[0])[:60]
         w.writerow(r)
+# per-launch durations of the pyramid launches by grid (kernel trace)
+kt = first("stats/**/*kernel_trace.csv")
+if kt:
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        k = short(r["Kernel_Name"])
+        if k.startswith("k_resize"):
+            d[(k, int(r["Grid_Size_X"]) // 256, int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open("profiles/%s_pyramid_launches.csv" % rnd, "w") as o:
+        o.write("# per-launch duration of the pyramid kernels by grid (workgroups x, y, frames), rocprofv3 --kernel-trace of the same run\nkernel,grid_x,grid_y,frames,launches,avg_us\n")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            o.write("%s,%d,%d,%d,%d,%.2f\n" % (k[0], k[1], k[2], k[3], len(v), sum(v) / len(v) / 1e3))
 open("profiles/%s_hbm_traffic_pmc.csv" % rnd, "w").write(open(os.path.join(src, "traffic.csv")).read())
 tr = {}
 for r in csv.reader(l for l in open(os.path.join(src, "traffic.csv")) if not l.startswith("#")):
     if r[0] == "kernel":
         continue
-    tr[r[0].split("<")[0]] = {"read_MB": float(r[4]), "written_MB": float(r[5]), "frames_per_launch": int(r[6]), "launches": int(r[1])}
+    # pmc_traffic.py runs 3 steps of one handle with two lanes = 6 launch sequences
+    tr[r[0].split("<")[0]] = {"read_MB": float(r[4]), "written_MB": float(r[5]), "frames_per_launch": int(r[6]), "launches": int(r[1]),
+                              "launches_per_sequence": int(r[1]) / 6.0}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/pmc_traffic.py; FETCH_SIZE x2 (gfx950, calibrated on "
-                     "a 1 GiB copy at 4 B/lane and 16 B/lane), WRITE_SIZE x1", "pairs_per_step": 16, "kernels": tr},
+                     "a 1 GiB copy at 4 B/lane and 16 B/lane), WRITE_SIZE x1", "pairs_per_step": PAIRS, "kernels": tr},
           open("profiles/%s_hbm_traffic.json" % rnd, "w"), indent=1)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(first("sq/**/*counter_collection.csv"))):
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    k = short(r["Kernel_Name"])
     if k.startswith("k_"):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = sorted({c for d in agg.values() for c in d})
+sq = {}
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
     o.write("# per-launch averages; bench.py default (2 handles x 8 pairs): 16 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
-    names = sorted({c for d in agg.values() for c in d})
     o.write("kernel,launches," + ",".join(names) + "\n")
     for k, d in agg.items():
-        o.write(k.replace(",", ";") + "," + str(len(next(iter(d.values())))) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names) + "\n")
+        n = len(next(iter(d.values())))
+        o.write(k.replace(",", ";") + "," + str(n) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names) + "\n")
+        # 5 steps (1 warm-up + 4) x 2 handles = 10 launch sequences
+        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / 10.0)
+json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
+           "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
-for name in ("bench", "matchers", "pcie", "c3", "c5", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_under_rocprof"):
+for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles1", "bench_handles3", "bench_under_rocprof"):
     p = os.path.join(src, name + ".json")
     try:
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
         summary[name] = json.loads(line)
-    except Exception as e:
+    except Exception:
         summary[name] = None
 json.dump(summary, open("profiles/%s_bench_lines.json" % rnd, "w"), indent=1)
+try:
+    open("profiles/%s_valu_issue_rates.txt" % rnd, "w").write(
+        "# tools/micro/valu_peak: wave-instructions per cycle and CU (at the nominal 2.4 GHz) of the instruction classes the kernels are made of, by waves per SIMD\n" +
+        "".join(l for l in open(os.path.join(src, "valu_issue_rates.txt")) if l.startswith("v_")))
+except Exception:
+    pass
 b = summary["bench"]
 print("value", b["value"], b["stage_ms_per_step"], b["roofline"])
