@@ -19,6 +19,7 @@ struct hs_orb {
     std::string err;
     uint16_t taps[7];
     HsFastKnobs fast_knobs{};          // HS_FAST_* environment knobs, read once in hs_orb_create
+    uint32_t fast_epoch = 0;           // FAST launches on this workspace so far (selects the work-queue counter set)
     bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
@@ -230,6 +231,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch, h->fast_knobs), 256)));
+        HIP_TRY(h, hipMemset(h->d_fast_ovf, 0, 2 * HS_FAST_QUEUE_DWORDS * 4));       // both work-queue counter sets start at zero
     }
     h->w = w; h->h = hh; h->batch_cap = batch;      // configured only now
     return HS_OK;
@@ -303,7 +305,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
     hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_knobs, s);
+                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch++, h->fast_knobs, s);
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, s);

@@ -129,12 +129,13 @@ int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kerne
 int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
 int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
-#define HS_FAST_QUEUE_DWORDS 256   // head of the FAST overflow buffer: 8 work-queue counters on 128-byte lines of their own, zeroed by the launcher
+#define HS_FAST_QUEUE_DWORDS 256   // head of the FAST overflow buffer: two alternating sets of 8 work-queue counters on 128-byte lines of their own
 struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes()*/, const HsFastKnobs& knobs, hipStream_t s);
+                    int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
+                    const HsFastKnobs& knobs, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,

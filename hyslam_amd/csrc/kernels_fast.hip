@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                                                   uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
-                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride)
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -189,8 +189,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
     uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
     uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
-    uint32_t* const queue = overflow;                                            // 8 work counters, 128 bytes apart (HS_FAST_QUEUE_DWORDS)
-    uint32_t* const ovf = overflow + HS_FAST_QUEUE_DWORDS + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
+    uint32_t* const queue = overflow + (size_t)(epoch & 1) * HS_FAST_QUEUE_DWORDS;   // 8 work counters, 128 bytes apart
+    if (blockIdx.x == 0 && threadIdx.x < 8) overflow[(size_t)((epoch + 1) & 1) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
+    uint32_t* const ovf = overflow + 2 * HS_FAST_QUEUE_DWORDS + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
     const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
     const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
 
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     // wave cycles waiting).  The grab for the item after next is issued right after the next tile's prefetch and consumed an item later,
     // so its latency is never exposed; 8 counters on lines of their own see ~11 grabs/us each.  When a queue runs dry its waves steal
     // from the other queues, and leave when all eight are empty (every wave reaches that exit: the counters only grow).
-    // The counters are zeroed by the launcher (a 1 KB hipMemsetAsync ahead of the kernel, only for launches with more items than waves).
+    // Two counter sets alternate between launches: a launch uses set `epoch & 1` and its first workgroup zeroes the OTHER set for the launch
+    // after it (launches of a handle are ordered on its stream; both sets start at zero) — no memset launch in the chain.
     const int per_x = (total_work + 7) >> 3, wpx = gridDim.x >> 3;
     int q = (int)(blockIdx.x & 7);                               // current queue (wave-uniform)
     auto q_size = [&](int qq) { return min(max(total_work - qq * per_x, 0), per_x); };
@@ -640,12 +642,12 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
-    return (size_t)HS_FAST_QUEUE_DWORDS * 4 + (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
+    return (size_t)2 * HS_FAST_QUEUE_DWORDS * 4 + (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
 }
 
 static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, uint32_t* overflow, const HsFastKnobs& knobs, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)max_wcell;
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
@@ -654,10 +656,9 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return;
     const int nblk = fast_rows_grid(c, total_work);
-    if (total_work > nblk) (void)hipMemsetAsync(overflow, 0, HS_FAST_QUEUE_DWORDS * 4, s);      // work-queue counters (dynamic launches only)
     const int force_scan_b = knobs.force_scan_b;
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
@@ -665,9 +666,9 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 
 void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow, const HsFastKnobs& knobs, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0) return;
-    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, knobs, s);
+    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
 }
