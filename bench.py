@@ -38,8 +38,8 @@ PROFILE_TAG = "r02"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 16 pairs = 0.11 s of GPU work at the default)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4,
                     help="distinct synthetic pairs generated per rank; the batch holds --pairs separate copies (pair i = distinct pair i %% distinct), "

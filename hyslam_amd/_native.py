@@ -71,7 +71,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
-    "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
+    "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
@@ -118,6 +118,7 @@ def lib():
                                                   vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
     L.hs_orb_set_lanes.argtypes = [vp, C.c_int]
     L.hs_orb_synchronize.argtypes = [vp, vp]
+    L.hs_frame_grid.argtypes = [vp, C.POINTER(FrameView), vp]
     L.hs_search_by_projection.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
     L.hs_search_by_projection_device.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp, vp]
     L.hs_search_by_projection_sim3.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.c_int, C.c_int, f32, vp, vp, vp]

@@ -746,6 +746,25 @@ int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark
     return HS_OK;
 }
 
+int hs_frame_grid(hs_orb* h, const hs_frame_view* F, int8_t* cell_xy)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!F || F->n < 0 || F->n > 65535 || (F->n > 0 && (!F->kps || !cell_xy))) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (F->n == 0) return HS_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nn = F->n;
+    int rc = scratch_begin(h, pad256(nn * sizeof(hs_keypoint)) + pad256(hs_frame_grid_bytes((int)nn)) + 256);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    hs_keypoint* d_kps = carve<hs_keypoint>(h, nn); int8_t* d_cell = carve<int8_t>(h, hs_frame_grid_bytes((int)nn));
+    HIP_TRY(h, hipMemcpyAsync(d_kps, F->kps, nn * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
+    hs_launch_frame_grid(*F, d_kps, d_cell, false, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(cell_xy, d_cell, nn * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HS_OK;
+}
+
 int hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,
                                    int32_t* d_match_idx, float* d_match_dist, int32_t* d_n_matches, void* stream)
 {

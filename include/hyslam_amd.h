@@ -196,6 +196,11 @@ typedef struct hs_proj_params {
 int  hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
                              int32_t* match_idx, float* match_dist, int32_t* n_matches);
 
+/* Frame::AssignFeaturesToGrid / PosInGrid (src/core/Frame.cc:137-153,459-469): the 64 x 48 grid cell of every keypoint, cell = round((x - mnMinX) *
+ * 64 / (mnMaxX - mnMinX)) (nearest, not floor), -1 when outside.  cell_xy [n][2] int8 (column, row).  The matchers build this grid on the device
+ * themselves; the entry point exposes it for Frame construction on the host side and for tests.  Host pointers; synchronous. */
+int  hs_frame_grid(hs_orb* h, const hs_frame_view* F, int8_t* cell_xy);
+
 /* the same on device-resident data (FeatureViews stay in HBM between extraction and tracking): every pointer inside *F and
  * d_lms / d_match_idx / d_match_dist / d_n_matches are device pointers (F->kps / F->desc can be the extractor's own outputs).  Asynchronous. */
 int  hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,

@@ -243,3 +243,23 @@ def test_sim3_projection_and_search(matcher):
     gm, gn = matcher.SearchBySim3(KFg, l1b, K2g, l2, s12, R12, t12, 7.5)
     om, on = oracle.search_by_sim3(KFo, l1b, K2o, l2, s12, R12, t12, 7.5, 100.0)
     assert on > 100 and gn == on and np.array_equal(gm, om)
+
+
+def test_frame_grid(matcher):
+    """Frame::AssignFeaturesToGrid / PosInGrid (row M7): cells of every keypoint, including keypoints on the borders (round, not floor: the last
+    column / row rounds to 64 / 48 = outside) and outside the bounds"""
+    import ctypes as C
+    sc = scenes.projection_scene(45, 640, 480, nfeat=1000, copies=1)
+    fa = dict(sc["frame_args"])
+    k = fa["kps"].copy()
+    k["x"][:6] = [0.0, 639.9, 4.99, 5.0, 634.9, 700.0]          # 4.99 * 0.1 rounds to 0, 5.0 * 0.1 = 0.5 rounds away from zero to 1 (std::round)
+    k["y"][:6] = [0.0, 479.9, 475.1, 5.0, -3.0, 10.0]
+    fa["kps"] = k
+    Fo, k1 = oracle.make_frame_view(oracle.FrameView, **fa)
+    Fg, k2 = oracle.make_frame_view(N.FrameView, **fa)
+    want = oracle.frame_grid(Fo)
+    got = np.zeros((len(k), 2), np.int8)
+    ex = matcher._ex
+    N.check(ex._h, ex._lib.hs_frame_grid(ex._h, C.byref(Fg), got.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(got.astype(np.int32), want)
+    assert (want[:6] == -1).any() and (want >= -1).all() and want[:, 0].max() <= 63 and want[:, 1].max() <= 47
