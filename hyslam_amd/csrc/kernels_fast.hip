@@ -139,6 +139,11 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
 #define FR_PAD 16            // row padding of the LDS tiles, bytes (multiple of 16)
 #endif
 
+// Instruction-budget builds (tools/fast_instr_breakdown.sh): make EXTRA=-DFR_STOP=n cuts the item short after phase n — 1 scan A masks,
+// 2 + list expansion, 3 + segment test, 4 + scores; results are meaningless (no candidates come out), only the SQ counters are read.
+#ifndef FR_STOP
+#define FR_STOP 99
+#endif
 #ifdef HS_FAST_PROFILE       // make EXTRA=-DHS_FAST_PROFILE: per-phase cycle totals over all waves (tools/fast_phase_profile.py)
 __device__ unsigned long long g_fr_prof[16];
 #define FR_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         // ---- pixel list -> corners -> scores
         // ---- scan codes [n_done, npx) of the list -> corners -> scores; the scored corners stay at the head of the list
         auto corners_and_scores = [&]() {
+            if (FR_STOP <= 2) { npx = n_done = 0; return; }
             FR_FENCE();
             FR_T(tc0);
             int n_corner = n_done;
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             FR_FENCE();
             FR_T(tc1);
             FR_ACC(4, tc0, tc1);
+            if (FR_STOP <= 3) { npx = n_done = 0; return; }
             for (int i = n_done + tid; i < n_corner; i += 64) {
                 const int pos = plist[i];
                 const bool bright = pos & 0x8000;
@@ -476,14 +483,16 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior
                     M &= vmask8 & (((1u << nrow) - 1u) * 0x01010101u);
                 }
+                if (FR_STOP <= 1) { if (M == 0x12345u) plist[tid] = 1; continue; }      // keeps M live
                 emit_mask(M, y0, false, b);
             }
             corners_and_scores();
         }
         FR_T(t4);
         FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
+        if (FR_STOP <= 4) n_done = 0;
         // ---- the pixel tile is dead: its LDS becomes the dense score tile (rows 0..ih+1, zero except at the corners)
-        for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
+        if (FR_STOP > 4) for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
         for (int i = tid; i < n_done; i += 64) {
             const int pos = plist[i];
             score[(pos >> 8) * PITCH + (pos & 255)] = pscore[i];

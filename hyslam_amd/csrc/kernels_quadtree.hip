@@ -136,16 +136,26 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
         constexpr int CPT = 4;                                     // cells per thread and round: the counts of a round are independent loads
         static_assert(sizeof(child_index) >= QT_T * CPT * 4, "s_pre scratch");
-        for (int c0 = 0; c0 < ncell; c0 += QT_T * CPT) {
-            int k[CPT], ksum = 0;
+        int cpt = CPT;
+        for (int c0 = 0; c0 < ncell;) {
+            // a round takes cpt cells per thread: as many as leave the round's records inside the scratch (dense frames: a 4000x3000 level
+            // has 3.3 records per cell and 4096 cells overflowed it — the per-cell fallback below then cost a quarter of the kernel);
+            // the next round starts from the density this one found
+            int k[CPT], ksum, tot, pre;
+            for (;;) {
+                ksum = 0;
 #pragma unroll
-            for (int q = 0; q < CPT; q++) { const int c = c0 + tid * CPT + q; k[q] = c < ncell ? min(ccnt[c], ccap) : 0; ksum += k[q]; }
-            int tot; int pre = block_scan_excl(ksum, s_wave, tot);
+                for (int q = 0; q < CPT; q++) { const int c = c0 + tid * cpt + q; k[q] = (q < cpt && c < ncell) ? min(ccnt[c], ccap) : 0; ksum += k[q]; }
+                pre = block_scan_excl(ksum, s_wave, tot);
+                if (tot <= QT_GKEYS || cpt == 1) break;
+                cpt >>= 1;
+            }
+            const int round_cells = QT_T * cpt;
             if (tot <= QT_GKEYS) {
 #pragma unroll
                 for (int q = 0; q < CPT; q++) {
-                    s_pre[tid * CPT + q] = (uint32_t)pre;
-                    for (int i = 0; i < k[q]; i++) s_cell[pre + i] = (uint16_t)(tid * CPT + q);
+                    if (q < cpt) s_pre[tid * cpt + q] = (uint32_t)pre;
+                    for (int i = 0; i < k[q]; i++) s_cell[pre + i] = (uint16_t)(tid * cpt + q);
                     pre += k[q];
                 }
                 __syncthreads();
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     const int lc = s_cell[e];
                     const int first = (int)s_pre[lc], i = e - first;
                     const uint32_t sk = ssk[(size_t)(c0 + lc) * ccap + i];           // in flight during the rank loop
-                    const int last = (lc + 1 < QT_T * CPT) ? (int)s_pre[lc + 1] : tot;   // cells past the last one have k = 0: s_pre = tot
+                    const int last = (lc + 1 < round_cells) ? (int)s_pre[lc + 1] : tot;   // cells past the last one have k = 0: s_pre = tot
                     const uint32_t key = s_key[e];
                     int rank = 0;
                     for (int j = first; j < last; j++) rank += s_key[j] < key;
@@ -168,8 +178,8 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 __syncthreads();                                   // the scratch is reused by the next round
             } else {                                               // saturated image: more records than the scratch holds; one thread per cell
 #pragma unroll
-                for (int q = 0; q < CPT; q++) {
-                    const size_t src = (size_t)min(c0 + tid * CPT + q, ncell - 1) * ccap;
+                for (int q = 0; q < CPT; q++) {                    // cpt == 1 here: k[1..] = 0
+                    const size_t src = (size_t)min(c0 + tid * cpt + q, ncell - 1) * ccap;
                     for (int i = 0; i < k[q]; i++) {
                         const uint32_t key = sxy[src + i];
                         int rank = 0;
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 }
             }
             n += tot;
+            c0 += round_cells;
         }
         __syncthreads();      // the dense list is complete (written and read by this workgroup only)
     }

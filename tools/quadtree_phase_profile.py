@@ -6,8 +6,9 @@ import ctypes as C, sys
 sys.path.insert(0, ".")
 import hyslam_amd as HS
 from hyslam_amd.synth import synth_stereo_pair
-L, R = synth_stereo_pair(1, 1920, 1080)
-ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000, fScaleFactor=1.2, nLevels=8))
+W, H, NF, SF = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080, 2000, 1.2)
+L, R = synth_stereo_pair(1, W, H)
+ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF, fScaleFactor=SF, nLevels=8))
 ex.extract_batch([L, R]); ex.extract_batch([L, R])
 out = (C.c_ulonglong * 128)()
 ex._lib.hs_debug_qt_profile(out)
