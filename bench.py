@@ -45,9 +45,11 @@ def parse_args():
                     help="distinct synthetic pairs generated per rank; the batch holds --pairs separate copies (pair i = distinct pair i %% distinct), "
                          "so no two frames of a step share an address")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH of the two CPU baseline samples (0 = skip)")
-    ap.add_argument("--handles", type=int, default=2,
+    ap.add_argument("--handles", type=int, default=1,
                     help="extractor handles per GPU; the pairs of a step are dealt over them and each runs on its own stream (the reference also "
-                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32)")
+                         "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  Default 1: every kernel then has the GPU "
+                         "to itself and its HIP-event duration is its own cost (the roofline block); 2 handles overlap the latency-bound stages of "
+                         "one with the wide kernels of the other (+4 %% pairs/s) but each kernel's duration then includes the time it shares")
     ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
                     help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",

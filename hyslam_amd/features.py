@@ -116,7 +116,11 @@ class ORBExtractor:
         return k[0], d[0]
 
     def extract_batch(self, images):
-        imgs = [np.ascontiguousarray(im) for im in images]
+        # row-strided views (a cv::Mat ROI: unit pixel stride, row stride >= width) go to the C ABI as they are
+        strided = lambda im: isinstance(im, np.ndarray) and im.ndim == 2 and im.dtype == np.uint8 and im.strides[1] == 1 and im.strides[0] >= im.shape[1]
+        imgs = [im if strided(im) else np.ascontiguousarray(im) for im in images]
+        if len({im.strides[0] for im in imgs if im.ndim == 2}) > 1:           # one row stride per call
+            imgs = [np.ascontiguousarray(im) for im in imgs]
         for im in imgs:
             if im.dtype != np.uint8 or im.ndim != 2:
                 raise TypeError("image must be CV_8UC1 (2-D uint8)")          # assert(image.type() == CV_8UC1), :503

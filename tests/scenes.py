@@ -61,10 +61,10 @@ def projection_scene(seed, w=640, h=480, nfeat=1000, copies=3, sensor=1, fx=500.
     t["desc"] = rng.integers(0, 256, (len(t), 32), dtype=np.uint8)
     t["skip"][-5:] = 1
     # a few landmarks already associated with a keypoint of this frame (landMarkSizePixels uses the keypoint size then)
-    pick = rng.choice(n, 25, replace=False)
+    pick = rng.choice(n, min(25, n), replace=False)
     lms["assoc_kp"][pick] = pick
     kp_lm_obs = np.full(n, -1, np.int32)
-    kp_lm_obs[rng.choice(n, 60, replace=False)] = rng.integers(0, 4, 60)                  # 0 observations must NOT block a keypoint
+    kp_lm_obs[rng.choice(n, min(60, n), replace=False)] = rng.integers(0, 4, min(60, n))                  # 0 observations must NOT block a keypoint
     perm = rng.permutation(len(lms))
     frame_args = dict(Rcw=Rcw, tcw=tcw, fx=fx, fy=fx, cx=cx, cy=cy, mbf=fx * 0.12, sensor=sensor, bounds=(0.0, float(w), 0.0, float(h)),
                       kps=kps, desc=desc, uR=uR, kp_lm_obs=kp_lm_obs)

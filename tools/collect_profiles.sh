@@ -18,6 +18,6 @@ timeout 300 python3 bench.py --config c4 --steps 30 --warmup 3 > $OUT/c4.json 2>
 timeout 300 python3 bench.py --config c5 --steps 50 --warmup 5 > $OUT/c5.json 2>/dev/null
 timeout 300 python3 bench.py --config c5 --c5-match bow --steps 50 --warmup 5 > $OUT/c5_bow.json 2>/dev/null
 for b in 1 4 64; do timeout 300 python3 bench.py --pairs $b --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_pairs$b.json; done
-for hn in 1 3; do timeout 300 python3 bench.py --handles $hn --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_handles$hn.json; done
+for hn in 2 3; do timeout 300 python3 bench.py --handles $hn --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_handles$hn.json; done
 timeout 120 tools/micro/valu_peak > $OUT/valu_issue_rates.txt 2>&1
 tail -1 $OUT/bench.json | cut -c1-400

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised extraction + stereo parity sweep: the HIP path against the oracle on random frame sizes, row strides, feature counts, scale
+factors, level counts and image statistics (structured scenes, noise, checkerboards that saturate FAST, nearly flat frames).
+Runs on the GPU box:  python3 tools/fuzz_parity.py --cases 300 --seed 1      (every case is printed; exit code 1 on the first mismatch)"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle                                   # noqa: E402  (tests/oracle.py: the checker)
+import hyslam_amd as HS                         # noqa: E402
+from hyslam_amd.synth import synth_image, synth_stereo_pair   # noqa: E402
+
+
+def make_image(rng, kind, w, h, seed):
+    if kind == "scene":
+        return synth_image(seed, w, h)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == "checker":                      # high-contrast blobs of random pitch: corner-saturated, exercises the list-overflow paths
+        p = int(rng.integers(3, 12))
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (((yy // p) + (xx // p)) % 2 * int(rng.integers(120, 255))).astype(np.int32) + rng.integers(0, 30, (h, w))
+        return np.clip(img, 0, 255).astype(np.uint8)
+    if kind == "flat":                         # nearly empty: a handful of corners, many empty cells and levels
+        img = np.full((h, w), int(rng.integers(20, 230)), np.int32) + rng.integers(0, 6, (h, w))
+        for _ in range(int(rng.integers(0, 12))):
+            x, y, s = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8)), int(rng.integers(3, 9))
+            img[y:y + s, x:x + s] += int(rng.integers(60, 120))
+        return np.clip(img, 0, 255).astype(np.uint8)
+    # gradient + mid-frequency texture
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 128 + 60 * np.sin(xx / float(rng.integers(3, 40))) * np.cos(yy / float(rng.integers(3, 40))) + (xx * 40.0 / w) + rng.normal(0, float(rng.uniform(0, 12)), (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def one_case(rng, i):
+    kind = ["scene", "scene", "noise", "checker", "flat", "texture"][int(rng.integers(0, 6))]
+    w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
+    h = int(rng.integers(64, 1100)) if rng.random() < 0.85 else int(rng.integers(1100, 1700))
+    if rng.random() < 0.95:
+        h = min(h, 2 * w - 1)                   # w/h < 0.5 gives zero root nodes in the reference (division by zero, :183): refused by the library
+    nfeat = int(rng.integers(20, 4000))
+    scale = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.25, 1.3, 1.4, 1.5, 2.0])))
+    levels = int(rng.choice([1, 2, 4, 6, 8, 8, 8, 10, 12]))
+    if levels <= 2:
+        nfeat = min(nfeat, int(rng.integers(20, 2000)))      # a level's quota is limited to 2040 (quadtree list in LDS)
+    seed = int(rng.integers(0, 1 << 30))
+    desc = "case %d: %s %dx%d nfeat %d scale %.2f levels %d seed %d" % (i, kind, w, h, nfeat, scale, levels, seed)
+    try:
+        ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels))
+    except Exception as e:                      # configuration the library refuses (too many levels for the size etc.): must be refused cleanly
+        return desc + "  -> refused at create: %s" % str(e)[:60], True
+    img = make_image(rng, kind, w, h, seed)
+    pad = int(rng.choice([0, 0, 1, 3, 16, 61]))
+    if pad:                                     # a row stride larger than the width (odd strides take the unaligned load path)
+        buf = np.zeros((h, w + pad), np.uint8)
+        buf[:, :w] = img
+        view = buf[:, :w]
+    else:
+        view = img
+    try:
+        gk, gd = ex(view)
+    except Exception as e:
+        return desc + "  -> refused at extract: %s" % str(e)[:80], True
+    p = oracle.default_params(nfeat, scale, levels)
+    big = 4 * nfeat + 64 * levels + 1024         # small quotas overshoot: a breadth-first pass quadruples the list before the size is checked
+    ok, od = oracle.extract(p, np.ascontiguousarray(img), cap=big)
+    good = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
+    msg = desc + " pad %d -> %d keypoints %s" % (pad, len(ok), "ok" if good else "MISMATCH (gpu %d)" % len(gk))
+    if good and len(ok) > 20 and rng.random() < 0.3:      # stereo: shifted copy with noise as the right frame
+        sh = int(rng.integers(1, 40))
+        right = np.roll(img, -sh, axis=1).copy()
+        right = np.clip(right.astype(np.int32) + rng.integers(-3, 4, right.shape), 0, 255).astype(np.uint8)
+        gkR, gdR = ex(right)
+        okR, odR = oracle.extract(p, right, cap=big)
+        good = gkR.tobytes() == okR.tobytes() and np.array_equal(gdR, odR)
+        fx = float(rng.uniform(300, 1500))
+        sp = oracle.stereo_params(fx=fx, mbf=fx * 0.12, n_rows=h)
+        ouR, odepth, _, _ = oracle.stereo_match(ok, od, okR, odR, sp)
+        sm = HS.Stereomatcher(gk, gkR, gd, gdR, HS.Camera(fx, fx * 0.12, float(h)), extractor=ex)
+        sm.computeStereoMatches()
+        guR, gdepth = sm.getData()
+        sgood = np.array_equal(guR, ouR) and np.array_equal(gdepth, odepth)
+        msg += "; stereo shift %d: %d matches %s" % (sh, int((odepth > 0).sum()), "ok" if (good and sgood) else "MISMATCH")
+        good = good and sgood
+    return msg, good
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0, bad = time.time(), 0
+    for i in range(a.cases):
+        msg, good = one_case(rng, i)
+        print(msg, flush=True)
+        bad += not good
+        if not good or time.time() - t0 > a.seconds:
+            break
+    print("fuzz: %d cases, %d mismatches, %.0f s" % (i + 1, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GIB = 1 << 30
 PAIRS = 16
-LANES = 2            # two launch sequences of 8 pairs each per step, the same launch shapes as bench.py's default (2 handles x 8 pairs)
+LANES = 1            # one launch sequence of 16 pairs per step: the launch shapes of bench.py's default (one handle)
 
 
 def run():

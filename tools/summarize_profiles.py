@@ -11,7 +11,7 @@ import sys
 tag, rnd = sys.argv[1], sys.argv[2]
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
-PAIRS, HANDLES = 16, 2          # bench.py defaults: 16 pairs per step dealt over 2 handles -> every launch sequence covers 16 frames
+PAIRS, HANDLES = 16, 1          # bench.py defaults: 16 pairs per step on one handle -> every launch sequence covers 32 frames
 
 
 def first(pattern):
@@ -27,7 +27,7 @@ f = first("stats/**/*kernel_stats.csv")
 rows = list(csv.reader(open(f)))
 with open("profiles/%s_kernel_stats.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0\n")
-    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step dealt over 2 handles -> every launch sequence covers 16 frames; MI355X; tag %s\n" % tag)
+    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step on one handle -> every launch sequence covers 32 frames; MI355X; tag %s\n" % tag)
     w = csv.writer(o)
     for r in rows:
         r[0] = short(r[0])[:60]
@@ -49,9 +49,9 @@ tr = {}
 for r in csv.reader(l for l in open(os.path.join(src, "traffic.csv")) if not l.startswith("#")):
     if r[0] == "kernel":
         continue
-    # pmc_traffic.py runs 3 steps of one handle with two lanes = 6 launch sequences
+    # pmc_traffic.py runs 3 steps of one handle = 3 launch sequences
     tr[r[0].split("<")[0]] = {"read_MB": float(r[4]), "written_MB": float(r[5]), "frames_per_launch": int(r[6]), "launches": int(r[1]),
-                              "launches_per_sequence": int(r[1]) / 6.0}
+                              "launches_per_sequence": int(r[1]) / 3.0}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/pmc_traffic.py; FETCH_SIZE x2 (gfx950, calibrated on "
                      "a 1 GiB copy at 4 B/lane and 16 B/lane), WRITE_SIZE x1", "pairs_per_step": PAIRS, "kernels": tr},
           open("profiles/%s_hbm_traffic.json" % rnd, "w"), indent=1)
@@ -64,17 +64,17 @@ names = sorted({c for d in agg.values() for c in d})
 sq = {}
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
-    o.write("# per-launch averages; bench.py default (2 handles x 8 pairs): 16 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
+    o.write("# per-launch averages; bench.py default (one handle, 16 pairs): 32 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
     o.write("kernel,launches," + ",".join(names) + "\n")
     for k, d in agg.items():
         n = len(next(iter(d.values())))
         o.write(k.replace(",", ";") + "," + str(n) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names) + "\n")
-        # 5 steps (1 warm-up + 4) x 2 handles = 10 launch sequences
-        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / 10.0)
+        # 5 steps (1 warm-up + 4) x HANDLES launch sequences
+        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / (5.0 * HANDLES))
 json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
-for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles1", "bench_handles3", "bench_under_rocprof"):
+for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof"):
     p = os.path.join(src, name + ".json")
     try:
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
