@@ -26,7 +26,28 @@
 #include "../../include/hyslam_orb_pattern.h"
 
 __constant__ int8_t c_pattern[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
-__constant__ int8_t c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };   // ORBFinder.cpp:131-149
+
+// intensity-centroid weights per aligned dword of the blurred tile (ORBFinder.cpp:131-149): rows v = -15..15 of the tile (row 18 + v),
+// dwords q = 0..9 (columns 4q..4q+3, u = column - 18): .x bytes = u + 15, .y bytes = 1 inside the 749-pixel disc, 0 outside.
+// A compile-time table in constant memory: every workgroup used to rebuild it in LDS (70 instructions per keypoint, 2.4 KB per workgroup).
+struct MomW { uint2 w[31 * 10]; };
+static constexpr MomW make_momw()
+{
+    constexpr int umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+    MomW t{};
+    for (int i = 0; i < 31 * 10; i++) {
+        const int r = i / 10, q = i - r * 10;
+        const int av = r < 15 ? 15 - r : r - 15, d = umax[av];
+        unsigned wu = 0, w1 = 0;
+        for (int j = 0; j < 4; j++) {
+            const int uu = 4 * q + j - 18;
+            if ((uu < 0 ? -uu : uu) <= d) { wu |= (unsigned)(uu + 15) << (8 * j); w1 |= 1u << (8 * j); }
+        }
+        t.w[i].x = wu; t.w[i].y = w1;
+    }
+    return t;
+}
+__constant__ MomW c_momw = make_momw();
 
 #define RAW_N 43
 #define RAW_P 48                 // raw tile pitch: 12 dwords hold 43 bytes at any source misalignment (3 + 43 <= 48)
@@ -74,6 +95,23 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)   
     return __builtin_amdgcn_udot2(__builtin_bit_cast(hs_ushort2, a), __builtin_bit_cast(hs_ushort2, b), c, false);
 }
 
+#ifdef HS_DESC_PROFILE      // make EXTRA=-DHS_DESC_PROFILE: cycle stamps per phase and wave (tools/describe_phase_profile.py)
+#define DP_WAVES (1 << 17)
+__device__ unsigned int g_desc_prof[DP_WAVES * 8];      // a slot of 8 deltas per wave: plain stores (atomics on a few hot addresses would BE the profile)
+#define DP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DP_ACC(i, a, b) do { if (lane == 0 && dp_slot < DP_WAVES) g_desc_prof[dp_slot * 8 + (i)] = (unsigned int)((b) - (a)); } while (0)
+extern "C" void hs_debug_describe_profile(unsigned int* out, int waves)      // out[waves * 8]; clears the buffer
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_prof), sizeof(unsigned int) * 8 * (size_t)(waves < DP_WAVES ? waves : DP_WAVES));
+    void* p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_desc_prof));
+    (void)hipMemset(p, 0, sizeof(unsigned int) * 8 * DP_WAVES);
+}
+#else
+#define DP_T(var)
+#define DP_ACC(i, a, b)
+#endif
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)   // lgkmcnt(0)
 
 template <bool FT>
@@ -84,22 +122,10 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][H_ELEMS];
-    __shared__ uint2 s_momw[31 * 10];        // intensity-centroid weights per aligned dword of the blurred tile: .x bytes = u + 15, .y bytes = 1 (0 outside the disc)
-
-    // weights of the 749-pixel disc (ORBFinder.cpp:131-149): rows v = -15..15 of the tile (row 18 + v), dwords q = 0..9 (columns 4q..4q+3, u = column - 18)
-    for (int i = threadIdx.x; i < 31 * 10; i += 64 * KP_PER_BLOCK) {
-        const int r = i / 10, q = i - r * 10;
-        const int av = r < 15 ? 15 - r : r - 15, d = c_umax[av];
-        uint32_t wu = 0, w1 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int uu = 4 * q + j - 18;
-            if ((uu < 0 ? -uu : uu) <= d) { wu |= (uint32_t)(uu + 15) << (8 * j); w1 |= 1u << (8 * j); }
-        }
-        s_momw[i] = make_uint2(wu, w1);
-    }
-    __syncthreads();
-
+    DP_T(dp0);
+#ifdef HS_DESC_PROFILE
+    const int dp_slot = (blockIdx.y * gridDim.x + blockIdx.x) * KP_PER_BLOCK + (threadIdx.x >> 6);
+#endif
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index: uniform, so everything derived from the
     const int img = blockIdx.y;                                                                // keypoint record stays in SGPRs / scalar loads
     // Which keypoint: the image's keypoints are walked in SPATIAL order (level, 64-px tile; sel_perm from the quadtree kernel), and the
@@ -143,6 +169,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 #pragma unroll
     for (int k = 0; k < 7; k++) { const uint32_t w = hs_cload<uint32_t>(reinterpret_cast<const uint8_t*>(taps7) + 4 * (k >> 1)); tp[k] = (k & 1) ? (w >> 16) : (w & 0xFFFFu); }
 
+    DP_T(dp1);
+    DP_ACC(0, dp0, dp1);
     // ---- raw 43x43 neighbourhood.  Interior keypoints: aligned dword rows, the tile keeps the source misalignment `sh`.
     //      Patches that touch the level border: byte loads with BORDER_REFLECT_101.
     const int x0 = cx - 21, y0 = cy - 21;
@@ -165,6 +193,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         }
     }
     WAVE_LDS_SYNC();
+    DP_T(dp2);
+    DP_ACC(1, dp1, dp2);
 
     if (FT) {
         // ---- row pass: H[r][c..c+3] from three/four aligned dwords, two dot4 per output; stored transposed HT[c][r]
@@ -184,6 +214,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         }
         if (lane < BL_N) hb[lane * HT_P + 43] = 0;              // pad element (only ever multiplied by a zero tap)
         WAVE_LDS_SYNC();
+        DP_T(dp3);
+        DP_ACC(2, dp2, dp3);
         // ---- column pass: lane = (column c, even row r): dwords (r,r+1)..(r+6,r+7) of HT[c]; even rows use taps (t0,t1)(t2,t3)(t4,t5)(t6,0),
         //      the odd row r+1 uses (0,t0)(t1,t2)(t3,t4)(t5,t6) on the SAME dwords
         const uint32_t e0 = tp[0] | (tp[1] << 16), e1 = tp[2] | (tp[3] << 16), e2 = tp[4] | (tp[5] << 16), e3 = tp[6];
@@ -231,6 +263,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         }
     }
     WAVE_LDS_SYNC();
+    DP_T(dp4);
+    DP_ACC(3, dp2, dp4);                                         // row + column pass (2 = row pass alone)
 
     // ---- intensity centroid (ORBFinder.cpp:16-43): integer moments over the umax disc
     //      m10 = sum u*I, m01 = sum v*I as v_dot4_u32_u8 over aligned dwords: sum (u+15)*I - 15*sum I, and v * (row sum)
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         for (int i = lane; i < 31 * 10; i += 64) {
             const int r = i / 10, q = i - r * 10;
             const uint32_t W = bl32[(3 + r) * (BL_P / 4) + q];
-            const uint2 wt = s_momw[i];
+            const uint2 wt = c_momw.w[i];
             const int s1 = (int)__builtin_amdgcn_udot4(W, wt.y, 0u, false), su = (int)__builtin_amdgcn_udot4(W, wt.x, 0u, false);
             m10 += su - 15 * s1; m01 += (r - 15) * s1;
         }
@@ -248,6 +282,8 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    DP_T(dp5);
+    DP_ACC(4, dp4, dp5);
 
     // ---- rBRIEF (ORBFinder.cpp:89-129)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
@@ -278,6 +314,10 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         k.size = L.kp_size; k.angle = angle; k.response = (float)score; k.octave = level;
         kps[(size_t)oimg * cap + g] = k;
     }
+    DP_T(dp6);
+    DP_ACC(5, dp5, dp6);
+    DP_ACC(6, dp0, dp6);
+    DP_ACC(7, 0ull, 1ull);
 }
 
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
