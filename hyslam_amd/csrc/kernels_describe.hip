@@ -23,9 +23,20 @@
 // rows use a tap packing shifted by one element instead of shifting data).  Integer sums are exact, so this is
 // bit-identical to the generic path, which stays for exotic taps and for keypoints whose patch crosses the border.
 #include "hs_internal.h"
+#define HS_HD __host__ __device__
+#include "lean_sincos.h"
 #include "../../include/hyslam_orb_pattern.h"
 
-__constant__ int8_t c_pattern[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
+// the 256 test pairs (x0, y0, x1, y1) as floats, 16 bytes per test: one 16-byte load per lane and round, no byte extraction / conversion
+struct alignas(16) PatternF { float v[HS_ORB_PATTERN_INTS]; };
+static constexpr PatternF make_pattern_f()
+{
+    constexpr int8_t src[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
+    PatternF t{};
+    for (int i = 0; i < HS_ORB_PATTERN_INTS; i++) t.v[i] = (float)src[i];
+    return t;
+}
+__constant__ PatternF c_pattern = make_pattern_f();
 
 // intensity-centroid weights per aligned dword of the blurred tile (ORBFinder.cpp:131-149): rows v = -15..15 of the tile (row 18 + v),
 // dwords q = 0..9 (columns 4q..4q+3, u = column - 18): .x bytes = u + 15, .y bytes = 1 inside the 749-pixel disc, 0 outside.
@@ -180,10 +191,15 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         // is aligned to the patch and the row pass below needs no per-keypoint byte shifts
         struct __attribute__((packed, aligned(1))) U128 { hs_u32x4 v; };
         typedef const HS_GLOBAL U128* gu128;
-        const uint8_t* src = base + (size_t)y0 * pitch + x0;
-        for (int i = lane; i < RAW_N * 3; i += 64) {
-            int r = i / 3, q = i - r * 3;
-            *reinterpret_cast<hs_u32x4*>(&raw[r * RAW_P + 16 * q]) = ((gu128)(uintptr_t)(src + (size_t)r * pitch + 16 * q))->v;
+        // lane = (row r0 of 21, 16-byte piece q of 3); rows r0, r0 + 21, r0 + 42: the per-iteration address arithmetic is one add
+        const int r0 = lane / 3, q = lane - r0 * 3;
+        const uint8_t* src = base + (size_t)(y0 + r0) * pitch + x0 + 16 * q;
+        uint8_t* dst = &raw[r0 * RAW_P + 16 * q];
+        if (lane < 63) {
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (r0 + 21 * k < RAW_N)
+                    *reinterpret_cast<hs_u32x4*>(dst + 21 * k * RAW_P) = ((gu128)(uintptr_t)(src + (size_t)(21 * k) * pitch))->v;
         }
     } else {
         for (int i = lane; i < RAW_N * RAW_N; i += 64) {
@@ -200,16 +216,26 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         // ---- row pass: H[r][c..c+3] from three/four aligned dwords, two dot4 per output; stored transposed HT[c][r]
         const uint32_t t0123 = tp[0] | (tp[1] << 8) | (tp[2] << 16) | (tp[3] << 24);
         const uint32_t t456 = tp[4] | (tp[5] << 8) | (tp[6] << 16);
-        for (int i = lane; i < RAW_N * 10; i += 64) {
-            const int r = i / 10, gq = i - r * 10;
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(&raw[r * RAW_P + 4 * gq]);
-            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
-            uint16_t* out = &hb[4 * gq * HT_P + r];            // columns 37..39 of the last group are written too (storage exists, never read)
+        // lane = (row r0 of 6, column group gq of 10), rows r0 + 6k: every address below is the lane's base plus a compile-time offset
+        // (a flat index over the 430 (row, group) tasks cost a division and two multiplications per iteration)
+        {
+            const int r0 = lane / 10, gq = lane - r0 * 10;
+            const uint32_t* row0 = reinterpret_cast<const uint32_t*>(&raw[r0 * RAW_P + 4 * gq]);
+            uint16_t* out0 = &hb[4 * gq * HT_P + r0];          // columns 37..39 of the last group are written too (storage exists, never read)
+            if (lane < 60) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, j);
-                const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, j);
-                out[j * HT_P] = (uint16_t)__builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
+                for (int k = 0; k < (RAW_N + 5) / 6; k++) {
+                    if (6 * k + 5 < RAW_N || r0 + 6 * k < RAW_N) {
+                        const uint32_t* row = row0 + 6 * k * (RAW_P / 4);
+                        const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, j);
+                            const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, j);
+                            out0[6 * k + j * HT_P] = (uint16_t)__builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
+                        }
+                    }
+                }
             }
         }
         if (lane < BL_N) hb[lane * HT_P + 43] = 0;              // pad element (only ever multiplied by a zero tap)
@@ -226,15 +252,17 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
             const int r = 4 * rq;
             const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
             const uint32_t a0 = col[0], a1 = col[1], a2 = col[2], a3 = col[3], a4 = col[4];   // rows >= 43 (last group): pad / next column, only the discarded outputs see them
-            const uint32_t v0 = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0u))));
-            const uint32_t v1 = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0u))));
-            const uint32_t v2 = udot2(a4, e3, udot2(a3, e2, udot2(a2, e1, udot2(a1, e0, 0u))));
-            const uint32_t v3 = udot2(a4, o3, udot2(a3, o2, udot2(a2, o1, udot2(a1, o0, 0u))));
+            // (sum + 0x8000) >> 16 saturated to 255: the rounding constant starts the accumulator, the saturation is applied before the shift
+            // (min(x, 0xFFFFFF) >> 16 == min(x >> 16, 255)); the byte store takes bits 16..23
+            const uint32_t v0 = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0x8000u))));
+            const uint32_t v1 = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0x8000u))));
+            const uint32_t v2 = udot2(a4, e3, udot2(a3, e2, udot2(a2, e1, udot2(a1, e0, 0x8000u))));
+            const uint32_t v3 = udot2(a4, o3, udot2(a3, o2, udot2(a2, o1, udot2(a1, o0, 0x8000u))));
             uint8_t* o = &bl[r * BL_P + c];                    // rows 37..39 of the last group land in the tile's unused tail (the tile is 43 x 48 bytes)
-            o[0] = (uint8_t)min((v0 + 0x8000u) >> 16, 255u);
-            o[BL_P] = (uint8_t)min((v1 + 0x8000u) >> 16, 255u);
-            o[2 * BL_P] = (uint8_t)min((v2 + 0x8000u) >> 16, 255u);
-            o[3 * BL_P] = (uint8_t)min((v3 + 0x8000u) >> 16, 255u);
+            o[0] = (uint8_t)(min(v0, 0xFFFFFFu) >> 16);
+            o[BL_P] = (uint8_t)(min(v1, 0xFFFFFFu) >> 16);
+            o[2 * BL_P] = (uint8_t)(min(v2, 0xFFFFFFu) >> 16);
+            o[3 * BL_P] = (uint8_t)(min(v3, 0xFFFFFFu) >> 16);
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
@@ -289,14 +317,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float theta = __fmul_rn(angle, factorPI);
     double sin_t, cos_t;
-    sincos((double)theta, &sin_t, &cos_t);                      // one argument reduction; same values as sin() and cos()
+    hs_lean_sincos((double)theta, &sin_t, &cos_t);              // equal to libm's after the rounding to float for every float theta (lean_sincos.h)
     const float a = (float)cos_t, b = (float)sin_t;
     uint8_t* dout = desc + ((size_t)oimg * cap + g) * HS_DESC_BYTES;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int t = 64 * r + lane;
-        float px0 = (float)c_pattern[4 * t + 0], py0 = (float)c_pattern[4 * t + 1];
-        float px1 = (float)c_pattern[4 * t + 2], py1 = (float)c_pattern[4 * t + 3];
+        const float4 pt = *reinterpret_cast<const float4*>(&c_pattern.v[4 * t]);
+        const float px0 = pt.x, py0 = pt.y, px1 = pt.z, py1 = pt.w;
         int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
         int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
         int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
