@@ -123,6 +123,17 @@ extern "C" void hs_debug_describe_profile(unsigned int* out, int waves)      // 
 #define DP_T(var)
 #define DP_ACC(i, a, b)
 #endif
+// sum over the 64 lanes, the same value in every lane's result (DPP row shifts + row broadcasts, then lane 63)
+__device__ __forceinline__ int wave_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8   -> lane 15 of each row holds the row's sum
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)   // lgkmcnt(0)
 
 template <bool FT>
@@ -214,8 +225,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
     if (FT) {
         // ---- row pass: H[r][c..c+3] from three/four aligned dwords, two dot4 per output; stored transposed HT[c][r]
-        const uint32_t t0123 = tp[0] | (tp[1] << 8) | (tp[2] << 16) | (tp[3] << 24);
-        const uint32_t t456 = tp[4] | (tp[5] << 8) | (tp[6] << 16);
+        // four adjacent outputs from the dwords d0 (bytes 0..3), d1 (4..7), d2 (8..11) of the row: output j = sum_k t[k] * byte[j + k].  The
+        // TAPS are shifted, not the data: ten v_dot4 with constant tap words per four outputs instead of six v_alignbyte + eight v_dot4
+        auto tw = [&](int k0) -> uint32_t {      // tap word whose byte i is t[k0 + i] (0 outside 0..6)
+            uint32_t w = 0;
+            for (int i = 0; i < 4; i++) { const int k = k0 + i; if (k >= 0 && k < 7) w |= tp[k] << (8 * i); }
+            return w;
+        };
+        const uint32_t ta0 = tw(0), ta1 = tw(4), tb0 = tw(-1), tb1 = tw(3), tc0 = tw(-2), tc1 = tw(2), tc2 = tw(6), td0 = tw(-3), td1 = tw(1), td2 = tw(5);
         // lane = (row r0 of 6, column group gq of 10), rows r0 + 6k: every address below is the lane's base plus a compile-time offset
         // (a flat index over the 430 (row, group) tasks cost a division and two multiplications per iteration)
         {
@@ -228,12 +245,11 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
                     if (6 * k + 5 < RAW_N || r0 + 6 * k < RAW_N) {
                         const uint32_t* row = row0 + 6 * k * (RAW_P / 4);
                         const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, j);
-                            const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, j);
-                            out0[6 * k + j * HT_P] = (uint16_t)__builtin_amdgcn_udot4(hi, t456, __builtin_amdgcn_udot4(lo, t0123, 0u, false), false);
-                        }
+                        uint16_t* out = out0 + 6 * k;
+                        out[0] = (uint16_t)__builtin_amdgcn_udot4(d1, ta1, __builtin_amdgcn_udot4(d0, ta0, 0u, false), false);
+                        out[HT_P] = (uint16_t)__builtin_amdgcn_udot4(d1, tb1, __builtin_amdgcn_udot4(d0, tb0, 0u, false), false);
+                        out[2 * HT_P] = (uint16_t)__builtin_amdgcn_udot4(d2, tc2, __builtin_amdgcn_udot4(d1, tc1, __builtin_amdgcn_udot4(d0, tc0, 0u, false), false), false);
+                        out[3 * HT_P] = (uint16_t)__builtin_amdgcn_udot4(d2, td2, __builtin_amdgcn_udot4(d1, td1, __builtin_amdgcn_udot4(d0, td0, 0u, false), false), false);
                     }
                 }
             }
@@ -246,23 +262,25 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         //      the odd row r+1 uses (0,t0)(t1,t2)(t3,t4)(t5,t6) on the SAME dwords
         const uint32_t e0 = tp[0] | (tp[1] << 16), e1 = tp[2] | (tp[3] << 16), e2 = tp[4] | (tp[5] << 16), e3 = tp[6];
         const uint32_t o0 = tp[0] << 16, o1 = tp[1] | (tp[2] << 16), o2 = tp[3] | (tp[4] << 16), o3 = tp[5] | (tp[6] << 16);
-        // a lane makes 4 vertically adjacent outputs (rows r..r+3, r = 4*rq) from the five dwords H[r..r+9] of its column
-        for (int i = lane; i < BL_N * 10; i += 64) {
-            const int c = i / 10, rq = i - c * 10;
-            const int r = 4 * rq;
+        // a lane makes 8 vertically adjacent outputs (rows r..r+7, r = 8*rg) from the seven dwords H[r..r+13] of its column: 185 (column,
+        // group) tasks in three rounds
+        for (int i = lane; i < BL_N * 5; i += 64) {
+            const int c = i / 5, rg = i - c * 5;
+            const int r = 8 * rg;
             const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
-            const uint32_t a0 = col[0], a1 = col[1], a2 = col[2], a3 = col[3], a4 = col[4];   // rows >= 43 (last group): pad / next column, only the discarded outputs see them
+            uint32_t a[7];                                     // rows >= 43 (last group): pad / next column, only the discarded outputs see them
+#pragma unroll
+            for (int k = 0; k < 7; k++) a[k] = col[k];
+            uint8_t* o = &bl[r * BL_P + c];                    // rows 37..39 of the last group land in the tile's unused tail (the tile is 43 x 48 bytes)
             // (sum + 0x8000) >> 16 saturated to 255: the rounding constant starts the accumulator, the saturation is applied before the shift
             // (min(x, 0xFFFFFF) >> 16 == min(x >> 16, 255)); the byte store takes bits 16..23
-            const uint32_t v0 = udot2(a3, e3, udot2(a2, e2, udot2(a1, e1, udot2(a0, e0, 0x8000u))));
-            const uint32_t v1 = udot2(a3, o3, udot2(a2, o2, udot2(a1, o1, udot2(a0, o0, 0x8000u))));
-            const uint32_t v2 = udot2(a4, e3, udot2(a3, e2, udot2(a2, e1, udot2(a1, e0, 0x8000u))));
-            const uint32_t v3 = udot2(a4, o3, udot2(a3, o2, udot2(a2, o1, udot2(a1, o0, 0x8000u))));
-            uint8_t* o = &bl[r * BL_P + c];                    // rows 37..39 of the last group land in the tile's unused tail (the tile is 43 x 48 bytes)
-            o[0] = (uint8_t)(min(v0, 0xFFFFFFu) >> 16);
-            o[BL_P] = (uint8_t)(min(v1, 0xFFFFFFu) >> 16);
-            o[2 * BL_P] = (uint8_t)(min(v2, 0xFFFFFFu) >> 16);
-            o[3 * BL_P] = (uint8_t)(min(v3, 0xFFFFFFu) >> 16);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t ve = udot2(a[m + 3], e3, udot2(a[m + 2], e2, udot2(a[m + 1], e1, udot2(a[m], e0, 0x8000u))));
+                const uint32_t vo = udot2(a[m + 3], o3, udot2(a[m + 2], o2, udot2(a[m + 1], o1, udot2(a[m], o0, 0x8000u))));
+                o[(2 * m) * BL_P] = (uint8_t)(min(ve, 0xFFFFFFu) >> 16);
+                o[(2 * m + 1) * BL_P] = (uint8_t)(min(vo, 0xFFFFFFu) >> 16);
+            }
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
@@ -299,16 +317,24 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     int m10 = 0, m01 = 0;
     {
         const uint32_t* bl32 = reinterpret_cast<const uint32_t*>(bl);
-        for (int i = lane; i < 31 * 10; i += 64) {
-            const int r = i / 10, q = i - r * 10;
-            const uint32_t W = bl32[(3 + r) * (BL_P / 4) + q];
-            const uint2 wt = c_momw.w[i];
-            const int s1 = (int)__builtin_amdgcn_udot4(W, wt.y, 0u, false), su = (int)__builtin_amdgcn_udot4(W, wt.x, 0u, false);
-            m10 += su - 15 * s1; m01 += (r - 15) * s1;
+        // lane = (row r0 of 6, dword q of 10), rows r0 + 6k: the table index is lane + 60k
+        const int r0 = lane / 10, q = lane - r0 * 10;
+        if (lane < 60) {
+            const uint32_t* w0 = bl32 + (3 + r0) * (BL_P / 4) + q;
+            int sv = 0;                                        // sum over k of (r0 + 6k - 15) * s1
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (6 * k + 5 < 31 || r0 + 6 * k < 31) {
+                    const uint32_t W = w0[6 * k * (BL_P / 4)];
+                    const uint2 wt = c_momw.w[lane + 60 * k];
+                    const int s1 = (int)__builtin_amdgcn_udot4(W, wt.y, 0u, false), su = (int)__builtin_amdgcn_udot4(W, wt.x, 0u, false);
+                    m10 += su - 15 * s1; sv += (6 * k - 15) * s1; m01 += s1;       // m01 holds sum s1 until the line below
+                }
+            }
+            m01 = r0 * m01 + sv;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    m10 = wave_sum(m10); m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     DP_T(dp5);
     DP_ACC(4, dp4, dp5);
@@ -325,12 +351,16 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         int t = 64 * r + lane;
         const float4 pt = *reinterpret_cast<const float4*>(&c_pattern.v[4 * t]);
         const float px0 = pt.x, py0 = pt.y, px1 = pt.z, py1 = pt.w;
-        int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
-        int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
-        int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
-        int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
-        int t0 = bl[(18 + dy0) * BL_P + 18 + dx0];
-        int t1 = bl[(18 + dy1) * BL_P + 18 + dx1];
+        // cvRound = round half to even: x + 1.5 * 2^23 has the rounded integer in its low mantissa bits (|x| < 27); the tile offset
+        // (18 + dy) * BL_P + 18 + dx comes out of one 24-bit multiply-add on those bits
+        const float M = 12582912.0f;
+        const uint32_t K = 0x400000u * BL_P + 0x4B400000u - (18 * BL_P + 18);      // the biases of the two encodings minus the tile centre
+        const uint32_t fy0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)), M));
+        const uint32_t fx0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)), M));
+        const uint32_t fy1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)), M));
+        const uint32_t fx1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)), M));
+        int t0 = bl[__umul24(fy0, BL_P) + fx0 - K];         // the multiply takes fy's low 24 bits (0x400000 + dy), fx enters whole
+        int t1 = bl[__umul24(fy1, BL_P) + fx1 - K];
         unsigned long long m = __ballot(t0 < t1);
         if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = m;
     }
