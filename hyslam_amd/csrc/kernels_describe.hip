@@ -67,7 +67,7 @@ __constant__ MomW c_momw = make_momw();
 #define H_P 38                   // generic path: row-major u16 row sums
 #define HT_P 46                  // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
 #define H_ELEMS (40 * HT_P)       // fast path: 40 columns are written (37 used); 1840 >= RAW_N * H_P = 1634
-#define BL_P 40
+#define BL_P 44                  // blurred tile pitch: 11 dwords, so that the column pass (lanes 8 rows apart) spreads its byte stores over the banks
 #define KP_PER_BLOCK 4
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -85,16 +85,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
     float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, (float)2.2204460492503131e-16));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, (float)2.2204460492503131e-16));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // both branches of the reference divide the smaller magnitude by (the larger + eps) and run the same polynomial: one division, one
+    // polynomial, and the branch only decides between p and 90 - p
+    const bool xmajor = ax >= ay;
+    const float c = __fdiv_rn(xmajor ? ay : ax, __fadd_rn(xmajor ? ax : ay, (float)2.2204460492503131e-16));
+    const float c2 = __fmul_rn(c, c);
+    const float p = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    float a = xmajor ? p : __fsub_rn(90.f, p);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
@@ -350,15 +347,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     for (int r = 0; r < 4; r++) {
         int t = 64 * r + lane;
         const float4 pt = *reinterpret_cast<const float4*>(&c_pattern.v[4 * t]);
-        const float px0 = pt.x, py0 = pt.y, px1 = pt.z, py1 = pt.w;
+        typedef float hs_f2 __attribute__((ext_vector_type(2)));   // both points of the test at once: v_pk_mul_f32 / v_pk_add_f32 (IEEE per component)
+        const hs_f2 pxv = {pt.x, pt.z}, pyv = {pt.y, pt.w};
         // cvRound = round half to even: x + 1.5 * 2^23 has the rounded integer in its low mantissa bits (|x| < 27); the tile offset
         // (18 + dy) * BL_P + 18 + dx comes out of one 24-bit multiply-add on those bits
         const float M = 12582912.0f;
         const uint32_t K = 0x400000u * BL_P + 0x4B400000u - (18 * BL_P + 18);      // the biases of the two encodings minus the tile centre
-        const uint32_t fy0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)), M));
-        const uint32_t fx0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)), M));
-        const uint32_t fy1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)), M));
-        const uint32_t fx1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)), M));
+        const hs_f2 fyv = (pxv * b + pyv * a) + M, fxv = (pxv * a - pyv * b) + M;      // -ffp-contract=off: separately rounded products and sums
+        const uint32_t fy0 = __float_as_uint(fyv.x), fy1 = __float_as_uint(fyv.y), fx0 = __float_as_uint(fxv.x), fx1 = __float_as_uint(fxv.y);
         int t0 = bl[__umul24(fy0, BL_P) + fx0 - K];         // the multiply takes fy's low 24 bits (0x400000 + dy), fx enters whole
         int t1 = bl[__umul24(fy1, BL_P) + fx1 - K];
         unsigned long long m = __ballot(t0 < t1);
