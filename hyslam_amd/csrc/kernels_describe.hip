@@ -67,7 +67,7 @@ __constant__ MomW c_momw = make_momw();
 #define H_P 38                   // generic path: row-major u16 row sums
 #define HT_P 46                  // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
 #define H_ELEMS (40 * HT_P)       // fast path: 40 columns are written (37 used); 1840 >= RAW_N * H_P = 1634
-#define BL_P 44                  // blurred tile pitch: 11 dwords, so that the column pass (lanes 8 rows apart) spreads its byte stores over the banks
+#define BL_P 40                  // blurred tile: COLUMN-major, 40 bytes per column (8-byte aligned columns for the 8-byte stores of the column pass)
 #define KP_PER_BLOCK 4
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -233,25 +233,34 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         // lane = (row r0 of 6, column group gq of 10), rows r0 + 6k: every address below is the lane's base plus a compile-time offset
         // (a flat index over the 430 (row, group) tasks cost a division and two multiplications per iteration)
         {
-            const int r0 = lane / 10, gq = lane - r0 * 10;
-            const uint32_t* row0 = reinterpret_cast<const uint32_t*>(&raw[r0 * RAW_P + 4 * gq]);
-            uint16_t* out0 = &hb[4 * gq * HT_P + r0];          // columns 37..39 of the last group are written too (storage exists, never read)
+            // lane = (row PAIR p0 of 6, column group gq of 10), pairs p0 + 6k: the two rows' sums of a column are neighbours in the
+            // transposed store, so they leave as one dword — an LDS store costs 4 cycles whatever its width (address + data transfer), and
+            // stores, not reads, fill this kernel's LDS time.  Pair 21 = (row 42, a row that does not exist): its second half lands in the
+            // pad element H[c][43], which only ever meets a zero tap.
+            const int p0 = lane / 10, gq = lane - p0 * 10;
+            const uint32_t* row0 = reinterpret_cast<const uint32_t*>(&raw[2 * p0 * RAW_P + 4 * gq]);
+            uint32_t* out0 = reinterpret_cast<uint32_t*>(&hb[4 * gq * HT_P + 2 * p0]);          // columns 37..39 of the last group are written too (storage exists, never read)
+            auto hrow = [&](const uint32_t* row, uint32_t (&h)[4]) {
+                const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // bytes beyond the row only meet zero taps
+                h[0] = __builtin_amdgcn_udot4(d1, ta1, __builtin_amdgcn_udot4(d0, ta0, 0u, false), false);
+                h[1] = __builtin_amdgcn_udot4(d1, tb1, __builtin_amdgcn_udot4(d0, tb0, 0u, false), false);
+                h[2] = __builtin_amdgcn_udot4(d2, tc2, __builtin_amdgcn_udot4(d1, tc1, __builtin_amdgcn_udot4(d0, tc0, 0u, false), false), false);
+                h[3] = __builtin_amdgcn_udot4(d2, td2, __builtin_amdgcn_udot4(d1, td1, __builtin_amdgcn_udot4(d0, td0, 0u, false), false), false);
+            };
             if (lane < 60) {
+                constexpr int NP = (RAW_N + 1) / 2;            // 22 row pairs
 #pragma unroll
-                for (int k = 0; k < (RAW_N + 5) / 6; k++) {
-                    if (6 * k + 5 < RAW_N || r0 + 6 * k < RAW_N) {
-                        const uint32_t* row = row0 + 6 * k * (RAW_P / 4);
-                        const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];   // window of output j = bytes j..j+6; bytes beyond the row only meet the zero tap
-                        uint16_t* out = out0 + 6 * k;
-                        out[0] = (uint16_t)__builtin_amdgcn_udot4(d1, ta1, __builtin_amdgcn_udot4(d0, ta0, 0u, false), false);
-                        out[HT_P] = (uint16_t)__builtin_amdgcn_udot4(d1, tb1, __builtin_amdgcn_udot4(d0, tb0, 0u, false), false);
-                        out[2 * HT_P] = (uint16_t)__builtin_amdgcn_udot4(d2, tc2, __builtin_amdgcn_udot4(d1, tc1, __builtin_amdgcn_udot4(d0, tc0, 0u, false), false), false);
-                        out[3 * HT_P] = (uint16_t)__builtin_amdgcn_udot4(d2, td2, __builtin_amdgcn_udot4(d1, td1, __builtin_amdgcn_udot4(d0, td0, 0u, false), false), false);
+                for (int k = 0; k < (NP + 5) / 6; k++) {
+                    if (6 * k + 5 < NP || p0 + 6 * k < NP) {
+                        uint32_t ha[4], hb2[4];
+                        hrow(row0 + 12 * k * (RAW_P / 4), ha);
+                        hrow(row0 + (12 * k + 1) * (RAW_P / 4), hb2);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) out0[6 * k + j * (HT_P / 2)] = ha[j] | (hb2[j] << 16);      // sums are < 65536
                     }
                 }
             }
         }
-        if (lane < BL_N) hb[lane * HT_P + 43] = 0;              // pad element (only ever multiplied by a zero tap)
         WAVE_LDS_SYNC();
         DP_T(dp3);
         DP_ACC(2, dp2, dp3);
@@ -268,16 +277,19 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
             uint32_t a[7];                                     // rows >= 43 (last group): pad / next column, only the discarded outputs see them
 #pragma unroll
             for (int k = 0; k < 7; k++) a[k] = col[k];
-            uint8_t* o = &bl[r * BL_P + c];                    // rows 37..39 of the last group land in the tile's unused tail (the tile is 43 x 48 bytes)
             // (sum + 0x8000) >> 16 saturated to 255: the rounding constant starts the accumulator, the saturation is applied before the shift
-            // (min(x, 0xFFFFFF) >> 16 == min(x >> 16, 255)); the byte store takes bits 16..23
+            // (min(x, 0xFFFFFF) >> 16 == min(x >> 16, 255)): the result is byte 2 of w.  The blurred tile is COLUMN-major (BL(row, col) =
+            // bl[col * BL_P + row]), so the lane's eight results are eight consecutive bytes: one 8-byte store instead of eight byte stores
+            uint32_t w[8];
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t ve = udot2(a[m + 3], e3, udot2(a[m + 2], e2, udot2(a[m + 1], e1, udot2(a[m], e0, 0x8000u))));
-                const uint32_t vo = udot2(a[m + 3], o3, udot2(a[m + 2], o2, udot2(a[m + 1], o1, udot2(a[m], o0, 0x8000u))));
-                o[(2 * m) * BL_P] = (uint8_t)(min(ve, 0xFFFFFFu) >> 16);
-                o[(2 * m + 1) * BL_P] = (uint8_t)(min(vo, 0xFFFFFFu) >> 16);
+                w[2 * m] = min(udot2(a[m + 3], e3, udot2(a[m + 2], e2, udot2(a[m + 1], e1, udot2(a[m], e0, 0x8000u)))), 0xFFFFFFu);
+                w[2 * m + 1] = min(udot2(a[m + 3], o3, udot2(a[m + 2], o2, udot2(a[m + 1], o1, udot2(a[m], o0, 0x8000u)))), 0xFFFFFFu);
             }
+            // v_perm_b32: byte 2 of each of four values -> one dword (selector bytes: 0-3 = second operand, 4-7 = first, 0x0c = zero)
+            const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0602u) | __builtin_amdgcn_perm(w[3], w[2], 0x06020c0cu);
+            const uint32_t hi = __builtin_amdgcn_perm(w[5], w[4], 0x0c0c0602u) | __builtin_amdgcn_perm(w[7], w[6], 0x06020c0cu);
+            *reinterpret_cast<uint2*>(&bl[c * BL_P + r]) = make_uint2(lo, hi);      // rows 37..39 of the last group: the column's unused tail
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
                 acc = acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc;
             }
             unsigned long long v = (acc + 0x8000ull) >> 16;
-            bl[r * BL_P + c] = (uint8_t)(v > 255 ? 255 : v);
+            bl[c * BL_P + r] = (uint8_t)(v > 255 ? 255 : v);
         }
     }
     WAVE_LDS_SYNC();
@@ -325,10 +337,12 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
                     const uint32_t W = w0[6 * k * (BL_P / 4)];
                     const uint2 wt = c_momw.w[lane + 60 * k];
                     const int s1 = (int)__builtin_amdgcn_udot4(W, wt.y, 0u, false), su = (int)__builtin_amdgcn_udot4(W, wt.x, 0u, false);
-                    m10 += su - 15 * s1; sv += (6 * k - 15) * s1; m01 += s1;       // m01 holds sum s1 until the line below
+                    // column-major tile: the lane's dword holds four ROWS of column r0 + 6k, so the weighted sum is the v moment and the
+                    // column index weights the u moment (the disc is symmetric: the same table serves both orientations)
+                    m01 += su - 15 * s1; sv += (6 * k - 15) * s1; m10 += s1;       // m10 holds sum s1 until the line below
                 }
             }
-            m01 = r0 * m01 + sv;
+            m10 = r0 * m10 + sv;
         }
     }
     m10 = wave_sum(m10); m01 = wave_sum(m01);
@@ -350,13 +364,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         typedef float hs_f2 __attribute__((ext_vector_type(2)));   // both points of the test at once: v_pk_mul_f32 / v_pk_add_f32 (IEEE per component)
         const hs_f2 pxv = {pt.x, pt.z}, pyv = {pt.y, pt.w};
         // cvRound = round half to even: x + 1.5 * 2^23 has the rounded integer in its low mantissa bits (|x| < 27); the tile offset
-        // (18 + dy) * BL_P + 18 + dx comes out of one 24-bit multiply-add on those bits
+        // (18 + dx) * BL_P + 18 + dy (column-major tile) comes out of one 24-bit multiply-add on those bits
         const float M = 12582912.0f;
         const uint32_t K = 0x400000u * BL_P + 0x4B400000u - (18 * BL_P + 18);      // the biases of the two encodings minus the tile centre
         const hs_f2 fyv = (pxv * b + pyv * a) + M, fxv = (pxv * a - pyv * b) + M;      // -ffp-contract=off: separately rounded products and sums
         const uint32_t fy0 = __float_as_uint(fyv.x), fy1 = __float_as_uint(fyv.y), fx0 = __float_as_uint(fxv.x), fx1 = __float_as_uint(fxv.y);
-        int t0 = bl[__umul24(fy0, BL_P) + fx0 - K];         // the multiply takes fy's low 24 bits (0x400000 + dy), fx enters whole
-        int t1 = bl[__umul24(fy1, BL_P) + fx1 - K];
+        int t0 = bl[__umul24(fx0, BL_P) + fy0 - K];         // column-major tile; the multiply takes fx's low 24 bits (0x400000 + dx), fy enters whole
+        int t1 = bl[__umul24(fx1, BL_P) + fy1 - K];
         unsigned long long m = __ballot(t0 < t1);
         if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = m;
     }
