@@ -73,21 +73,37 @@ __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict_
         const size_t sb = (size_t)pair * n_strips + (rowL >> STRIP_SHIFT);
         const int nc = strip_count[sb];
         const uint16_t* cl = strip_list + sb * cap;
-        for (int c = lane; c < nc; c += 64) {
-            const int iR = cl[c];
-            const hs_keypoint kr = kpsR[o + iR];
-            const float r = 2.0f * kr.size / sp.size_ref;    // :56
-            const int maxr = (int)ceilf(kr.y + r);
-            const int minr = (int)floorf(kr.y - r);
-            if (rowL < minr || rowL > maxr) continue;
-            if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
-            const float uR = kr.x;
-            if (!(uR >= minU && uR <= maxU)) continue;
-            const unsigned long long* dr = reinterpret_cast<const unsigned long long*>(descR + (o + iR) * 32);
-            int d = __popcll(l0 ^ dr[0]) + __popcll(l1 ^ dr[1]) + __popcll(l2 ^ dr[2]) + __popcll(l3 ^ dr[3]);
-            if ((float)d < th_high) {
-                uint32_t key = ((uint32_t)d << 16) | (uint32_t)iR;
-                best = min(best, key);
+        // two candidates per lane and round (a strip holds ~100): index -> record -> descriptor is a chain of three dependent loads, and
+        // a plain loop walked it once per 64 candidates; here the chains of both candidates advance together.  Lanes without a candidate
+        // re-read the strip's first entry (a valid index) and are masked at the end.
+        for (int c0 = 0; c0 < nc; c0 += 128) {
+            int iR[2]; hs_keypoint kr[2]; bool in[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) { const int c = c0 + 64 * j + lane; in[j] = c < nc; iR[j] = cl[in[j] ? c : 0]; }
+#pragma unroll
+            for (int j = 0; j < 2; j++) kr[j] = kpsR[o + iR[j]];
+            bool pass[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float r = 2.0f * kr[j].size / sp.size_ref;    // :56
+                const int maxr = (int)ceilf(kr[j].y + r);
+                const int minr = (int)floorf(kr[j].y - r);
+                pass[j] = in[j] && !(rowL < minr || rowL > maxr);
+                pass[j] = pass[j] && !(kr[j].octave < levelL - 1 || kr[j].octave > levelL + 1);
+                const float uR = kr[j].x;
+                pass[j] = pass[j] && (uR >= minU && uR <= maxU);
+            }
+            unsigned long long dr[2][4];                     // descriptors only of the candidates that passed (a fifth of them)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const unsigned long long* p = reinterpret_cast<const unsigned long long*>(descR + (o + iR[j]) * 32);
+                if (pass[j]) { dr[j][0] = p[0]; dr[j][1] = p[1]; dr[j][2] = p[2]; dr[j][3] = p[3]; }
+                else { dr[j][0] = dr[j][1] = dr[j][2] = dr[j][3] = 0ull; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int d = __popcll(l0 ^ dr[j][0]) + __popcll(l1 ^ dr[j][1]) + __popcll(l2 ^ dr[j][2]) + __popcll(l3 ^ dr[j][3]);
+                if (pass[j] && (float)d < th_high) best = min(best, ((uint32_t)d << 16) | (uint32_t)iR[j]);
             }
         }
     }
@@ -129,27 +145,44 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
     const size_t o = (size_t)pair * cap;
     for (int i = threadIdx.x; i < 257; i += 256) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nL; i += 256) {
+    // the distances stay in registers between the histogram and the rejection sweep (8 per thread cover cap <= 2048; more loop again below)
+    constexpr int DPT = 8;
+    int dreg[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; k++) { const int i = threadIdx.x + 256 * k; dreg[k] = i < nL ? best_dist[o + i] : -1; }
+#pragma unroll
+    for (int k = 0; k < DPT; k++) if (dreg[k] >= 0) atomicAdd(&hist[min(dreg[k], 256)], 1);
+    for (int i = threadIdx.x + 256 * DPT; i < nL; i += 256) {
         int d = best_dist[o + i];
         if (d >= 0) atomicAdd(&hist[min(d, 256)], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int d = 0; d <= 256; d++) total += hist[d];
-        float th = -1.f;
-        if (total > 0) {
-            // sorted (dist, iL) pairs: element total/2 carries the median distance (:142-144)
-            int target = total / 2, acc = 0, med = 0;
-            for (int d = 0; d <= 256; d++) { acc += hist[d]; if (acc > target) { med = d; break; } }
-            th = 1.5f * 1.4f * (float)med;
-        }
-        s_th = th;
+    if (threadIdx.x < 64) {
+        // sorted (dist, iL) pairs: element total/2 carries the median distance (:142-144) = the first bin at which the running count exceeds
+        // total/2.  One wavefront: four bins per lane (+ bin 256), inclusive scan over the lanes, the crossing lane finishes inside its bins.
+        const int lane = threadIdx.x;
+        const int b0 = hist[4 * lane], b1 = hist[4 * lane + 1], b2 = hist[4 * lane + 2], b3 = hist[4 * lane + 3];
+        int incl = b0 + b1 + b2 + b3;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { const int v = __shfl_up(incl, s, 64); if (lane >= s) incl += v; }
+        const int total = __shfl(incl, 63, 64) + hist[256];
+        const int target = total / 2, excl = incl - (b0 + b1 + b2 + b3);
+        int med = -1;
+        if (excl <= target && incl > target) med = 4 * lane + (excl + b0 > target ? 0 : excl + b0 + b1 > target ? 1 : excl + b0 + b1 + b2 > target ? 2 : 3);
+        const unsigned long long hit = __ballot(med >= 0);
+        if (total == 0) { if (lane == 0) s_th = -1.f; }
+        else if (hit == 0) { if (lane == 0) s_th = 1.5f * 1.4f * 256.f; }            // the crossing is in bin 256
+        else if (med >= 0) s_th = 1.5f * 1.4f * (float)med;                          // exactly one lane
     }
     __syncthreads();
     const float th = s_th;
     if (th < 0.f) return;
-    for (int i = threadIdx.x; i < nL; i += 256) {
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+        const int i = threadIdx.x + 256 * k, d = dreg[k];
+        if (d >= 0 && !((float)d < th)) { uRight[o + i] = -1.f; depth[o + i] = -1.f; }      // :146-155
+    }
+    for (int i = threadIdx.x + 256 * DPT; i < nL; i += 256) {
         int d = best_dist[o + i];
         if (d >= 0 && !((float)d < th)) { uRight[o + i] = -1.f; depth[o + i] = -1.f; }      // :146-155
     }
