@@ -145,6 +145,7 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
     profiles/<tag>_sq_counters.json: --pmc SQ_INSTS_VALU ...).  Counters cannot be read from inside this process, so values are only
     reported when the profiled launch shape matches; otherwise null."""
     traffic = valu = None
+    sq = {}
     src = []
     try:       # a stage can be several kernels (the pyramid): per-launch averages x launches per launch sequence, summed
         t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")))
@@ -161,10 +162,13 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
             m = [e for k, e in t["kernels"].items() if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch]
             if m:
                 valu = float(sum(e["SQ_INSTS_VALU"] * e.get("launches_per_sequence", 1) for e in m))
+                for c in ("SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"):
+                    if all(c in e for e in m):
+                        sq[c] = float(sum(e[c] * e.get("launches_per_sequence", 1) for e in m))
                 src.append("profiles/%s_sq_counters.json" % PROFILE_TAG)
     except Exception:
         pass
-    return traffic, valu, src
+    return traffic, valu, src, sq
 
 
 def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches, pairs_per_step, moved_bytes=None):
@@ -174,7 +178,7 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
     ms = stage_ms[stage]
     algo = per_stage_bytes[stage] * frames_per_launch
     achieved = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, valu, src = committed_counters(stage, pairs_per_step, frames_per_launch)
+    traffic, valu, src, sq = committed_counters(stage, pairs_per_step, frames_per_launch)
     rl = {"bound": "hbm", "kernel": stage, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if traffic is None else int(traffic / launches), "counter_source": src or None,
           "algorithmic_bytes_per_launch": int(algo / launches), "launch_ms": round(ms / launches, 5), "launches_per_step_and_handle": launches,
@@ -183,9 +187,16 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
         rl["moved_bytes_per_launch"] = int(moved_bytes * frames_per_launch)
         rl["achieved_on_moved_bytes"] = round(moved_bytes * frames_per_launch / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0
     if valu is not None and ms > 0:
-        per_cu_cycle = valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9)
         rl["valu_insts_per_launch"] = int(valu / launches)
-        rl["valu_issue_frac"] = round(per_cu_cycle, 4)       # of 1 VALU wave-instruction per cycle and CU
+        busy = sq.get("SQ_BUSY_CU_CYCLES")
+        if busy:      # counters of the same profiled launch: VALU wave-instructions per busy CU cycle (1 = a VALU instruction issued every cycle on
+            # every busy CU; the measured ceiling of this instruction mix is 0.8-0.9, profiles/*_valu_issue_rates.txt), no clock assumption
+            rl["valu_issue_frac"] = round(valu / busy, 4)
+            if "SQ_LDS_IDX_ACTIVE" in sq:
+                rl["lds_active_frac"] = round(sq["SQ_LDS_IDX_ACTIVE"] / busy, 4)
+                rl["lds_conflict_frac"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / busy, 4)
+        else:         # older counter files: against the nominal clock (the clock under load is lower: this understates the fraction)
+            rl["valu_issue_frac"] = round(valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
     return rl
 
 

@@ -63,7 +63,7 @@ for r in csv.DictReader(open(first("sq/**/*counter_collection.csv"))):
 names = sorted({c for d in agg.values() for c in d})
 sq = {}
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
-    o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
+    o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
     o.write("# per-launch averages; bench.py default (one handle, 16 pairs): 32 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
     o.write("kernel,launches," + ",".join(names) + "\n")
     for k, d in agg.items():
