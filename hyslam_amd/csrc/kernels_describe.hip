@@ -17,11 +17,14 @@
 //            separately rounded fp32 products; bit i of byte j = test 8j+i -> one ballot per 64 tests.
 //
 // Fast path (FT = true: every tap <= 255 and 255*sum(taps) <= 65535, i.e. the row sums cannot saturate — true for the
-// default taps): the patch is fetched as (unaligned) dwords straight into an LDS tile aligned to the patch,
-// the row pass is two v_dot4_u32_u8 per output on v_alignbyte'd windows, the row sums are stored TRANSPOSED as u16
-// so that the column pass is four v_dot2_u32_u16 per output (two vertically adjacent outputs share their loads; odd
-// rows use a tap packing shifted by one element instead of shifting data).  Integer sums are exact, so this is
-// bit-identical to the generic path, which stays for exotic taps and for keypoints whose patch crosses the border.
+// default taps): the patch is fetched with unaligned 16-byte loads straight into an LDS tile aligned to the patch; the row pass makes four
+// adjacent outputs from three dwords with TEN v_dot4_u32_u8 against shifted tap words (the taps are shifted, not the data) and stores the
+// sums of a row PAIR transposed, one dword per column; the column pass makes 8 vertically adjacent outputs from 7 dwords with four
+// v_dot2_u32_u16 each (odd rows use a tap packing shifted by one element) and writes them with one 8-byte store into a COLUMN-major
+// blurred tile.  Integer sums are exact, so this is bit-identical to the generic path, which stays for exotic taps; keypoints whose patch
+// crosses the level border fetch their bytes one by one with BORDER_REFLECT_101.
+// The kernel is bound by VALU issue (0.80 instructions per busy CU cycle) with the LDS pipe second (46 % busy): what is here is what
+// survived counting instructions per keypoint (915 -> 566) and LDS instructions (118 -> 50); DESIGN.md §4 lists what was tried.
 #include "hs_internal.h"
 #define HS_HD __host__ __device__
 #include "lean_sincos.h"

@@ -11,7 +11,7 @@ from hyslam_amd.synth import synth_stereo_pair
 
 L, R = synth_stereo_pair(1, 1920, 1080)
 ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000, fScaleFactor=1.2, nLevels=8))
-imgs = [L, R] * 8
+imgs = [L, R] * (int(sys.argv[1]) if len(sys.argv) > 1 else 8)
 ex.extract_batch(imgs)
 lib = ex._lib
 out = (C.c_ulonglong * 16)()
