@@ -268,13 +268,13 @@ int ensure_outputs(hs_orb* h, int batch, int cap)
 int ensure_stereo_strips(hs_orb* h, int pairs, int cap, int n_rows)
 {
     // two capacities: the counters (pairs * strips) and the lists (pairs * strips * cap) grow independently
+    if (n_rows > 65536) return fail(h, HS_ERR_INVALID, "stereo: more than 65536 image rows");      // k_stereo_strips keeps one counter per 32 rows in LDS
     const size_t need_count = (size_t)pairs * hs_stereo_strips(n_rows), need_list = need_count * (size_t)cap;
     if (need_count <= h->strip_count_entries && need_list <= h->strip_list_entries) return HS_OK;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (need_count > h->strip_count_entries) {
         hipFree(h->d_strip_count); h->d_strip_count = nullptr; h->strip_count_entries = 0;
         HIP_TRY(h, hipMalloc(&h->d_strip_count, need_count * 4));
-        HIP_TRY(h, hipMemset(h->d_strip_count, 0, need_count * 4));      // every call leaves the counters it used zero again
         h->strip_count_entries = need_count;
     }
     if (need_list > h->strip_list_entries) {

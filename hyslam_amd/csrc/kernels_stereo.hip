@@ -20,22 +20,44 @@
 // 2000 (the reference's per-row table, Stereomatcher.cpp:46-63, at 1/32 of its size).  The exact band test is repeated per candidate.
 #define STRIP_SHIFT 5
 
-__global__ __launch_bounds__(256) void k_stereo_strips(const hs_keypoint* __restrict__ kpsR, const int32_t* __restrict__ nRs, int cap,
-                                                       float size_ref, int n_rows, int n_strips,
-                                                       int32_t* __restrict__ strip_count, uint16_t* __restrict__ strip_list)
+// One workgroup per pair: the strip counters live in LDS (a slot is an LDS atomic away, not a round trip to L2), every right keypoint's
+// record is loaded up front, and the counters are written out whole, so nothing has to be zeroed between calls.
+#define STRIPS_T 1024
+#define STRIPS_MAX 2048            // 65536 rows / 32
+__global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* __restrict__ kpsR, const int32_t* __restrict__ nRs, int cap,
+                                                            float size_ref, int n_rows, int n_strips,
+                                                            int32_t* __restrict__ strip_count, uint16_t* __restrict__ strip_list)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
-    if (i >= min(nRs[pair], cap)) return;
-    const hs_keypoint kr = kpsR[(size_t)pair * cap + i];
-    const float r = 2.0f * kr.size / size_ref;               // :56
-    int maxr = (int)ceilf(kr.y + r), minr = (int)floorf(kr.y - r);
-    if (maxr < 0 || minr >= n_rows) return;                   // rows outside [0, nRows) do not exist (D2)
-    minr = max(minr, 0); maxr = min(maxr, n_rows - 1);
-    for (int s = minr >> STRIP_SHIFT; s <= (maxr >> STRIP_SHIFT); s++) {
-        const size_t b = (size_t)pair * n_strips + s;
-        const int slot = atomicAdd(&strip_count[b], 1);
-        strip_list[b * cap + slot] = (uint16_t)i;
+    __shared__ int s_cnt[STRIPS_MAX];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nR = min(nRs[pair], cap);
+    for (int s = tid; s < n_strips; s += STRIPS_T) s_cnt[s] = 0;
+    constexpr int KPT = 4;                                    // keypoints per thread whose records are in flight together
+    __syncthreads();
+    for (int i0 = 0; i0 < nR; i0 += STRIPS_T * KPT) {
+        float ky[KPT], ks[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; k++) {
+            const int i = min(i0 + tid + STRIPS_T * k, nR - 1);
+            const hs_keypoint* kr = &kpsR[(size_t)pair * cap + i];
+            ky[k] = kr->y; ks[k] = kr->size;
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; k++) {
+            const int i = i0 + tid + STRIPS_T * k;
+            if (i >= nR) continue;
+            const float r = 2.0f * ks[k] / size_ref;         // :56
+            int maxr = (int)ceilf(ky[k] + r), minr = (int)floorf(ky[k] - r);
+            if (maxr < 0 || minr >= n_rows) continue;         // rows outside [0, nRows) do not exist (D2)
+            minr = max(minr, 0); maxr = min(maxr, n_rows - 1);
+            for (int s = minr >> STRIP_SHIFT; s <= (maxr >> STRIP_SHIFT); s++) {
+                const int slot = atomicAdd(&s_cnt[s], 1);
+                strip_list[((size_t)pair * n_strips + s) * cap + slot] = (uint16_t)i;
+            }
+        }
     }
+    __syncthreads();
+    for (int s = tid; s < n_strips; s += STRIPS_T) strip_count[(size_t)pair * n_strips + s] = s_cnt[s];
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict__ strip_count, const uint16_t* __restrict__ strip_list, int n_strips,
@@ -136,8 +158,6 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
                                                        const int32_t* __restrict__ best_dist,
                                                        int32_t* __restrict__ strip_count, int n_strips)
 {
-    // the pair's strip counters are dead now: leave them zero for the next call (saves a memset launch per call)
-    for (int i = threadIdx.x; i < n_strips; i += 256) strip_count[(size_t)blockIdx.x * n_strips + i] = 0;
     __shared__ int hist[257];
     __shared__ float s_th;
     const int pair = blockIdx.x;
@@ -195,7 +215,7 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
 {
     if (pairs <= 0 || cap <= 0) return;
     const int n_strips = hs_stereo_strips(sp.n_rows);
-    hipLaunchKernelGGL(k_stereo_strips, dim3((cap + 255) / 256, pairs), dim3(256), 0, s, kpsR, nR, cap, sp.size_ref, sp.n_rows, n_strips, strip_count, strip_list);
+    hipLaunchKernelGGL(k_stereo_strips, dim3(pairs), dim3(STRIPS_T), 0, s, kpsR, nR, cap, sp.size_ref, sp.n_rows, n_strips, strip_count, strip_list);
     dim3 grid((cap + 3) / 4, pairs, 1);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, s, strip_count, strip_list, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
 }
