@@ -17,7 +17,11 @@
  *     SURVEY.md Appendix A.
  * What pins it instead: the source-derived known-answer tables T1–T5 of SURVEY.md §8d
  * (tests/test_oracle_kat.py), an independent numpy restatement of every primitive
- * (tests/pyref.py) and committed golden vectors produced by this oracle (tests/golden/).
+ * (tests/pyref.py), committed golden vectors produced by this oracle (tests/golden/), and
+ * scikit-image — an implementation that shares nothing with this file or with OpenCV — for the
+ * FAST corner set, score and non-max suppression (exact), the orientation (within fastAtan2's
+ * error), the disc table and the rBRIEF pattern (exact); PyTorch for the geometry of resize and
+ * blur (tests/test_skimage_crosscheck.py).
  *
  * Documented deviations from the (non-deterministic / UB) reference behaviour:
  *   D1  DistributeOctTree sorts pair<int,ExtractorNode*> (src/features/ORBExtractor.cpp:321-324),
