@@ -20,7 +20,8 @@
  * (tests/pyref.py), committed golden vectors produced by this oracle (tests/golden/), and
  * scikit-image — an implementation that shares nothing with this file or with OpenCV — for the
  * FAST corner set, score and non-max suppression (exact), the orientation (within fastAtan2's
- * error), the disc table and the rBRIEF pattern (exact); PyTorch for the geometry of resize and
+ * error), the disc table and the rBRIEF pattern (exact), the steered-BRIEF bits (identical on
+ * the test frame; double vs float rotation tolerated); PyTorch for the geometry of resize and
  * blur (tests/test_skimage_crosscheck.py).
  *
  * Documented deviations from the (non-deterministic / UB) reference behaviour:

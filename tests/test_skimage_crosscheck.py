@@ -17,11 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PY39 = "/opt/conda/bin/python3.9"
 
 
-def _reference(tmp_path, img, kps, threshold=20):
+def _reference(tmp_path, img, kps, threshold=20, angles=None):
     if not os.path.exists(PY39):
         pytest.skip("no conda python 3.9 (scikit-image) in this image")
     src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
-    np.savez(src, img=img, threshold=threshold, kps=np.asarray(kps, np.int64).reshape(-1, 2))
+    extra = {} if angles is None else {"kps_angle_deg": np.asarray(angles, np.float64)}
+    np.savez(src, img=img, threshold=threshold, kps=np.asarray(kps, np.int64).reshape(-1, 2), **extra)
     r = subprocess.run([PY39, os.path.join(ROOT, "tools", "skimage_reference.py"), src, dst], capture_output=True, text=True)
     if r.returncode != 0:
         if "No module named" in r.stderr:
@@ -62,20 +63,29 @@ def test_fast_corner_set_and_score_equal_skimage(tmp_path, kind):
 
 
 def test_orientation_disc_and_pattern_equal_skimage(tmp_path):
-    img = synth_image(9, 320, 240)
-    p = oracle.default_params(300)
+    img = synth_image(9, 640, 480)
+    p = oracle.default_params(1500)
     kps, _ = oracle.extract(p, img)
     lvl0 = kps[kps["octave"] == 0]
-    assert len(lvl0) > 50
+    assert len(lvl0) > 250
     xy = np.stack([lvl0["x"], lvl0["y"]], 1).astype(np.int64)
     blurred = oracle.gaussian_blur7(img)         # the reference measures the angle on the blurred level (ORBExtractor.cpp:536-541)
-    ref = _reference(tmp_path, blurred, xy)
+    ref = _reference(tmp_path, blurred, xy, angles=lvl0["angle"])
     assert np.array_equal(ref["umax"], oracle.umax())
     assert np.array_equal(ref["pattern"].astype(np.int32).reshape(-1), np.asarray(oracle.pattern(), np.int32).reshape(-1))
     # scikit-image takes atan2 of the same moments in double; cv::fastAtan2 is a polynomial with 0.3 degrees of error
     d = np.abs(lvl0["angle"].astype(np.float64) - ref["angle_deg"])
     d = np.minimum(d, 360.0 - d)
     assert d.max() < 0.35, d.max()
+    # steered BRIEF: scikit-image rotates the same pattern in double and rounds half away from zero, the reference in float with cvRound;
+    # a sample position can differ by a pixel only when a rotated coordinate lies within ~1e-6 of a .5 boundary, so nearly every descriptor
+    # must be bit-identical (same pattern order, same rotation sense, same comparison direction, bit i of byte j = test 8j + i)
+    want = ref["brief_bits"].astype(np.uint8)
+    _, desc = oracle.extract(p, img)
+    got = np.unpackbits(desc[kps["octave"] == 0], axis=1, bitorder="little")
+    assert got.shape == want.shape
+    same = (got == want).all(axis=1)
+    assert same.mean() > 0.97 and (got != want).mean() < 5e-4, (same.mean(), (got != want).mean())
 
 
 def test_resize_and_blur_geometry_against_torch():
