@@ -50,6 +50,9 @@ def parse_args():
                          "keeps separate extractor instances side by side, ImageProcessing.cpp:31-32).  Default 1: every kernel then has the GPU "
                          "to itself and its HIP-event duration is its own cost (the roofline block); 2 handles overlap the latency-bound stages of "
                          "one with the wide kernels of the other (+4 %% pairs/s) but each kernel's duration then includes the time it shares")
+    ap.add_argument("--profile-steps", type=int, default=-1,
+                    help="timed steps that record per-stage HIP events (the roofline's kernel durations); default: a tenth of --steps, at least 1.  "
+                         "Every recorded event drains the stream between two stages, so the remaining steps run un-instrumented")
     ap.add_argument("--lanes", type=int, default=1, choices=[1, 2],
                     help="launch sequences INSIDE one handle (hs_orb_set_lanes): same effect for callers that own a single handle")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
@@ -209,8 +212,11 @@ def fence_fn(torch, dist, world):
     return fence
 
 
-def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None):
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, pause=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.
+    The per-stage HIP events (begin / pause / end) are recorded on the FIRST `profiled_steps(args)` of the K timed steps only: an event record
+    drains the stream between two stages (28 us per step on MI355X: 5 % of a 16-pair step, 16 % of a single-pair step), so instrumenting every
+    step would make the measured throughput a property of the instrumentation."""
     if begin:
         begin()
     for _ in range(args.warmup):
@@ -219,10 +225,13 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None):
     if end:
         end()
     fence()
-    if begin:
+    n_prof = profiled_steps(args) if begin else 0
+    if n_prof:
         begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == n_prof and n_prof and pause:
+            pause()
         step()
     fence()
     t1 = time.perf_counter()
@@ -231,6 +240,12 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None):
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     return float(elapsed.item()), prof
+
+
+def profiled_steps(args):
+    """timed steps that record stage events: --profile-steps, default a tenth of the timed steps (at least one)"""
+    p = args.profile_steps if args.profile_steps >= 0 else max(1, args.steps // 10)
+    return min(p, args.steps)
 
 
 def base_line(metric, value, unit, args, world, elapsed):
@@ -281,6 +296,10 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
         for e in exs:
             e.profile_begin()
 
+    def profile_pause():
+        for e in exs:
+            e.profile_pause()
+
     def profile_end():
         tot = {}
         for e in exs:
@@ -289,7 +308,7 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
                 tot[k] = (m0 + ms, c0 + c)
         return tot
 
-    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, profile_begin, profile_end)
+    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, profile_begin, profile_end, profile_pause)
     value = world * B * args.steps / elapsed
     n_left = nL.cpu().numpy()
     n_match = int((depth.view(B, cap)[0] > 0).sum().item())
@@ -315,6 +334,7 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["roofline"] = rls[dom]
     out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
     out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
+    out["profiled_steps"] = profiled_steps(args)      # the first of the timed steps; the others record no events
     pair_bytes = 2 * per_frame
     out["end_to_end"] = {"algorithmic_bytes_per_pair": int(pair_bytes), "achieved_GBps": round(value / world * pair_bytes / 1e9, 2),
                          "frac_of_hbm_peak": round(value / world * pair_bytes / 1e9 / HBM_PEAK_GBS, 5),
@@ -342,7 +362,7 @@ def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
     def step():
         ex.extract_batch_device(frames.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, 0)
 
-    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, ex.profile_begin, ex.profile_end)
+    elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, ex.profile_begin, ex.profile_end, ex.profile_pause)
     if rank != 0:
         return
     per_stage, per_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
@@ -353,6 +373,7 @@ def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["config"] = {"workload": "C3: 64 x 1920x1080 mono frames per step, 2000 features, extract only", "distinct_frames": nd,
                      "keypoints_frame0": int(n[0].item())}
     out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
+    out["profiled_steps"] = profiled_steps(args)      # the first of the timed steps; the others record no events
     out["per_kernel_algorithmic_GBps"] = gbs
     out["end_to_end"] = {"algorithmic_bytes_per_frame": int(per_frame), "achieved_GBps": round(value / world * per_frame / 1e9, 1),
                          "frac_of_hbm_peak": round(value / world * per_frame / 1e9 / HBM_PEAK_GBS, 5)}

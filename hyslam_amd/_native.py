@@ -75,7 +75,7 @@ EXPORTS = [
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
-    "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_end", "hs_debug_stream_copy",
+    "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_pause", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
 
@@ -152,6 +152,7 @@ def lib():
     L.hs_debug_stream_copy.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.hs_orb_stage_launches.argtypes = [vp, C.c_int]
     L.hs_orb_profile_begin.argtypes = [vp]
+    L.hs_orb_profile_pause.argtypes = [vp]
     L.hs_orb_profile_end.argtypes = [vp, vp, vp]
     L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.hs_orb_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]

@@ -1112,6 +1112,14 @@ int hs_orb_profile_begin(hs_orb* h)
     return HS_OK;
 }
 
+int hs_orb_profile_pause(hs_orb* h)
+{
+    if (!h) return HS_ERR_INVALID;
+    h->prof = false;
+    if (h->lane2) h->lane2->prof = false;
+    return HS_OK;
+}
+
 int hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches)
 {
     if (!h) return HS_ERR_INVALID;

@@ -173,6 +173,10 @@ class ORBExtractor:
     def profile_begin(self):
         N.check(self._h, self._lib.hs_orb_profile_begin(self._h))
 
+    def profile_pause(self):
+        """stop recording stage events; what was recorded stays for profile_end()"""
+        N.check(self._h, self._lib.hs_orb_profile_pause(self._h))
+
     def profile_end(self):
         """-> {stage: (total_ms, launches)} measured with HIP events on the launch stream."""
         ms = np.zeros(6, np.float64)

@@ -325,12 +325,15 @@ int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_s
 /* ---- per-stage device timing (HIP events recorded on the stream the kernels run on) ----
  * Stages: 0 pyramid, 1 FAST+NMS cells, 2 quadtree distribution, 3 blur+orient+rBRIEF, 4 stereo match, 5 stereo median.
  * begin: start collecting (events are recorded around every stage of every later call on this handle);
+ * pause: stop recording without collecting (later calls run un-instrumented; what was recorded stays for `end`).  A recorded event
+ *        drains the stream between two stages (≈5 µs each on MI355X, 28 µs per call): measure on some calls, not on all;
  * end:   synchronise, write the summed milliseconds per stage into ms[6] and the number of launches of each
  *        stage into launches[6] (pyramid counts one launch per call although it is nlevels-1 kernels), stop collecting. */
 #define HS_NUM_STAGES 6
 /* kernel launches that stage `stage` issues per call (the pyramid is several launches, the stereo match two) */
 int  hs_orb_stage_launches(const hs_orb* h, int stage);
 int  hs_orb_profile_begin(hs_orb* h);
+int  hs_orb_profile_pause(hs_orb* h);
 int  hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches);
 
 /* Measurement utility: streams `bytes` from d_src to d_dst with `width` (4 or 16) bytes per lane — a kernel of KNOWN HBM traffic
