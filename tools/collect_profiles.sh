@@ -3,7 +3,7 @@
 # Counter passes are separate runs with --pmc only (no trace domains), as MI355X_MICROARCH.md prescribes.
 TAG=${1:-x}
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT      # a tag used before must not leave its files behind (summarize_profiles.py takes the first match)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $OUT/bench_under_rocprof.json 2>/dev/null
