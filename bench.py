@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md); issue-rate fractions are quoted against it
 W, H, NFEAT = 1920, 1080, 2000
-PROFILE_TAG = "r02"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
+PROFILE_TAG = "r03"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
 
 
 def parse_args():
@@ -60,6 +60,16 @@ def parse_args():
                          "c4 = dual camera (stereo pair + 4000x3000 'Imaging' frame) + 50k-landmark projection search; "
                          "c5 = one mono stream per GPU + all-gather + cross-camera match")
     ap.add_argument("--c5-match", choices=["knn2", "bow"], default="knn2", help="c5: brute-force 2-NN or vocabulary-grouped (BoW) matching against every peer")
+    ap.add_argument("--c5-comm", choices=["hs", "torch"], default="hs",
+                    help="c5 exchange: hs = the C ABI's own RCCL all-gather (hs_comm_*, enqueued on the step's stream; the id travels over torch.distributed), "
+                         "torch = torch.distributed.all_gather_into_tensor issued on the same stream")
+    ap.add_argument("--density", type=int, choices=[1, 3], default=1,
+                    help="scene density: 1 = the default synthetic scene (w*h/800 shapes: ~5 k FAST corners on level 0 of a 1080p frame), "
+                         "3 = three times the shapes (>= 12 k level-0 corners): FAST's sparse phases scale with the corner load")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="every timed step repeats its batch `inner_repeats` times so that the K timed steps cover at least this much GPU time "
+                         "(0 = one pass per step); value counts every pass")
+    ap.add_argument("--pcie-seconds", type=float, default=1.5, help="c2, N = 1: budget of the host-fed (PCIe-inclusive) secondary measurement (0 = skip)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: ranks rendezvous over gloo, exchange one tensor and rank 0 prints a JSON line (covers the --gpus spawn path on CPU)")
     return ap.parse_args()
@@ -85,16 +95,37 @@ def spawn_ranks(args):
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()
-        rc = rc or p.returncode
-    sys.stdout.write(out0)
+    # poll every child: a rank that dies at start-up would leave rank 0 blocked in the rendezvous until the process-group timeout
+    out0, rc, deadline = b"", 0, time.time() + 3600
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    alive = set(range(args.gpus))
+    eof0 = False
+    while alive or not eof0:
+        if not eof0:
+            for key, _ in sel.select(timeout=0.2):
+                chunk = os.read(key.fileobj.fileno(), 1 << 16)
+                if chunk:
+                    out0 += chunk
+                else:
+                    eof0 = True
+                    sel.unregister(key.fileobj)
+        else:
+            time.sleep(0.05)
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                rc = rc or (1 if code else 0)
+        if (rc or time.time() > deadline) and alive:      # one rank failed (or nothing finishes): stop the others, never report success
+            for r in alive:
+                procs[r].kill()
+            for r in alive:
+                procs[r].wait()
+            alive.clear()
+            rc = 1
+    sys.stdout.write(out0.decode())
     sys.stdout.flush()
     if rc:
         sys.stderr.write("bench.py: a rank failed (exit codes %s)\n" % [p.returncode for p in procs])
@@ -150,11 +181,18 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
     traffic = valu = None
     sq = {}
     src = []
+    from hyslam_amd._native import source_digests
+    want = source_digests().get(KERNEL_OF_STAGE[stage])
+
+    def fresh(entries):      # a counter is replayed only if it was collected from the kernel sources this library was built from
+        return all(e.get("source_sha16") == want for e in entries)
     try:       # a stage can be several kernels (the pyramid): per-launch averages x launches per launch sequence, summed
         t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_hbm_traffic.json")))
         if t["pairs_per_step"] == pairs_per_step:
             m = [e for k, e in t["kernels"].items() if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch]
-            if m:
+            if m and not fresh(m):
+                src.append("STALE: profiles/%s_hbm_traffic.json was collected from other kernel sources" % PROFILE_TAG)
+            elif m:
                 traffic = int(sum((e["read_MB"] + e["written_MB"]) * 1e6 * e.get("launches_per_sequence", 1) for e in m))
                 src.append("profiles/%s_hbm_traffic.json" % PROFILE_TAG)
     except Exception:
@@ -163,7 +201,9 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
         t = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_sq_counters.json")))
         if t["pairs_per_step"] == pairs_per_step:
             m = [e for k, e in t["kernels"].items() if k.startswith(KERNEL_OF_STAGE[stage]) and e["frames_per_launch"] == frames_per_launch]
-            if m:
+            if m and not fresh(m):
+                src.append("STALE: profiles/%s_sq_counters.json was collected from other kernel sources" % PROFILE_TAG)
+            elif m:
                 valu = float(sum(e["SQ_INSTS_VALU"] * e.get("launches_per_sequence", 1) for e in m))
                 for c in ("SQ_BUSY_CU_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"):
                     if all(c in e for e in m):
@@ -200,6 +240,10 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
                 rl["lds_conflict_frac"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / busy, 4)
         else:         # older counter files: against the nominal clock (the clock under load is lower: this understates the fraction)
             rl["valu_issue_frac"] = round(valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+        # what the counters say bounds the kernel: at >= 0.7 VALU wave-instructions per busy CU cycle (the measured ceiling of this instruction mix
+        # is 0.8-0.9) it is instruction issue, not HBM; `frac` stays the HBM fraction of the algorithmic bytes either way
+        if rl["valu_issue_frac"] >= 0.7:
+            rl["bound"] = "valu_issue"
     return rl
 
 
@@ -219,11 +263,24 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, paus
     step would make the measured throughput a property of the instrumentation."""
     if begin:
         begin()
-    for _ in range(args.warmup):
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
+    t_pass = (time.perf_counter() - tw) / max(args.warmup, 1)
     if end:
         end()
+    # the driver may ask for so few steps that the timed region is a few milliseconds (20 steps = 10 ms): repeat the batch inside a step so that
+    # the K steps cover >= --min-timed-ms of GPU time.  `steps` stays the caller's unit; every rank uses the same factor.
+    inner = 1
+    if args.min_timed_ms > 0 and t_pass > 0:
+        inner = max(1, int(np.ceil(args.min_timed_ms * 1e-3 / (args.steps * t_pass))))
+    if world > 1:
+        t = torch.tensor([inner], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        inner = int(t.item())
+    args.inner_repeats = inner
     fence()
     n_prof = profiled_steps(args) if begin else 0
     if n_prof:
@@ -232,7 +289,8 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, paus
     for i in range(args.steps):
         if i == n_prof and n_prof and pause:
             pause()
-        step()
+        for _ in range(inner):
+            step()
     fence()
     t1 = time.perf_counter()
     prof = end() if end else None
@@ -250,8 +308,8 @@ def profiled_steps(args):
 
 def base_line(metric, value, unit, args, world, elapsed):
     return {"metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic"}
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "inner_repeats": getattr(args, "inner_repeats", 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
 
 
 # ------------------------------------------------------------------------------------------------ C2 (headline)
@@ -260,7 +318,8 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     from hyslam_amd.distributed import shard_range
     B = args.pairs
     nd = max(1, min(args.distinct, B))
-    pairs = [synth_stereo_pair(1000 + 97 * rank + i, W, H) for i in range(nd)]
+    n_shapes = args.density * max(40, (W * H) // 800)
+    pairs = [synth_stereo_pair(1000 + 97 * rank + i, W, H, n_shapes) for i in range(nd)]
     left = torch.from_numpy(np.stack([pairs[i % nd][0] for i in range(B)])).to(dev)
     right = torch.from_numpy(np.stack([pairs[i % nd][1] for i in range(B)])).to(dev)
 
@@ -309,7 +368,7 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
         return tot
 
     elapsed, prof = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev, profile_begin, profile_end, profile_pause)
-    value = world * B * args.steps / elapsed
+    value = world * B * args.steps * args.inner_repeats / elapsed
     n_left = nL.cpu().numpy()
     n_match = int((depth.view(B, cap)[0] > 0).sum().item())
     if rank != 0:
@@ -326,7 +385,7 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     rls = {s: roofline_block(s, stage_ms, per_stage, frames_per_launch, launches[s], B, moved.get(s)) for s in launches}
     out = base_line("stereo frames/sec ORB extract+match, 1920x1080 @2000 feat", value, "stereo_pairs/s", args, world, elapsed)
     out["config"] = {"workload": "C2: 1920x1080 stereo pair, 2000 features/frame, 8 levels @1.2, extract L+R + stereo match",
-                     "pairs_per_step_per_gpu": B, "handles": nh, "lanes_per_handle": lanes,
+                     "pairs_per_step_per_gpu": B * args.inner_repeats, "pairs_per_pass": B, "handles": nh, "lanes_per_handle": lanes, "scene_density": args.density,
                      "distinct_pairs": "%d distinct synthetic pairs per rank; the %d pairs of a step are separate copies in HBM (pair i = distinct pair i %% %d): "
                                        "no address reuse inside a step, every step re-reads the same %d MB of frames" % (nd, B, nd, 2 * B * W * H // 1000000),
                      "sharding": "pairs sharded over ranks, no collective",
@@ -339,6 +398,9 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["end_to_end"] = {"algorithmic_bytes_per_pair": int(pair_bytes), "achieved_GBps": round(value / world * pair_bytes / 1e9, 2),
                          "frac_of_hbm_peak": round(value / world * pair_bytes / 1e9 / HBM_PEAK_GBS, 5),
                          "note": "algorithmic bytes include the reference's full-level blur (2P per frame) that k_describe does not move"}
+    moved_pair = pair_bytes - 2 * 2 * sum(px)             # without the blur's read + write of every level
+    out["end_to_end"]["moved_bytes_per_pair"] = int(moved_pair)
+    out["end_to_end"]["frac_on_moved_bytes"] = round(value / world * moved_pair / 1e9 / HBM_PEAK_GBS, 5)
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
     print(json.dumps(out), flush=True)
@@ -368,7 +430,7 @@ def run_c3(args, rank, world, local_rank, dev, torch, dist, HS, N):
     per_stage, per_frame = algorithmic_bytes(pyramid_pixels(ex, W, H), NFEAT)
     stage_ms = {s: (ms / max(c, 1)) for s, (ms, c) in prof.items() if c}
     gbs = {s: round(per_stage[s] * B / (stage_ms[s] * 1e-3) / 1e9, 1) for s in ("pyramid", "fast_cells", "describe") if s in stage_ms}
-    value = world * B * args.steps / elapsed
+    value = world * B * args.steps * args.inner_repeats / elapsed
     out = base_line("mono frames/sec ORB extract, 1920x1080 @2000 feat, batch 64", value, "frames/s", args, world, elapsed)
     out["config"] = {"workload": "C3: 64 x 1920x1080 mono frames per step, 2000 features, extract only", "distinct_frames": nd,
                      "keypoints_frame0": int(n[0].item())}
@@ -464,7 +526,7 @@ def run_c4(args, rank, world, local_rank, dev, torch, dist, HS, N):
     _, img_frame = algorithmic_bytes(pyramid_pixels(exi, IW, IH), IFEAT)
     proj_bytes = L * lms.dtype.itemsize + n0 * (24 + 32 + 4)
     step_bytes = 2 * pair_frame + img_frame + proj_bytes
-    value = world * args.steps / elapsed
+    value = world * args.steps * args.inner_repeats / elapsed
     out = base_line("dual-camera steps/sec: 1080p stereo extract+match + 4000x3000 extract + 50k-landmark SearchByProjection", value, "steps/s", args, world, elapsed)
     out["config"] = {"workload": "C4: per step one 1920x1080 stereo pair (2000 feat @1.2) + one 4000x3000 frame (3000 feat @1.4) + SearchByProjection of a "
                                  "50 000-landmark local map (th 5, nnratio 0.8) on the stereo frame's device-resident outputs",
@@ -488,31 +550,52 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
     (one launch, counts read from the record headers on the device) or vocabulary-grouped BoW matching.  Nothing synchronises with the
     host inside a step.  value = frames/s over all ranks."""
     from hyslam_amd import distributed as D
-    from hyslam_amd.synth import synth_image
+    from hyslam_amd.synth import synth_rig
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
     cap = ex.max_keypoints()
-    frame = torch.from_numpy(synth_image(200 + rank, W, H)).to(dev)
+    # an 8-camera rig over one wide scene, neighbours overlapping by three quarters (SURVEY.md §8d C5); two instants per camera, alternated
+    # step by step, so that a step that reads a buffer another stage is still writing shows up as a wrong count instead of passing silently
+    rig = max(world, 8)
+    frames = [torch.from_numpy(synth_rig(200 + 10 * t, rig, W, H, cams=[rank % rig])[0]).to(dev) for t in range(2)]
     rb = D.record_bytes(cap)
     gathered = torch.zeros((world, rb), dtype=torch.uint8, device=dev)
-    rec = gathered[rank] if world == 1 else torch.zeros(rb, dtype=torch.uint8, device=dev)
     o_n, o_k, o_d = D.record_offsets(cap)
     ex.reserve(W, H, 1)
-    stream = torch.cuda.current_stream().cuda_stream
+    # ONE explicit stream carries extraction, all-gather and matcher of a step (torch's current stream during the step, so that
+    # torch.distributed's collective is ordered on it too): the three stages are serial by construction
+    s = torch.cuda.Stream()
+    stream = s.cuda_stream
     outs = tuple(torch.zeros((world, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    xc = None
+    if world > 1 and args.c5_comm == "hs":
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(D.RecordExchange.unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        xc = D.RecordExchange(ex, bytes(ident.cpu().numpy().tobytes()), world, rank)
+    # hs path: the extractor writes straight into this rank's slot of the gathered buffer and the all-gather runs in place;
+    # torch path: a separate send buffer (all_gather_into_tensor does not promise in-place operation)
+    rec = gathered[rank] if (world == 1 or xc is not None) else torch.zeros(rb, dtype=torch.uint8, device=dev)
     bow = None
     if args.c5_match == "bow":
         if not hasattr(D, "BowCrossCamera"):
             sys.exit("bench.py: --c5-match bow needs the device-resident vocabulary path (hyslam_amd.distributed.BowCrossCamera)")
         bow = D.BowCrossCamera(ex, world, cap, seed=17)
+    tick = {"n": 0}
 
     def step():
-        ex.extract_batch_device(frame.data_ptr(), 1, W, H, W, W * H, rec.data_ptr() + o_k, rec.data_ptr() + o_d, rec.data_ptr() + o_n, cap, stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), rec)
-        if bow is not None:
-            bow.match(gathered, rank, stream)
-        else:
-            D.cross_camera_knn2(ex, gathered, rank, cap, stream, out=outs)
+        frame = frames[tick["n"] & 1]
+        tick["n"] += 1
+        with torch.cuda.stream(s):
+            ex.extract_batch_device(frame.data_ptr(), 1, W, H, W, W * H, rec.data_ptr() + o_k, rec.data_ptr() + o_d, rec.data_ptr() + o_n, cap, stream)
+            if xc is not None:
+                xc.allgather(rec.data_ptr(), gathered.data_ptr(), rb, stream)
+            elif world > 1:
+                dist.all_gather_into_tensor(gathered.view(-1), rec)
+            if bow is not None:
+                bow.match(gathered, rank, stream)
+            else:
+                D.cross_camera_knn2(ex, gathered, rank, cap, stream, out=outs)
 
     elapsed, _ = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev)
     counts = gathered[:, :4].view(torch.int32)[:, 0].cpu().tolist()
@@ -527,10 +610,11 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
         good = bow.total_matches(rank)
     if rank != 0:
         return
-    out = base_line("mono frames/sec ORB extract + all-gather + cross-camera match, 1920x1080 @2000 feat", world * args.steps / elapsed, "frames/s",
+    out = base_line("mono frames/sec ORB extract + all-gather + cross-camera match, 1920x1080 @2000 feat", world * args.steps * args.inner_repeats / elapsed, "frames/s",
                     args, world, elapsed)
     out["config"] = {"workload": "C5: one 1920x1080 mono stream per GPU, 2000 features, all-gather of %d-byte records, %s vs every peer"
                                  % (rb, "brute-force Hamming 2-NN" if bow is None else "vocabulary transform + BoW-grouped match (synthetic 10-ary vocabulary)"),
+                     "exchange": "none (one rank)" if world == 1 else ("hs_comm_allgather_records (RCCL through the C ABI), in place" if xc is not None else "torch.distributed.all_gather_into_tensor"),
                      "keypoints_rank0": counts[0], "matches_rank0": good}
     print(json.dumps(out), flush=True)
 

@@ -68,18 +68,47 @@ class HsError(RuntimeError):
 # every symbol include/hyslam_amd.h declares (tests check the library exports all of them)
 EXPORTS = [
     "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
-    "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
+    "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_device", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
     "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
+    "hs_comm_get_unique_id", "hs_comm_create", "hs_comm_destroy", "hs_comm_world", "hs_comm_rank", "hs_comm_last_error", "hs_comm_allgather_records",
     "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_pause", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
 
 _lib = None
+
+# source files each kernel family is compiled from: the committed rocprofv3 counter passes (profiles/*_{hbm_traffic,sq_counters}.json) are stamped
+# with these digests and bench.py only replays a counter whose kernel sources are unchanged
+KERNEL_SOURCES = {
+    "k_fast_rows": ["kernels_fast.hip", "hs_internal.h"],
+    "k_resize": ["kernels_pyramid.hip", "hs_internal.h"],
+    "k_describe": ["kernels_describe.hip", "lean_sincos.h", "hs_internal.h"],
+    "k_quadtree": ["kernels_quadtree.hip", "hs_internal.h"],
+    "k_qt": ["kernels_quadtree.hip", "hs_internal.h"],
+    "k_stereo": ["kernels_stereo.hip", "hs_internal.h"],
+}
+
+
+def source_digests():
+    """{kernel-name prefix: sha256[:16] of the source files it is compiled from} (hyslam_amd/csrc travels with the repository snapshot)"""
+    import hashlib
+    out = {}
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for k, files in KERNEL_SOURCES.items():
+        h = hashlib.sha256()
+        for f in files:
+            try:
+                h.update(open(os.path.join(src, f), "rb").read())
+            except OSError:
+                h.update(b"missing:" + f.encode())
+        out[k] = h.hexdigest()[:16]
+    return out
+
 
 
 def lib():
@@ -104,6 +133,7 @@ def lib():
     L.hs_orb_last_error.argtypes = [vp]
     L.hs_orb_last_error.restype = C.c_char_p
     L.hs_orb_get_levels.argtypes = [vp]
+    L.hs_orb_get_device.argtypes = [vp]
     L.hs_orb_get_scale_factor.argtypes = [vp]
     L.hs_orb_get_scale_factor.restype = f32
     L.hs_orb_get_scale_tables.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -149,6 +179,15 @@ def lib():
     L.hs_record_offsets.argtypes = [C.c_int, vp, vp, vp]
     L.hs_record_offsets.restype = None
     L.hs_records_knn2_device.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.hs_comm_get_unique_id.argtypes = [vp]
+    L.hs_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.hs_comm_destroy.argtypes = [vp]
+    L.hs_comm_destroy.restype = None
+    L.hs_comm_world.argtypes = [vp]
+    L.hs_comm_rank.argtypes = [vp]
+    L.hs_comm_last_error.argtypes = [vp]
+    L.hs_comm_last_error.restype = C.c_char_p
+    L.hs_comm_allgather_records.argtypes = [vp, vp, vp, sz, vp]
     L.hs_debug_stream_copy.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.hs_orb_stage_launches.argtypes = [vp, C.c_int]
     L.hs_orb_profile_begin.argtypes = [vp]

@@ -304,8 +304,17 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     mark(h, 0, s);
     hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
     mark(h, 1, s);
-    hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                   h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch++, h->fast_knobs, s);
+    {   // launch N uses work-queue counter set N & 1 and relies on launch N - 1 having zeroed it: the epoch advances only when a launch was
+        // enqueued without error; after a failed launch both sets are zeroed again so that the next one starts from a known state
+        const bool launched = hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
+                                             h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs, s);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            (void)hipMemsetAsync(h->d_fast_ovf, 0, 2 * HS_FAST_QUEUE_DWORDS * 4, s);
+            return fail(h, HS_ERR_HIP, std::string("FAST launch: ") + hipGetErrorString(e));
+        }
+        if (launched) h->fast_epoch++;
+    }
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, s);
@@ -458,6 +467,7 @@ void hs_orb_destroy(hs_orb* h)
 
 const char* hs_orb_last_error(const hs_orb* h) { return h ? h->err.c_str() : "null handle"; }
 int hs_orb_get_levels(const hs_orb* h) { return h ? h->p.nlevels : 0; }
+int hs_orb_get_device(const hs_orb* h) { return h ? h->device : -1; }
 float hs_orb_get_scale_factor(const hs_orb* h) { return h ? (float)(double)h->p.scale_factor : 0.f; }
 
 int hs_orb_get_scale_tables(const hs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int32_t* fpl)

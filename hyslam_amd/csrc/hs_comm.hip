@@ -1,0 +1,123 @@
+// hs_comm.hip — the ONE collective of the path in C: an RCCL all-gather of the fixed-size frame records (BASELINE config 5).
+// The reference has no multi-camera exchange; north_star adds it ("RCCL all-gather over xGMI of per-frame keypoints / descriptors for
+// cross-camera matching") and keeps the host in C++, so the exchange must not need Python: hs_comm_* wraps ncclGetUniqueId /
+// ncclCommInitRank / ncclAllGather / ncclCommDestroy.  The caller carries the 128-byte id from rank 0 to the other ranks over whatever channel
+// it already has (a file, a socket, MPI, torch.distributed) — the same contract as NCCL's own bootstrap.
+// librccl is resolved with dlopen on first use: the extractor / matcher library has no link-time dependency on RCCL, a process that never
+// creates a communicator never loads it, and a process that already loaded an RCCL (PyTorch ships one) shares that copy.
+// The all-gather is enqueued on the caller's stream (default: the handle's own): with the extraction before it and the matcher after it on the
+// SAME stream the three stages of a config-5 step are ordered without events and without touching the host.
+#include "hs_internal.h"
+#include <dlfcn.h>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+void hs_set_error(hs_orb* h, const char* msg);       // hs_api.hip
+int hs_orb_device_of(const hs_orb* h);              // hs_api.hip
+hipStream_t hs_orb_stream_of(const hs_orb* h);      // hs_api.hip
+
+// the RCCL types this file needs (rccl.h: ncclResult_t is an enum, ncclComm_t an opaque pointer, ncclUniqueId 128 opaque bytes, ncclChar = 0)
+typedef int hs_nccl_result;
+typedef struct ncclComm* hs_nccl_comm;
+struct hs_nccl_id { char internal[HS_COMM_ID_BYTES]; };
+static_assert(HS_COMM_ID_BYTES == 128, "NCCL_UNIQUE_ID_BYTES");
+
+namespace {
+struct Rccl {
+    void* so = nullptr;
+    hs_nccl_result (*GetUniqueId)(hs_nccl_id*) = nullptr;
+    hs_nccl_result (*CommInitRank)(hs_nccl_comm*, int, hs_nccl_id, int) = nullptr;
+    hs_nccl_result (*AllGather)(const void*, void*, size_t, int, hs_nccl_comm, hipStream_t) = nullptr;
+    hs_nccl_result (*CommDestroy)(hs_nccl_comm) = nullptr;
+    const char* (*GetErrorString)(hs_nccl_result) = nullptr;
+    std::string why;
+};
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.so) break; }
+        if (!r.so) { const char* e = dlerror(); r.why = std::string("librccl not found: ") + (e ? e : ""); return; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.why = "librccl lacks an expected symbol"; r.so = nullptr; }
+    });
+    return r;
+}
+std::string nccl_text(const Rccl& r, const char* what, hs_nccl_result rc)
+{
+    return std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+}
+}  // namespace
+
+struct hs_comm {
+    hs_orb* h = nullptr;
+    hs_nccl_comm comm = nullptr;
+    int world = 0, rank = 0;
+    std::string err;
+};
+
+extern "C" {
+
+int hs_comm_get_unique_id(uint8_t* id)
+{
+    if (!id) return HS_ERR_INVALID;
+    Rccl& r = rccl();
+    if (!r.so) return HS_ERR_NO_DEVICE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); return HS_ERR_NO_DEVICE; }
+    hs_nccl_id u;
+    if (r.GetUniqueId(&u) != 0) return HS_ERR_HIP;
+    memcpy(id, u.internal, HS_COMM_ID_BYTES);
+    return HS_OK;
+}
+
+int hs_comm_create(hs_orb* h, const uint8_t* id, int world, int rank, hs_comm** out)
+{
+    if (!h || !id || !out || world < 1 || rank < 0 || rank >= world) return HS_ERR_INVALID;
+    *out = nullptr;
+    Rccl& r = rccl();
+    if (!r.so) { hs_set_error(h, r.why.c_str()); return HS_ERR_NO_DEVICE; }
+    if (hipSetDevice(hs_orb_device_of(h)) != hipSuccess) { (void)hipGetLastError(); hs_set_error(h, "hipSetDevice failed"); return HS_ERR_HIP; }
+    hs_nccl_id u;
+    memcpy(u.internal, id, HS_COMM_ID_BYTES);
+    hs_comm* c = new hs_comm();
+    c->h = h; c->world = world; c->rank = rank;
+    const hs_nccl_result rc = r.CommInitRank(&c->comm, world, u, rank);      // blocks until all `world` ranks have called it
+    if (rc != 0) { hs_set_error(h, nccl_text(r, "ncclCommInitRank", rc).c_str()); delete c; return HS_ERR_HIP; }
+    *out = c;
+    return HS_OK;
+}
+
+void hs_comm_destroy(hs_comm* c)
+{
+    if (!c) return;
+    Rccl& r = rccl();
+    if (c->comm && r.so) { hipSetDevice(hs_orb_device_of(c->h)); r.CommDestroy(c->comm); }
+    delete c;
+}
+
+int hs_comm_world(const hs_comm* c) { return c ? c->world : 0; }
+int hs_comm_rank(const hs_comm* c) { return c ? c->rank : -1; }
+const char* hs_comm_last_error(const hs_comm* c) { return c ? c->err.c_str() : "null communicator"; }
+
+int hs_comm_allgather_records(hs_comm* c, const void* d_record, void* d_gathered, size_t record_bytes, void* stream)
+{
+    if (!c) return HS_ERR_INVALID;
+    if (!d_record || !d_gathered || record_bytes == 0) { c->err = "bad argument"; return HS_ERR_INVALID; }
+    Rccl& r = rccl();
+    if (hipSetDevice(hs_orb_device_of(c->h)) != hipSuccess) { (void)hipGetLastError(); c->err = "hipSetDevice failed"; return HS_ERR_HIP; }
+    hipStream_t s = stream ? (hipStream_t)stream : hs_orb_stream_of(c->h);
+    // ncclChar = 0; in place when d_record == d_gathered + rank * record_bytes (NCCL's in-place all-gather convention)
+    const hs_nccl_result rc = r.AllGather(d_record, d_gathered, record_bytes, 0, c->comm, s);
+    if (rc != 0) { c->err = nccl_text(r, "ncclAllGather", rc); return HS_ERR_HIP; }
+    return HS_OK;
+}
+
+}  // extern "C"

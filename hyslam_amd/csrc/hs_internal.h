@@ -132,7 +132,7 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[su
 #define HS_FAST_QUEUE_DWORDS 256   // head of the FAST overflow buffer: two alternating sets of 8 work-queue counters on 128-byte lines of their own
 struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
-void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
+bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
                     const HsFastKnobs& knobs, hipStream_t s);

@@ -7,8 +7,13 @@
 // formats are restated from the published ORB-SLAM2 DBoW2 sources that define them:
 //   text    line 1: "k L scoring weighting"; then one line per node in id order (ids 1.., 0 is the root):
 //           "parent_id is_leaf b0 b1 ... b31 weight"   (32 descriptor bytes as decimal numbers)
-//   binary  uint32 nb_nodes, uint32 size_node (= 4 + 32 + 4 + 1), int32 k, int32 L, int32 scoring, int32 weighting, then nb_nodes records
-//           { int32 parent; uint8 desc[32]; float weight; uint8 is_leaf }
+//   binary  uint32 nb_nodes, uint32 size_node (= 4 + 32 + 4 + 1), int32 k, int32 L, int32 scoring, int32 weighting, then records
+//           { uint32 parent; uint8 desc[32]; float weight; uint8 is_leaf } for nodes 1 .. nb_nodes-1 until the end of the file:
+//           saveToBinaryFile writes nb_nodes = m_nodes.size(), i.e. the root is COUNTED but has no record (its loop starts at node 1), and
+//           loadFromBinaryFile sizes m_nodes from the header and reads records until EOF.  The loader therefore trusts the FILE LENGTH and
+//           accepts nb_nodes - 1 records (DBoW2's writer) or nb_nodes records (files written by round 2 of this library, which did not count
+//           the root).  BINARY LAYOUT UNVERIFIED: restated from the ORB-SLAM2 DBoW2 fork's published source; neither that library nor a sample
+//           .bin file is in the reference tree (tools/bin_vocabulary.cc only calls the two functions), so no fixture pins it.
 // Word ids are assigned to the leaves in file order, children keep file order (DBoW2 walks them in that order and the first minimum wins).
 // The flat tree keeps DBoW2's node numbering whenever the children of every node are contiguous in it (true for vocabularies made by DBoW2's
 // hierarchical k-means, ORBvoc included); otherwise nodes are renumbered breadth first and `orig_id` maps back to the DBoW2 NodeId.
@@ -124,10 +129,17 @@ int load_binary(hs_vocab* v, const char* path)
     v->k = hdr[0]; v->L = hdr[1]; v->scoring = hdr[2]; v->weighting = hdr[3];
     std::vector<RawNode> nodes(1);
     nodes[0].parent = -1; nodes[0].leaf = false; nodes[0].w = 0; memset(nodes[0].d, 0, 32);
-    std::vector<uint8_t> buf((size_t)nb * 41);
-    ok = fread(buf.data(), 41, nb, f) == nb;
+    std::vector<uint8_t> buf;
+    {   // DBoW2 reads 41-byte records until EOF
+        uint8_t chunk[41 * 256]; size_t got;
+        while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) buf.insert(buf.end(), chunk, chunk + got);
+    }
     fclose(f);
-    if (!ok) { v->err = "truncated binary vocabulary"; return HS_ERR_INVALID; }
+    if (buf.size() % 41 != 0) { v->err = "truncated binary vocabulary (the node records do not end on a record boundary)"; return HS_ERR_INVALID; }
+    const uint32_t records = (uint32_t)(buf.size() / 41);
+    if (records != nb && records + 1 != nb) { v->err = "binary vocabulary: header announces " + std::to_string(nb) + " nodes, file holds " + std::to_string(records) + " records"; return HS_ERR_INVALID; }
+    if (records < 1) { v->err = "binary vocabulary without nodes"; return HS_ERR_INVALID; }
+    nb = records;
     nodes.reserve(nb + 1);
     for (uint32_t i = 0; i < nb; i++) {
         const uint8_t* p = &buf[(size_t)i * 41];
@@ -224,7 +236,7 @@ int hs_vocab_save(const hs_vocab* v, const char* path)
     }
     FILE* f = fopen(path, "wb");
     if (!f) return HS_ERR_INVALID;
-    const uint32_t nb = (uint32_t)(n - 1), sz = 41; const int32_t hdr[4] = { v->k, v->L, v->scoring, v->weighting };
+    const uint32_t nb = (uint32_t)n /* m_nodes.size(): the root is counted, its record is not written */, sz = 41; const int32_t hdr[4] = { v->k, v->L, v->scoring, v->weighting };
     fwrite(&nb, 4, 1, f); fwrite(&sz, 4, 1, f); fwrite(hdr, 4, 4, f);
     for (int o = 1; o < n; o++) {
         const int i = by_orig[o];

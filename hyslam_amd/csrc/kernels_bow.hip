@@ -291,7 +291,8 @@ int hs_records_bow_match_device(hs_orb* h, hs_vocab_dev* v, const uint8_t* d_rec
     hipStream_t s = stream ? (hipStream_t)stream : hs_orb_stream_of(h);
     const size_t feats = (size_t)world * cap;
     if (feats > v->cap_feats || (size_t)world > v->cap_records) {             // scratch grows; steady state allocates nothing
-        if (hipStreamSynchronize(s) != hipSuccess) return HS_ERR_HIP;
+        // the scratch belongs to the vocabulary object, which callers may have used on another stream before: drain the whole device (rare path)
+        if (hipDeviceSynchronize() != hipSuccess) return HS_ERR_HIP;
         hipFree(v->d_fgroup); hipFree(v->d_start); hipFree(v->d_items); v->d_fgroup = nullptr; v->d_start = nullptr; v->d_items = nullptr; v->cap_feats = v->cap_records = 0;
         if (hipMalloc(&v->d_fgroup, feats * 4) != hipSuccess || hipMalloc(&v->d_items, feats * 2) != hipSuccess ||
             hipMalloc(&v->d_start, (size_t)world * (v->groups + 1) * 4) != hipSuccess) { (void)hipGetLastError(); hs_set_error(h, "out of device memory"); return HS_ERR_HIP; }

@@ -654,7 +654,7 @@ size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKno
     return (size_t)2 * HS_FAST_QUEUE_DWORDS * 4 + (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
 }
 
-static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
+static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                              int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
@@ -663,7 +663,7 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const FastRowsLds& L = c.lds;
     const int lc = c.lc, tr = c.tr;
     const int total_work = items_per_img * batch;
-    if (total_work <= 0) return;
+    if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
@@ -671,13 +671,16 @@ static void launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
+    return true;
 }
 
-void hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
+// returns whether a kernel was enqueued: a launch consumes one work-queue counter set (`epoch` & 1) and zeroes it for the launch after next,
+// so the caller advances its epoch only for launches that happened
+bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
-    if (total_cells <= 0) return;
-    launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
+    if (total_cells <= 0) return false;
+    return launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
 }

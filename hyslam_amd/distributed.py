@@ -71,6 +71,51 @@ def all_gather_records(record, group=None):
     return out
 
 
+class RecordExchange:
+    """The exchange through the C ABI (hs_comm_*: RCCL's all-gather without torch).  One rank calls unique_id() and hands the 128 bytes to
+    the others (any channel: a file, a socket, torch.distributed.broadcast); every rank then builds RecordExchange(extractor, id, world, rank),
+    which blocks until all ranks arrived.  allgather() enqueues on `stream` (0 = the extractor handle's own stream), where the extraction
+    before it and the matcher after it run too: no events, no host synchronisation inside a step."""
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _native as N
+        ident = (C.c_uint8 * 128)()
+        st = N.lib().hs_comm_get_unique_id(ident)
+        if st != N.HS_OK:
+            raise N.HsError(st, "hs_comm_get_unique_id: " + N.lib().hs_status_string(st).decode())
+        return bytes(ident)
+
+    def __init__(self, extractor, ident, world, rank):
+        import ctypes as C
+        from . import _native as N
+        self._ex, self.world, self.rank = extractor, world, rank
+        self._c = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident)
+        N.check(extractor._h, extractor._lib.hs_comm_create(extractor._h, buf, world, rank, C.byref(self._c)))
+
+    def allgather(self, d_record, d_gathered, record_bytes, stream=0):
+        """device addresses (integers); in place when d_record == d_gathered + rank * record_bytes"""
+        import ctypes as C
+        from . import _native as N
+        lib = self._ex._lib
+        st = lib.hs_comm_allgather_records(self._c, C.c_void_p(d_record), C.c_void_p(d_gathered), record_bytes, C.c_void_p(stream) if stream else None)
+        if st != N.HS_OK:
+            raise N.HsError(st, "hs_comm_allgather_records: " + lib.hs_comm_last_error(self._c).decode())
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._ex._lib.hs_comm_destroy(self._c)
+            self._c.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def records_knn2_device(extractor, d_records, record_stride, world, rank, cap, d_best_idx, d_best_dist, d_second_dist, stream=0):
     """hs_records_knn2_device on raw device addresses (integers): 2-NN of record `rank`'s descriptors against every other record's;
     outputs [world][cap] int32.  The counts are read from the record headers on the device — nothing synchronises with the host."""

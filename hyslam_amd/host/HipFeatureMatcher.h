@@ -11,7 +11,10 @@
 //   search   one C-ABI call (GPU)
 //   replay   Frame::associateLandMark(idx, lm, true) for every match, in that same address order (FeatureMatcher.cc:113-118) — a later
 //            landmark that picked the same keypoint overwrites the earlier one, exactly as in the reference.
-// Entry points not overridden here (Sim3 / loop-closing legacy, SearchByBoW(KF,KF), SearchForTriangulation) stay the reference's CPU code.
+// Overridden: the four SearchByProjection overloads, SearchByBoW(KF, Frame), SearchByBoW2, SearchForTriangulation, SearchForInitialization,
+// Fuse(pKF, points, ...), Fuse(pKF, Scw, ...) (an empty body in the reference, FeatureMatcher.cc:523-624) and SearchBySim3 — every entry point
+// that has a call site in hySLAM.  Not overridden: SearchByBoW(KF, KF, vpMatches12) (FeatureMatcher.cc:938-1077), which no file of hySLAM calls
+// ("aim to replace this with SearchByBoW2", :939); it stays the reference's CPU code.
 #pragma once
 #ifdef HYSLAM_AMD_WITH_HYSLAM
 #include <FeatureMatcher.h>
@@ -22,11 +25,13 @@
 #include "cv_compat.h"
 #endif
 #include <algorithm>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
 #include "../../include/hyslam_amd.h"
+#include "HipORBExtractor.h"
 
 namespace HYSLAM {
 
@@ -70,8 +75,8 @@ public:
         for (const auto& kv : pKF->getLandMarkMatches())
             if (kv.second && !kv.second->isBad() && kv.first >= 0 && kv.first < (int)keep1.size()) keep1[kv.first] = 1;
         std::vector<int32_t> m12(std::max<size_t>(a.kps.size(), 1), -1); int32_t n = 0;
-        check(hs_search_by_bow(h, a.kps.data(), a.desc.data(), (int)a.kps.size(), f1.id.data(), f1.ptr.data(), f1.idx.data(), (int)f1.id.size(),
-                               b.kps.data(), b.desc.data(), (int)b.kps.size(), f2.id.data(), f2.ptr.data(), f2.idx.data(), (int)f2.id.size(),
+        check(hs_search_by_bow(h, a.kps.data(), a.desc.data(), (int)a.kps.size(), f1.id.data(), f1.ptr.data(), f1.idx.data(), (int)f1.ptr.size() - 1,
+                               b.kps.data(), b.desc.data(), (int)b.kps.size(), f2.id.data(), f2.ptr.data(), f2.idx.data(), (int)f2.ptr.size() - 1,
                                keep1.data(), TH_LOW, mfNNratio, 1, m12.data(), &n), "SearchByBoW");
         for (size_t i = 0; i < a.kps.size(); i++)          // ascending key-frame index = the order of the reference's std::map (:267-272)
             if (m12[i] >= 0) matches[(size_t)m12[i]] = pKF->hasAssociation((int)i);
@@ -110,7 +115,75 @@ public:
         return (int)fuse_matches.size();
     }
 
+    // SearchByBoW2(pKF1, pKF2, vpMatches12) — LoopClosing.cc:275 (FeatureMatcher.cc:346-371): _SearchByBoW_ with PreviouslyMatchedIndexCriterion(true) on
+    // BOTH key frames (:306-309), BestMatchBoWCriterion(TH_LOW, mfNNratio), RotationConsistencyBoW; vpMatches12[i] = KF2's landmark at the matched view.
+    int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override {
+        std::vector<int32_t> m12; const int n = bow_between_keyframes(pKF1, pKF2, true, false, nullptr, mfNNratio, m12, "SearchByBoW2");
+        const size_t N1 = pKF1->GetMapPointMatches().size();
+        vpMatches12 = std::vector<MapPoint*>(N1, static_cast<MapPoint*>(NULL));
+        for (size_t i = 0; i < N1 && i < m12.size(); i++) if (m12[i] >= 0) vpMatches12[i] = pKF2->hasAssociation((int)m12[i]);
+        return n;
+    }
+
+    // SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) — LandMarkTriangulator.cpp:81 (FeatureMatcher.cc:373-402):
+    // PreviouslyMatchedIndexCriterion(false) (+ StereoIndexCriterion when bOnlyStereo) on both key frames, EpipolarConsistencyBoWCriterion(F12)
+    // — the epipole (ex, ey) the reference computes is stored by the criterion and never read (MatchCriteria.cpp:637-676) —
+    // BestMatchBoWCriterion(TH_LOW, 1.0), RotationConsistencyBoW.  Pairs are appended in ascending idx1 order (std::map iteration, :396-398).
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo) override {
+        float F[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
+        std::vector<int32_t> m12; const int n = bow_between_keyframes(pKF1, pKF2, false, bOnlyStereo, F, 1.0f, m12, "SearchForTriangulation");
+        for (size_t i = 0; i < m12.size(); i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+        return n;
+    }
+
+    // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) — LoopClosing.cc:389 (FeatureMatcher.cc:628-737).  Landmarks stay in vpPoints order (the
+    // search is sequential: a keypoint taken by an earlier landmark is invisible to later ones, :713,731).
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) override {
+        FrameArrays fa; hs_frame_view V = gather_frame(*pKF, fa);
+        float S[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S[4 * r + c] = Scw.at<float>(r, c);
+        std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());                               // :649-650
+        spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+        std::vector<hs_landmark> L = gather_landmarks(vpPoints, *pKF, nullptr);
+        for (size_t i = 0; i < vpPoints.size(); i++)
+            if (vpPoints[i] && (vpPoints[i]->isBad() || spAlreadyFound.count(vpPoints[i]))) L[i].skip = 1;   // :660-661
+        std::vector<uint8_t> taken(std::max<size_t>(V.n, 1), 0);
+        for (int i = 0; i < V.n && i < (int)vpMatched.size(); i++) taken[i] = vpMatched[i] != nullptr;
+        std::vector<int32_t> midx(std::max<size_t>(vpPoints.size(), 1), -1); int32_t n = 0;
+        check(hs_search_by_projection_sim3(h, &V, S, L.data(), (int)vpPoints.size(), th, TH_LOW, taken.data(), midx.data(), &n), "SearchByProjection(Scw)");
+        for (size_t i = 0; i < vpPoints.size(); i++) if (midx[i] >= 0) vpMatched[midx[i]] = vpPoints[i];     // :731
+        return n;
+    }
+
+    // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) — LoopClosing.cc:632.  The reference's body is commented out in full (FeatureMatcher.cc:523-624):
+    // it computes nothing and falls off the end of an int function.  Nothing to run on the GPU; the override leaves vpReplacePoint untouched and returns 0.
+    int Fuse(KeyFrame* /*pKF*/, cv::Mat /*Scw*/, const std::vector<MapPoint*>& /*vpPoints*/, float /*th*/, std::vector<MapPoint*>& /*vpReplacePoint*/) override { return 0; }
+
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — LoopClosing.cc:333 (FeatureMatcher.cc:739-934): both projection directions, then the
+    // agreement check; vpMatches12[i1] = KF2's landmark at the agreed view.
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) override {
+        FrameArrays fa1, fa2; hs_frame_view V1 = gather_frame(*pKF1, fa1), V2 = gather_frame(*pKF2, fa2);
+        const std::vector<MapPoint*> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
+        const int N1 = (int)mp1.size(), N2 = (int)mp2.size();
+        std::vector<bool> done1(N1, false), done2(N2, false);                                                 // vbAlreadyMatched1 / 2 (:768-781)
+        for (int i = 0; i < N1 && i < (int)vpMatches12.size(); i++)
+            if (MapPoint* pMP = vpMatches12[i]) { done1[i] = true; const int idx2 = pMP->GetIndexInKeyFrame(pKF2); if (idx2 >= 0 && idx2 < N2) done2[idx2] = true; }
+        // the landmark of each keypoint, sized in the OTHER key frame (landMarkSizePixels of pKF2 / pKF1, :823,883)
+        std::vector<hs_landmark> L1 = gather_landmarks(mp1, *pKF2, nullptr), L2 = gather_landmarks(mp2, *pKF1, nullptr);
+        for (int i = 0; i < N1; i++) if (mp1[i] && (done1[i] || mp1[i]->isBad())) L1[i].skip = 1;
+        for (int i = 0; i < N2; i++) if (mp2[i] && (done2[i] || mp2[i]->isBad())) L2[i].skip = 1;
+        float R[9], t[3];
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[3 * r + c] = R12.at<float>(r, c); t[r] = t12.at<float>(r); }
+        std::vector<int32_t> m12(std::max(N1, 1), -1); int32_t n = 0;
+        check(hs_search_by_sim3(h, &V1, L1.data(), &V2, L2.data(), s12, R, t, th, TH_HIGH, m12.data(), &n), "SearchBySim3");
+        if ((int)vpMatches12.size() < N1) vpMatches12.resize(N1, static_cast<MapPoint*>(NULL));
+        for (int i = 0; i < N1; i++) if (m12[i] >= 0) vpMatches12[i] = mp2[m12[i]];                            // :925
+        return n;
+    }
+
     hs_orb* handle() const { return h; }
+    HipCallTiming timing;             // of the last SearchByProjection(Frame...) / Fuse / key-frame BoW call (HipORBExtractor.h)
 
 private:
     struct Views { std::vector<hs_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> uR; };
@@ -195,8 +268,37 @@ private:
         }
         return out;
     }
+    // _SearchByBoW_ between two key frames (FeatureMatcher.cc:281-345): the index criteria apply to BOTH sides (:306-309).
+    // keep_matched = PreviouslyMatchedIndexCriterion's flag (MatchCriteria.cpp:554-574); only_stereo adds StereoIndexCriterion (:577-595: a mono key
+    // frame passes everything, otherwise uR >= 0).  m12[i] = KF2 view matched to KF1 view i, or -1.
+    int bow_between_keyframes(KeyFrame* pKF1, KeyFrame* pKF2, bool keep_matched, bool only_stereo, const float* F12, float ratio, std::vector<int32_t>& m12, const char* what) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const FeatureViews& v1 = pKF1->getViews(); const FeatureViews& v2 = pKF2->getViews();
+        Views a = gather_views(v1), b = gather_views(v2);
+        Csr f1 = gather_featvec(pKF1->mFeatVec), f2 = gather_featvec(pKF2->mFeatVec);
+        auto index_mask = [&](KeyFrame* pKF, const Views& v) {
+            std::vector<uint8_t> has(std::max<size_t>(v.kps.size(), 1), 0), keep(has.size(), 0);
+            for (const auto& kv : pKF->getLandMarkMatches())
+                if (kv.second && !kv.second->isBad() && kv.first >= 0 && kv.first < (int)v.kps.size()) has[kv.first] = 1;
+            const bool stereo_gate = only_stereo && pKF->getCamera().sensor != 0;
+            for (size_t i = 0; i < v.kps.size(); i++) keep[i] = (has[i] != 0) == keep_matched && (!stereo_gate || v.uR[i] >= 0);
+            return keep;
+        };
+        std::vector<uint8_t> keep1 = index_mask(pKF1, a), keep2 = index_mask(pKF2, b);
+        const FeatureExtractorSettings orb2 = v2.orbParams();
+        m12.assign(std::max<size_t>(a.kps.size(), 1), -1); int32_t n = 0;
+        timing.gather_ms = hip_detail::ms_since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
+        check(hs_search_by_bow_ex(h, a.kps.data(), a.desc.data(), (int)a.kps.size(), f1.id.data(), f1.ptr.data(), f1.idx.data(), (int)f1.ptr.size() - 1,
+                                  b.kps.data(), b.desc.data(), (int)b.kps.size(), f2.id.data(), f2.ptr.data(), f2.idx.data(), (int)f2.ptr.size() - 1,
+                                  keep1.data(), keep2.data(), F12, orb2.size_ref, orb2.sigma_ref, TH_LOW, ratio, 1, m12.data(), &n), what);
+        timing.abi_ms = hip_detail::ms_since(t1); timing.scatter_ms = 0;
+        m12.resize(a.kps.size());
+        return n;
+    }
     int project_and_associate(Frame& F, const std::vector<MapPoint*>& landmarks, const Frame* prev, const hs_proj_params& pp) {
         // address order == iteration order of the reference's std::map<MapPoint*, SingleMatchData> (FeatureMatcher.cc:64); duplicates collapse like map keys
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<MapPoint*> lms;
         lms.reserve(landmarks.size());
         for (MapPoint* p : landmarks) if (p) lms.push_back(p);
@@ -206,9 +308,14 @@ private:
         FrameArrays fa; hs_frame_view V = gather_frame(F, fa);
         std::vector<hs_landmark> L = gather_landmarks(lms, F, prev);
         std::vector<int32_t> midx(lms.size(), -1); std::vector<float> mdist(lms.size(), -1.f); int32_t n = 0;
+        timing.gather_ms = hip_detail::ms_since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
         check(hs_search_by_projection(h, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n), "SearchByProjection");
+        timing.abi_ms = hip_detail::ms_since(t1);
+        const auto t2 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < lms.size(); i++)          // replay, FeatureMatcher.cc:113-118
             if (midx[i] >= 0) F.associateLandMark(midx[i], lms[i], true);
+        timing.scatter_ms = hip_detail::ms_since(t2);
         return n;
     }
 

@@ -16,13 +16,37 @@
 #else
 #include "cv_compat.h"
 #endif
-#include <mutex>
+#include <atomic>
+#include <chrono>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
 #include "../../include/hyslam_amd.h"
 
 namespace HYSLAM {
+
+// Wall-clock split of the last call of an adaptor: gather = hySLAM objects -> flat arrays, abi = the C-ABI call (H2D + kernels + D2H),
+// scatter = flat results -> hySLAM objects.  Three clock reads per call; read by tests/cpp/bench_adaptor.cpp.
+struct HipCallTiming { double gather_ms = 0, abi_ms = 0, scatter_ms = 0; };
+namespace hip_detail {
+inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+// One matcher / stereo-matcher handle per (calling thread, device), created on first use and destroyed when the thread exits.  These handles are
+// created with default parameters and only lend a stream and scratch memory, so the device is the whole key: two factories on two devices used from
+// one thread get two handles, two threads never share one (a handle is thread-compatible, include/hyslam_amd.h).
+inline hs_orb* thread_handle(int device, const char* who) {
+    struct Owner { std::map<int, hs_orb*> by_device; ~Owner() { for (auto& kv : by_device) if (kv.second) hs_orb_destroy(kv.second); } };
+    static thread_local Owner o;
+    auto it = o.by_device.find(device);
+    if (it != o.by_device.end()) return it->second;
+    hs_orb_params p; hs_orb_default_params(&p);
+    hs_orb* h = nullptr;
+    const int st = hs_orb_create(&p, device, &h);
+    if (st != HS_OK) throw std::runtime_error(std::string(who) + ": " + hs_status_string(st));
+    o.by_device[device] = h;
+    return h;
+}
+}  // namespace hip_detail
 
 // ORBDistance (DescriptorDistance.cpp:9-25) kept on the host for the callers that still ask per-pair distances.
 class HipORBDistance : public DescriptorDistance {
@@ -63,8 +87,11 @@ public:
         if (image.empty()) return;
         if (image.type() != CV_8UC1) throw std::runtime_error("HipORBExtractor: image must be CV_8UC1");
         int32_t n = 0;
+        const auto t0 = std::chrono::steady_clock::now();
         int st = hs_orb_extract(h, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(), cap, &n);
         if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        timing.gather_ms = 0; timing.abi_ms = hip_detail::ms_since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
         _keypoints.clear();
         _keypoints.reserve(n);
         descriptors.reserve(descriptors.size() + n);
@@ -75,6 +102,7 @@ public:
             _keypoints.push_back(k);
             descriptors.push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + (size_t)i * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
         }
+        timing.scatter_ms = hip_detail::ms_since(t1);
     }
     int GetLevels() override { return hs_orb_get_levels(h); }
     float GetScaleFactor() override { return hs_orb_get_scale_factor(h); }
@@ -83,6 +111,7 @@ public:
     std::vector<float> GetScaleSigmaSquares() override { return table(2); }
     std::vector<float> GetInverseScaleSigmaSquares() override { return table(3); }
     hs_orb* handle() { return h; }
+    HipCallTiming timing;             // of the last operator() call
 
 private:
     std::vector<float> table(int which) {
@@ -100,49 +129,44 @@ private:
 
 // Stereomatcher (src/features/Stereomatcher.h:25-51): the reference's constructor (FeatureViews, Camera, FeatureMatcherSettings),
 // computeStereoMatches(), getData(...) — src/main/ImageProcessing.cpp:100-103 compiles unchanged against it.
-// The reference constructor carries no device handle, so the matcher runs on a process-wide handle created on first use (device 0 or
-// HipStereomatcher::setDefaultDevice); calls are serialised by a mutex (a handle is thread-compatible, and ImageProcessing calls from one thread).
+// The reference constructor carries no device handle, so the matcher runs on a handle of the CALLING THREAD (created on first use on device 0 or
+// HipStereomatcher::setDefaultDevice, destroyed with the thread): stereo matchers of different cameras / threads never wait for each other.
 class HipStereomatcher {
 public:
     HipStereomatcher(FeatureViews views, Camera cam_data, FeatureMatcherSettings settings) : h(nullptr) {
         // what Stereomatcher::Stereomatcher reads (src/features/Stereomatcher.cpp:7-24)
+        const auto t0 = std::chrono::steady_clock::now();
         const FeatureExtractorSettings orb_params = views.orbParams();
         sp.fx = cam_data.fx(); sp.mbf = cam_data.mbf; sp.n_rows = (int)cam_data.mnMaxY;
         sp.th_high = settings.TH_HIGH; sp.th_low = settings.TH_LOW; sp.size_ref = orb_params.size_ref;
         gather(views.getKeys(), views.getDescriptors(), kL, dL); gather(views.getKeysR(), views.getDescriptorsR(), kR, dR);
+        timing.gather_ms = hip_detail::ms_since(t0);
     }
     // explicit-handle form (tests, callers that own an extractor on another device)
     HipStereomatcher(hs_orb* handle, const std::vector<cv::KeyPoint>& keys, const std::vector<cv::KeyPoint>& keysR,
                      const std::vector<FeatureDescriptor>& descs, const std::vector<FeatureDescriptor>& descsR,
                      float fx, float mbf, float mnMaxY, FeatureMatcherSettings settings, float size_ref = 31.f)
         : h(handle) {
+        const auto t0 = std::chrono::steady_clock::now();
         sp.fx = fx; sp.mbf = mbf; sp.n_rows = (int)mnMaxY; sp.th_high = settings.TH_HIGH; sp.th_low = settings.TH_LOW; sp.size_ref = size_ref;
         gather(keys, descs, kL, dL); gather(keysR, descsR, kR, dR);
+        timing.gather_ms = hip_detail::ms_since(t0);
     }
     void computeStereoMatches() {
+        const auto t0 = std::chrono::steady_clock::now();
         mvuRight.assign(kL.size(), -1.0f); mvDepth.assign(kL.size(), -1.0f);
-        std::unique_lock<std::mutex> lock(shared_mutex(), std::defer_lock);
-        hs_orb* use = h;
-        if (!use) { lock.lock(); use = shared_handle(); }
+        hs_orb* use = h ? h : hip_detail::thread_handle(default_device().load(), "HipStereomatcher");
         int st = hs_stereo_match(use, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
         if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
+        timing.abi_ms = hip_detail::ms_since(t0);
     }
     void getData(std::vector<float>& mvuRight_, std::vector<float>& mvDepth_) { mvuRight_ = mvuRight; mvDepth_ = mvDepth; }
     void getData(FeatureViews& views) { views.setuRs(mvuRight); views.setDepths(mvDepth); }       // Stereomatcher.cpp:31-34
-    static void setDefaultDevice(int device) { default_device() = device; }
+    static void setDefaultDevice(int device) { default_device().store(device); }
+    HipCallTiming timing;             // gather = constructor, abi = computeStereoMatches
 
 private:
-    static int& default_device() { static int d = 0; return d; }
-    static std::mutex& shared_mutex() { static std::mutex m; return m; }
-    static hs_orb* shared_handle() {                     // caller holds shared_mutex()
-        static hs_orb* hh = nullptr;
-        if (!hh) {
-            hs_orb_params p; hs_orb_default_params(&p);
-            int st = hs_orb_create(&p, default_device(), &hh);
-            if (st != HS_OK) { hh = nullptr; throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st)); }
-        }
-        return hh;
-    }
+    static std::atomic<int>& default_device() { static std::atomic<int> d{ 0 }; return d; }
     static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) {
         ok.resize(k.size()); od.resize(k.size() * HS_DESC_BYTES);
         for (size_t i = 0; i < k.size(); i++) {

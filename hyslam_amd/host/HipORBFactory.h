@@ -61,22 +61,14 @@ public:
     FeatureExtractorSettings getFeatureExtractorSettings() override { return extractor_settings; }
 
     // Every call site builds a short-lived matcher through this function (TrackLocalMap.cpp:72-75, TrackMotionModel.cpp:24, ...).  Matchers
-    // created on different threads must not share a handle: each call gets a handle of its own thread (created once per thread).
+    // created on different threads must not share a handle, and a factory must hand out handles of ITS device: the handle is looked up per
+    // (calling thread, device) — hip_detail::thread_handle in HipORBExtractor.h.
     std::unique_ptr<FeatureMatcher> getFeatureMatcher() override {
-        return std::make_unique<HipFeatureMatcher>(matcher_settings, thread_handle());
+        return std::make_unique<HipFeatureMatcher>(matcher_settings, hip_detail::thread_handle(device, "HipORBFactory"));
     }
+    int deviceIndex() const { return device; }
 
 private:
-    hs_orb* thread_handle() {
-        struct Owner { hs_orb* h = nullptr; ~Owner() { if (h) hs_orb_destroy(h); } };
-        static thread_local Owner o;
-        if (!o.h) {
-            hs_orb_params p; hs_orb_default_params(&p);
-            int st = hs_orb_create(&p, device, &o.h);
-            if (st != HS_OK) { o.h = nullptr; throw std::runtime_error(std::string("HipORBFactory: ") + hs_status_string(st)); }
-        }
-        return o.h;
-    }
     void LoadSettings(const std::string& path, const std::string& type) {
 #ifdef HYSLAM_AMD_WITH_HYSLAM
         if (!path.empty()) {                                   // ORBFactory::LoadSettings, ORBFactory.cpp:55-85

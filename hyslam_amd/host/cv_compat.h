@@ -148,11 +148,13 @@ public:
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }      // MapPoint.cc:145-149
     bool isBad() { return mbBad; }
     bool Protected() { return n_protected > 0; }
-    bool IsInKeyFrame(KeyFrame* pKF) { return in_keyframes.count(pKF) > 0; }
+    bool IsInKeyFrame(KeyFrame* pKF) { return in_keyframes.count(pKF) > 0 || mObservations.count(pKF) > 0; }
+    int GetIndexInKeyFrame(KeyFrame* pKF) { auto it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }      // MapPoint.cc:124-131
     // test set-up (the reference fills these through Map / MapPointDB)
     cv::Mat mWorldPos = cv::Mat(3, 1, CV_32F), mNormalVector = cv::Mat(3, 1, CV_32F);
     FeatureDescriptor mDescriptor; int nObs = 0; float size = 0, mfMinDistance = 0, mfMaxDistance = 0; bool mbBad = false; int n_protected = 0;
     std::set<KeyFrame*> in_keyframes;
+    std::map<KeyFrame*, size_t> mObservations;
 };
 
 // src/core/LandMarkMatches.h:27-66 — same observable behaviour as src/core/LandMarkMatches.cpp:6-51 (own wording)
@@ -224,9 +226,13 @@ public:
     }
     cv::Mat GetPose() { return Tcw.clone(); }
     cv::Mat GetCameraCenter() { return Ow.clone(); }
+    cv::Mat GetRotation() { cv::Mat R(3, 3, CV_32F); for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.at<float>(r, c) = Tcw.at<float>(r, c); return R; }      // KeyFrame.cc:126-130
+    cv::Mat GetTranslation() { cv::Mat t(3, 1, CV_32F); for (int r = 0; r < 3; r++) t.at<float>(r) = Tcw.at<float>(r, 3); return t; }                                  // KeyFrame.cc:132-136
     MapPoint* hasAssociation(int i) const { return matches.hasAssociation(i); }
     int hasAssociation(MapPoint* pMP) const { return matches.hasAssociation(pMP); }
     int associateLandMark(int i, MapPoint* pMP, bool replace) { return matches.associateLandMark(i, pMP, replace); }
+    std::vector<MapPoint*> GetMapPointMatches() { std::vector<MapPoint*> v; const int N = views.numViews(); v.reserve(N); for (int i = 0; i < N; ++i) v.push_back(matches.hasAssociation(i)); return v; }   // KeyFrame.cc:580-593
+    bool IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }                                             // KeyFrame.cc:371-374
     const Camera& getCamera() const { return camera; }
     const FeatureViews& getViews() const { return views; }
     const LandMarkMatches& getLandMarkMatches() { return matches; }
@@ -251,6 +257,12 @@ public:
     virtual int SearchByBoW(KeyFrame* pKF, Frame& F, std::map<size_t, MapPoint*>& matches) { (void)pKF; (void)F; (void)matches; return -1; }
     virtual int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) { (void)F1; (void)F2; (void)vbPrevMatched; (void)vnMatches12; (void)windowSize; return -1; }
     virtual int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, std::map<std::size_t, MapPoint*>& fuse_matches, const float th = 3.0, const float reprojection_err = 5.99) { (void)pKF; (void)vpMapPoints; (void)fuse_matches; (void)th; (void)reprojection_err; return -1; }
+    virtual int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) { (void)pKF; (void)Scw; (void)vpPoints; (void)vpMatched; (void)th; return -1; }
+    virtual int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) { (void)pKF1; (void)pKF2; (void)vpMatches12; return -1; }
+    virtual int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) { (void)pKF1; (void)pKF2; (void)vpMatches12; return -1; }
+    virtual int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo) { (void)pKF1; (void)pKF2; (void)F12; (void)vMatchedPairs; (void)bOnlyStereo; return -1; }
+    virtual int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) { (void)pKF; (void)Scw; (void)vpPoints; (void)th; (void)vpReplacePoint; return -1; }
+    virtual int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) { (void)pKF1; (void)pKF2; (void)vpMatches12; (void)s12; (void)R12; (void)t12; (void)th; return -1; }
 protected:
     float mfNNratio; bool mbCheckOrientation; float TH_LOW; float TH_HIGH;
 };

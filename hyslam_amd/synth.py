@@ -73,6 +73,20 @@ def synth_image(seed, w, h, n_shapes=None):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def synth_rig(seed, n_cams, w, h, step=None, cams=None):
+    """A rig of `n_cams` cameras looking at one wide scene (BASELINE config 5: "overlapping content between neighbours"): camera i sees the
+    columns [i*step, i*step + w) of a (w + (n_cams-1)*step)-wide panorama (default step = w/4: neighbours share three quarters of their
+    view), each with its own pixel noise.  `cams` selects which cameras to render (default all); returns a list of uint8 h x w frames."""
+    if step is None:
+        step = w // 4
+    pw = w + (n_cams - 1) * step
+    pano = _render(_scene(seed, pw, h, max(40, (pw * h) // 800)), pw, h, False, 0)
+    out = []
+    for i in (range(n_cams) if cams is None else cams):
+        out.append(np.clip(pano[:, i * step:i * step + w] + _noise(seed, 20 + i, h, w), 0, 255).astype(np.uint8))
+    return out
+
+
 def synth_stereo_pair(seed, w, h, n_shapes=None):
     """Rectified stereo pair: the right frame renders the same scene with every shape moved left by
     its own disparity (background: 4 px) and independent noise."""

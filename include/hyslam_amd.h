@@ -82,6 +82,7 @@ const char* hs_orb_last_error(const hs_orb* h);
 /* GetLevels / GetScaleFactor(s) / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares,
  * FeatureExtractor.h:31-36.  Any output pointer may be NULL; arrays hold nlevels entries. */
 int  hs_orb_get_levels(const hs_orb* h);
+int  hs_orb_get_device(const hs_orb* h);          /* the device index given to hs_orb_create (-1 for a NULL handle) */
 float hs_orb_get_scale_factor(const hs_orb* h);
 int  hs_orb_get_scale_tables(const hs_orb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                              int32_t* features_per_level);
@@ -293,7 +294,9 @@ int  hs_bow_transform_device(hs_orb* h, const hs_vocab_dev* v, const uint8_t* d_
  * _SearchByBoW_ (FeatureMatcher.cc:216-345: per shared vocabulary node, best / second-best Hamming of every side-1 feature over the node's side-2
  * features, `d < score_threshold && d < ratio * d2`, then RotationConsistencyBoW) between record `rank` (side 1) and record p (side 2), with the
  * vocabulary transform of all records done on the device.  d_match12 [world][cap] = side-2 index or -1 (row `rank`: all -1), d_n_matches [world].
- * No host synchronisation.  Asynchronous. */
+ * No host synchronisation.  Asynchronous.  The matcher's scratch (feature groups, bucket lists) lives INSIDE `v`: one hs_vocab_dev serves one
+ * caller stream at a time and is not thread-safe for this entry point (hs_bow_transform_device only reads `v` and may run concurrently); give
+ * every handle / stream that matches concurrently its own hs_vocab_upload. */
 int  hs_records_bow_match_device(hs_orb* h, hs_vocab_dev* v, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,
                                  float score_threshold, float second_best_ratio, int check_rotation,
                                  int32_t* d_match12, int32_t* d_n_matches, void* stream);
@@ -321,6 +324,23 @@ void   hs_record_offsets(int cap, size_t* off_count, size_t* off_kps, size_t* of
  * the query count are left untouched.  One launch.  Asynchronous. */
 int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,
                             int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
+
+/* ---- the exchange itself in C: an RCCL all-gather of the frame records (north_star: "RCCL all-gather over xGMI of per-frame keypoints /
+ * descriptors"; hs_comm.hip).  hs_comm_get_unique_id on ONE rank; the caller carries the 128 bytes to the other ranks over its own channel
+ * (file, socket, MPI, ...); every rank then calls hs_comm_create(handle of its GPU, id, world, rank), which blocks until all ranks arrived
+ * (ncclCommInitRank).  One process per GPU.  hs_comm_allgather_records enqueues ncclAllGather of `record_bytes` bytes per rank on `stream`
+ * (NULL = the handle's stream): d_gathered [world][record_bytes]; in place when d_record == d_gathered + rank * record_bytes.  With the
+ * extraction before it and the matcher after it on the same stream a config-5 step needs no event and no host synchronisation.
+ * librccl is loaded on first use (dlopen): HS_ERR_NO_DEVICE when it or a GPU is missing.  Asynchronous. */
+#define HS_COMM_ID_BYTES 128
+typedef struct hs_comm hs_comm;
+int  hs_comm_get_unique_id(uint8_t* id /* [HS_COMM_ID_BYTES] */);
+int  hs_comm_create(hs_orb* h, const uint8_t* id, int world, int rank, hs_comm** out);
+void hs_comm_destroy(hs_comm* c);
+int  hs_comm_world(const hs_comm* c);
+int  hs_comm_rank(const hs_comm* c);
+const char* hs_comm_last_error(const hs_comm* c);
+int  hs_comm_allgather_records(hs_comm* c, const void* d_record, void* d_gathered, size_t record_bytes, void* stream);
 
 /* ---- per-stage device timing (HIP events recorded on the stream the kernels run on) ----
  * Stages: 0 pyramid, 1 FAST+NMS cells, 2 quadtree distribution, 3 blur+orient+rBRIEF, 4 stereo match, 5 stereo median.

@@ -10,9 +10,11 @@
 // associateLandMark in address order on a copy of the frame's LandMarkMatches.
 // usage: test_matcher_adaptor scene.bin          prints "MATCHER ADAPTOR OK ..." on success, "NO DEVICE" without a GPU
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 #include <vector>
 #include "../../hyslam_amd/host/HipORBFactory.h"
 #include "../../oracle/hs_oracle.h"
@@ -106,6 +108,16 @@ int main(int argc, char** argv)
     if (exS->GetLevels() != 8 || exI->GetScaleFactor() != 1.4f || factory->getFeatureExtractorSettings().nFeatures != 3000) FAIL(5, "factory settings");
     std::unique_ptr<FeatureMatcher> matcher = factory->getFeatureMatcher();
     if (!dynamic_cast<HipFeatureMatcher*>(matcher.get())) FAIL(6, "getFeatureMatcher() did not dispatch to the HIP matcher");
+    {   // matcher handles are per (calling thread, device): the same handle again on this thread, the factory's device, another handle on another thread
+        hs_orb* mine = static_cast<HipFeatureMatcher*>(matcher.get())->handle();
+        if (hs_orb_get_device(mine) != 0 || static_cast<HipFeatureMatcher*>(factory->getFeatureMatcher().get())->handle() != mine) FAIL(8, "matcher handle is not the calling thread's handle on the factory's device");
+        std::unique_ptr<FeatureFactory> other = std::make_unique<HipORBFactory>(per_type, ms, 0);
+        if (static_cast<HipFeatureMatcher*>(other->getFeatureMatcher().get())->handle() != mine) FAIL(8, "a second factory on the same device must reuse the thread's handle");
+        hs_orb* theirs = nullptr;
+        std::thread t([&] { theirs = static_cast<HipFeatureMatcher*>(factory->getFeatureMatcher().get())->handle(); });
+        t.join();
+        if (!theirs || theirs == mine) FAIL(9, "two threads share one matcher handle");
+    }
 
     // ---- the scene as hySLAM objects; MapPoints allocated in shuffled order
     std::shared_ptr<DescriptorDistance> dist = factory->getDistanceFunc();
@@ -260,6 +272,204 @@ int main(int argc, char** argv)
         hso_stereo_match(s.kps.data(), s.desc.data(), s.n_kp, kR.data(), s.desc.data(), s.n_kp, &sp, ou.data(), od.data(), nullptr, nullptr);
         for (int i = 0; i < s.n_kp; i++) if (uR[i] != ou[i] || depth[i] != od[i] || views.uR(i) != ou[i] || views.depth(i) != od[i]) FAIL(16, "stereo %d differs", i);
     }
-    printf("MATCHER ADAPTOR OK %d keypoints, %d landmarks, %d matches over 4 searches\n", s.n_kp, s.n_lm, total_matches);
+    // ================= the key-frame entry points (LandMarkTriangulator.cpp:81, LoopClosing.cc:275,333,389) =================
+    // Two key frames that see the same landmarks: every keypoint of KF1 owns a landmark back-projected with KF1's pose at a seeded depth;
+    // KF2 = the same keypoints in permuted order with sub-pixel jitter, posed so that x_c1 = s12 R12 x_c2 + t12.
+    {
+        const int n = s.n_kp;
+        const float fx = s.pose[12], fy = s.pose[13], cx = s.pose[14], cy = s.pose[15];
+        std::mt19937 r2(777);
+        auto unif = [&](double a, double b) { return a + (b - a) * (double)(r2() & 0xFFFFFF) / (double)0x1000000; };
+        const double R1[9] = { s.pose[0], s.pose[1], s.pose[2], s.pose[3], s.pose[4], s.pose[5], s.pose[6], s.pose[7], s.pose[8] };
+        const double t1[3] = { s.pose[9], s.pose[10], s.pose[11] };
+        std::vector<hso_landmark> own1(n);                                   // landmark of KF1's keypoint i (flat record, invariance range in min/max_dist)
+        std::vector<MapPoint*> mp1(n, nullptr);
+        for (int i = 0; i < n; i++) {
+            const double d = unif(3.0, 20.0);
+            const double pc[3] = { (s.kps[i].x - cx) * d / fx - t1[0], (s.kps[i].y - cy) * d / fy - t1[1], d - t1[2] };
+            double pw[3], ow[3];
+            for (int k = 0; k < 3; k++) { pw[k] = R1[k] * pc[0] + R1[3 + k] * pc[1] + R1[6 + k] * pc[2]; ow[k] = -(R1[k] * t1[0] + R1[3 + k] * t1[1] + R1[6 + k] * t1[2]); }
+            const double dist = std::sqrt((pw[0] - ow[0]) * (pw[0] - ow[0]) + (pw[1] - ow[1]) * (pw[1] - ow[1]) + (pw[2] - ow[2]) * (pw[2] - ow[2]));
+            hso_landmark& L = own1[i]; std::memset(&L, 0, sizeof(L));
+            for (int k = 0; k < 3; k++) { L.pos[k] = (float)pw[k]; L.normal[k] = (float)((pw[k] - ow[k]) / dist); }
+            L.size = (float)(s.kps[i].size * d / fx);
+            L.min_dist = (float)(dist * unif(0.4, 1.15)); L.max_dist = (float)(dist * unif(0.9, 2.5));      // mfMin/MaxDistance: some fall outside 0.8 / 1.2
+            std::memcpy(L.desc, &s.desc[(size_t)i * 32], 32);
+            L.assoc_kp = -1;
+        }
+        std::vector<int> alloc_order(n); for (int i = 0; i < n; i++) alloc_order[i] = i;
+        std::shuffle(alloc_order.begin(), alloc_order.end(), r2);
+        for (int i : alloc_order) {
+            MapPoint* m = new MapPoint();
+            for (int k = 0; k < 3; k++) { m->mWorldPos.at<float>(k) = own1[i].pos[k]; m->mNormalVector.at<float>(k) = own1[i].normal[k]; }
+            m->size = own1[i].size; m->mfMinDistance = own1[i].min_dist; m->mfMaxDistance = own1[i].max_dist;
+            m->mDescriptor = FeatureDescriptor(cv::Mat(1, 32, CV_8UC1, own1[i].desc, 32), dist); m->nObs = 2;
+            mp1[i] = m;
+        }
+        auto flat_of = [&](MapPoint* m) {                                    // independent gather of one MapPoint (what gather_landmarks must arrive at)
+            hso_landmark L; std::memset(&L, 0, sizeof(L)); L.assoc_kp = -1;
+            if (!m) { L.skip = 1; return L; }
+            for (int k = 0; k < 3; k++) { L.pos[k] = m->mWorldPos.at<float>(k); L.normal[k] = m->mNormalVector.at<float>(k); }
+            L.size = m->size; L.min_dist = 0.8f * m->mfMinDistance; L.max_dist = 1.2f * m->mfMaxDistance;
+            std::memcpy(L.desc, m->mDescriptor.rawDescriptor().ptr(0), 32);
+            return L;
+        };
+        // KF2
+        std::vector<int> perm(n); for (int i = 0; i < n; i++) perm[i] = i;
+        std::shuffle(perm.begin(), perm.end(), r2);
+        std::vector<hso_keypoint> k2(n); std::vector<uint8_t> d2((size_t)n * 32); std::vector<float> u2(n);
+        for (int i = 0; i < n; i++) {
+            k2[i] = s.kps[perm[i]]; k2[i].x += (float)unif(-0.9, 0.9); k2[i].y += (float)unif(-0.9, 0.9);
+            std::memcpy(&d2[(size_t)i * 32], &s.desc[(size_t)perm[i] * 32], 32);
+            if (i % 3 == 0) d2[(size_t)i * 32 + 11] ^= 0x18;
+            u2[i] = (i % 4 == 1) ? -1.f : s.uR[perm[i]];
+        }
+        const float s12 = 1.0f / 1.1f;
+        const double ax = 0.001, ay = 0.002, az = -0.001;
+        const double cxr = std::cos(ax), sxr = std::sin(ax), cyr = std::cos(ay), syr = std::sin(ay), czr = std::cos(az), szr = std::sin(az);
+        const double Rm[9] = { czr * cyr, czr * syr * sxr - szr * cxr, czr * syr * cxr + szr * sxr, szr * cyr, szr * syr * sxr + czr * cxr, szr * syr * cxr - czr * sxr, -syr, cyr * sxr, cyr * cxr };
+        cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+        for (int i = 0; i < 9; i++) R12.at<float>(i / 3, i % 3) = (float)Rm[i];
+        t12.at<float>(0) = 0.02f; t12.at<float>(1) = -0.01f; t12.at<float>(2) = 0.03f;
+        cv::Mat T2(4, 4, CV_32F);                                             // T2w = (1/s12) R12^T (T1w - t12)
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += (double)R12.at<float>(k, r) * R1[3 * k + c]; T2.at<float>(r, c) = (float)a; }
+            double a = 0; for (int k = 0; k < 3; k++) a += (double)R12.at<float>(k, r) * (t1[k] - (double)t12.at<float>(k));
+            T2.at<float>(r, 3) = (float)(a / s12);
+        }
+        T2.at<float>(3, 0) = T2.at<float>(3, 1) = T2.at<float>(3, 2) = 0.f; T2.at<float>(3, 3) = 1.f;
+        Scene s2 = s; s2.kps = k2; s2.desc = d2; s2.uR = u2;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) s2.pose[3 * r + c] = T2.at<float>(r, c); s2.pose[9 + r] = T2.at<float>(r, 3); }
+
+        auto fresh_keyframes = [&](KeyFrame& K1, KeyFrame& K2) {
+            K1 = KeyFrame(make_views(s.kps, s.desc, s.uR, dist), cam); K1.SetPose(Tcw);
+            K2 = KeyFrame(make_views(k2, d2, u2, dist), cam); K2.SetPose(T2);
+        };
+        auto csr = [](const DBoW2::FeatureVector& fv, std::vector<int32_t>& id, std::vector<int32_t>& ptr, std::vector<int32_t>& idx) {
+            ptr.push_back(0);
+            for (const auto& kv : fv) { id.push_back((int32_t)kv.first); for (unsigned i : kv.second) idx.push_back((int32_t)i); ptr.push_back((int32_t)idx.size()); }
+        };
+        auto node_of = [](const uint8_t* d) { return 5u + 11u * ((d[1] ^ (d[20] << 2)) % 97u); };
+
+        // ---- SearchByProjection(pKF, Scw, vpPoints, vpMatched, th): LoopClosing.cc:389
+        {
+            KeyFrame K1, K2; fresh_keyframes(K1, K2);
+            for (int i = 0; i < n; i += 7) K1.associateLandMark(i, mp1[i], true);                  // landMarkSizePixels then uses the keypoint's size
+            cv::Mat Scw(4, 4, CV_32F);
+            const float sc = 1.07f, dt[3] = { 0.01f, -0.02f, 0.015f };
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Scw.at<float>(r, c) = sc * Tcw.at<float>(r, c); Scw.at<float>(r, 3) = sc * (Tcw.at<float>(r, 3) + dt[r]); }
+            Scw.at<float>(3, 0) = Scw.at<float>(3, 1) = Scw.at<float>(3, 2) = 0.f; Scw.at<float>(3, 3) = 1.f;
+            std::vector<MapPoint*> pts = mp1;
+            for (int i = 0; i < n; i += 2) pts.push_back(mp1[i]);                                   // duplicates: the second copy must lose its keypoint
+            std::shuffle(pts.begin(), pts.end(), r2);
+            for (int i = 3; i < n; i += 19) mp1[i]->mbBad = true;
+            std::vector<MapPoint*> matched(n, nullptr);
+            for (int i = 0; i < n; i += 10) matched[i] = (i % 20 == 0) ? mp1[(i + 1) % n] : new MapPoint();      // pre-matched views; half of them hold candidates (spAlreadyFound)
+            std::set<MapPoint*> found(matched.begin(), matched.end()); found.erase(nullptr);
+            std::vector<int32_t> obs; hso_frame_view V = view_of(K1, s, Tcw, obs);
+            std::vector<hso_landmark> L(pts.size());
+            for (size_t i = 0; i < pts.size(); i++) { L[i] = flat_of(pts[i]); L[i].assoc_kp = K1.hasAssociation(pts[i]); L[i].skip = pts[i]->isBad() || found.count(pts[i]); }
+            std::vector<uint8_t> taken(n); for (int i = 0; i < n; i++) taken[i] = matched[i] != nullptr;
+            std::vector<int32_t> mi(pts.size());
+            float S[16]; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S[4 * r + c] = Scw.at<float>(r, c);
+            const int n_want = hso_search_by_projection_sim3(&V, S, L.data(), (int)L.size(), 4, 50.f, taken.data(), mi.data());
+            std::vector<MapPoint*> want = matched;
+            for (size_t i = 0; i < pts.size(); i++) if (mi[i] >= 0) want[mi[i]] = pts[i];
+            const int n_got = matcher->SearchByProjection(&K1, Scw, pts, matched, 4);
+            if (n_got != n_want || n_want < 100) FAIL(20, "SearchByProjection(Scw): %d matches, expected %d", n_got, n_want);
+            if (matched != want) FAIL(21, "SearchByProjection(Scw): vpMatched differs");
+            for (int i = 0; i < n; i++) mp1[i]->mbBad = false;
+            total_matches += n_got;
+        }
+        // ---- SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): LoopClosing.cc:333
+        {
+            KeyFrame K1, K2; fresh_keyframes(K1, K2);
+            for (int i = 0; i < n; i++) if (i % 12 != 5) K1.associateLandMark(i, mp1[i], true);     // a twelfth of KF1's keypoints own no landmark
+            for (int i = 0; i < n; i++) if (i % 10 != 3) K2.associateLandMark(i, mp1[perm[i]], true);
+            for (int i = 6; i < n; i += 23) mp1[i]->mbBad = true;
+            std::vector<MapPoint*> m12(n, nullptr);
+            for (int i = 0; i < n; i += 15) if (K1.hasAssociation(i)) {                              // already matched pairs (vbAlreadyMatched1 / 2)
+                m12[i] = K1.hasAssociation(i);
+                const int i2 = K2.hasAssociation(m12[i]);
+                if (i2 >= 0) m12[i]->mObservations[&K2] = (size_t)i2;
+            }
+            const std::vector<MapPoint*> v1 = K1.GetMapPointMatches(), v2 = K2.GetMapPointMatches();
+            std::vector<uint8_t> a1(n, 0), a2(n, 0);
+            for (int i = 0; i < n; i++) if (m12[i]) { a1[i] = 1; const int i2 = m12[i]->GetIndexInKeyFrame(&K2); if (i2 >= 0 && i2 < n) a2[i2] = 1; }
+            std::vector<int32_t> o1, o2; hso_frame_view V1 = view_of(K1, s, Tcw, o1), V2 = view_of(K2, s2, T2, o2);
+            std::vector<hso_landmark> L1(n), L2(n);
+            for (int i = 0; i < n; i++) {
+                L1[i] = flat_of(v1[i]); if (v1[i]) { L1[i].assoc_kp = K2.hasAssociation(v1[i]); L1[i].skip = a1[i] || v1[i]->isBad(); }
+                L2[i] = flat_of(v2[i]); if (v2[i]) { L2[i].assoc_kp = K1.hasAssociation(v2[i]); L2[i].skip = a2[i] || v2[i]->isBad(); }
+            }
+            float Rf[9], tf[3]; for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rf[3 * r + c] = R12.at<float>(r, c); tf[r] = t12.at<float>(r); }
+            std::vector<int32_t> om(n);
+            const int n_want = hso_search_by_sim3(&V1, L1.data(), &V2, L2.data(), s12, Rf, tf, 7.5f, 100.f, om.data());
+            std::vector<MapPoint*> want = m12;
+            for (int i = 0; i < n; i++) if (om[i] >= 0) want[i] = v2[om[i]];
+            const int n_got = matcher->SearchBySim3(&K1, &K2, m12, s12, R12, t12, 7.5f);
+            if (n_got != n_want || n_want < 100) FAIL(22, "SearchBySim3: %d found, expected %d", n_got, n_want);
+            if (m12 != want) FAIL(23, "SearchBySim3: vpMatches12 differs");
+            for (int i = 0; i < n; i++) { mp1[i]->mbBad = false; mp1[i]->mObservations.clear(); }
+            total_matches += n_got;
+        }
+        // ---- SearchForTriangulation (LandMarkTriangulator.cpp:81) and SearchByBoW2 (LoopClosing.cc:275) on hashed feature vectors
+        for (int variant = 0; variant < 3; variant++) {                       // 0: triangulation, all views; 1: triangulation, bOnlyStereo; 2: SearchByBoW2
+            KeyFrame K1, K2; fresh_keyframes(K1, K2);
+            for (int i = 0; i < n; i++) { K1.mFeatVec[node_of(&s.desc[(size_t)i * 32])].push_back(i); K2.mFeatVec[node_of(&d2[(size_t)i * 32])].push_back(i); }
+            const int gap1 = variant == 2 ? 7 : 2, gap2 = variant == 2 ? 9 : 3;                      // BoW2 wants matched views, triangulation un-matched ones
+            for (int i = 0; i < n; i++) if ((i % gap1 != 0) == (variant == 2)) K1.associateLandMark(i, mp1[i], true);
+            for (int i = 0; i < n; i++) if ((i % gap2 != 0) == (variant == 2)) K2.associateLandMark(i, mp1[perm[i]], true);
+            for (int i = 1; i < n; i += 5) mp1[i]->mbBad = true;                                     // a bad landmark counts as "no landmark" (MatchCriteria.cpp:559-563)
+            const bool only_stereo = variant == 1;
+            auto mask = [&](KeyFrame& K, const std::vector<float>& uR, bool keep_matched) {
+                std::vector<uint8_t> keep(n, 0);
+                for (int i = 0; i < n; i++) {
+                    MapPoint* m = K.hasAssociation(i); const bool has = m && !m->isBad();
+                    keep[i] = has == keep_matched && (!only_stereo || K.getCamera().sensor == 0 || uR[i] >= 0);
+                }
+                return keep;
+            };
+            std::vector<uint8_t> keep1 = mask(K1, s.uR, variant == 2), keep2 = mask(K2, u2, variant == 2);
+            std::vector<int32_t> i1, p1, x1, i2, p2, x2; csr(K1.mFeatVec, i1, p1, x1); csr(K2.mFeatVec, i2, p2, x2);
+            // F12 = K^-T [t12]x R12 K^-1 (GenUtils::ComputeF12): x1' F12 x2 = 0 for x_c1 = s12 R12 x_c2 + t12
+            cv::Mat F12(3, 3, CV_32F);
+            {
+                const double tx[9] = { 0, -t12.at<float>(2), t12.at<float>(1), t12.at<float>(2), 0, -t12.at<float>(0), -t12.at<float>(1), t12.at<float>(0), 0 };
+                double E[9], Ki[9] = { 1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1 }, A[9];
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += tx[3 * r + k] * Rm[3 * k + c]; E[3 * r + c] = a; }
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += Ki[3 * k + r] * E[3 * k + c]; A[3 * r + c] = a; }
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += A[3 * r + k] * Ki[3 * k + c]; F12.at<float>(r, c) = (float)a; }
+            }
+            float Ff[9]; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ff[3 * r + c] = F12.at<float>(r, c);
+            std::vector<int32_t> om(n, -1);
+            const int n_want = hso_search_by_bow_ex(s.kps.data(), s.desc.data(), n, i1.data(), p1.data(), x1.data(), (int)i1.size(),
+                                                    k2.data(), d2.data(), n, i2.data(), p2.data(), x2.data(), (int)i2.size(), keep1.data(), keep2.data(),
+                                                    variant == 2 ? nullptr : Ff, 31.f, 1.f, 50.f, variant == 2 ? 0.8f : 1.0f, 1, om.data());
+            if (variant == 2) {
+                std::vector<MapPoint*> want(n, nullptr), got;
+                for (int i = 0; i < n; i++) if (om[i] >= 0) want[i] = K2.hasAssociation(om[i]);
+                const int n_got = matcher->SearchByBoW2(&K1, &K2, got);
+                if (n_got != n_want || n_want < 20) FAIL(26, "SearchByBoW2: %d matches, expected %d", n_got, n_want);
+                if (got != want) FAIL(27, "SearchByBoW2: vpMatches12 differs");
+                total_matches += n_got;
+            } else {
+                std::vector<std::pair<size_t, size_t>> want, got;
+                for (int i = 0; i < n; i++) if (om[i] >= 0) want.push_back({ (size_t)i, (size_t)om[i] });
+                const int n_got = matcher->SearchForTriangulation(&K1, &K2, F12, got, only_stereo);
+                if (n_got != n_want || n_want < 20) FAIL(24, "SearchForTriangulation(%d): %d matches, expected %d", variant, n_got, n_want);
+                if (got != want) FAIL(25, "SearchForTriangulation(%d): pairs differ", variant);
+                total_matches += n_got;
+            }
+            for (int i = 0; i < n; i++) mp1[i]->mbBad = false;
+        }
+        // ---- Fuse(pKF, Scw, ...): an empty body in the reference (FeatureMatcher.cc:523-624); the override must leave its output alone
+        {
+            KeyFrame K1, K2; fresh_keyframes(K1, K2);
+            std::vector<MapPoint*> repl(3, mp1[0]);
+            if (matcher->Fuse(&K1, Tcw, mp1, 4.f, repl) != 0 || repl != std::vector<MapPoint*>(3, mp1[0])) FAIL(28, "Fuse(Scw) touched its output");
+        }
+    }
+    printf("MATCHER ADAPTOR OK %d keypoints, %d landmarks, %d matches over 9 searches\n", s.n_kp, s.n_lm, total_matches);
     return 0;
 }

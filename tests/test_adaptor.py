@@ -12,12 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
 EXE = os.path.join(BUILD, "test_adaptor")
 EXE_M = os.path.join(BUILD, "test_matcher_adaptor")
+EXE_B = os.path.join(BUILD, "bench_adaptor")
 
 
 def build(src="test_adaptor.cpp", exe=EXE):
     os.makedirs(BUILD, exist_ok=True)
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "cpp", src), "-o", exe,
+    subprocess.check_call(["g++", "-O2" if "bench" in src else "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", os.path.join(ROOT, "tests", "cpp", src), "-o", exe,
                            "-L" + os.path.join(ROOT, "hyslam_amd"), "-lhyslam_amd", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lhs_oracle",
                            "-Wl,-rpath," + os.path.join(ROOT, "hyslam_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_build")])
 
@@ -50,6 +51,15 @@ def run_matcher():
     return subprocess.run([EXE_M, scene], capture_output=True, timeout=600)
 
 
+def run_bench(w=640, h=480, reps=6, n_lm=5000):
+    """tests/cpp/bench_adaptor.cpp: ImageProcessing::ProcessStereoImage + TrackLocalMap + LandMarkTriangulator through the adaptors, timed"""
+    from hyslam_amd.synth import synth_stereo_pair
+    L, R = synth_stereo_pair(2, w, h)
+    fl, fr = os.path.join(BUILD, "bench_L.raw"), os.path.join(BUILD, "bench_R.raw")
+    L.tofile(fl); R.tofile(fr)
+    return subprocess.run([EXE_B, str(w), str(h), fl, fr, str(reps), str(n_lm)], capture_output=True, timeout=900)
+
+
 def test_adaptor_compiles_and_fails_loudly_without_gpu():
     build()
     r = run()
@@ -64,6 +74,27 @@ def test_matcher_adaptor_and_factory_compile_and_fail_loudly_without_gpu():
     assert b"NO DEVICE" in r.stdout or b"MATCHER ADAPTOR OK" in r.stdout
 
 
+def test_bench_adaptor_compiles():
+    build("bench_adaptor.cpp", EXE_B)
+    r = run_bench()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert b"NO DEVICE" in r.stdout or b"ProcessStereoImage_ms" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_adaptor_runs_on_gpu(gpu):
+    """the call-site timing binary runs end to end: stereo front end with two extractor threads + HipStereomatcher,
+    a local-map projection search, a triangulation search — all with matches"""
+    import json
+    build("bench_adaptor.cpp", EXE_B)
+    r = run_bench()
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads(r.stdout.decode())
+    assert j["keypoints"] > 500 and j["stereo_matches"] > 100
+    assert j["TrackLocalMap_SearchByProjection_ms"]["matches"] > 200 and j["SearchForTriangulation_ms"]["matches"] > 100
+    assert j["ProcessStereoImage_ms"]["total"] > 0
+
+
 @pytest.mark.gpu
 def test_adaptor_bit_exact_on_gpu(gpu):
     build()
@@ -74,7 +105,8 @@ def test_adaptor_bit_exact_on_gpu(gpu):
 @pytest.mark.gpu
 def test_matcher_adaptor_replays_associations_in_address_order_on_gpu(gpu):
     """HipORBFactory -> unique_ptr<FeatureMatcher> -> HipFeatureMatcher: gather -> C ABI -> associateLandMark replay (D6: address-sorted
-    landmarks) == oracle + reference-order replay; Fuse, SearchByBoW(KF, Frame) and the reference-signature Stereomatcher as well"""
+    landmarks) == oracle + reference-order replay; Fuse, SearchByBoW(KF, Frame), the reference-signature Stereomatcher, and the key-frame entry
+    points SearchByProjection(pKF, Scw, ...), SearchBySim3, SearchForTriangulation (all views / stereo only), SearchByBoW2 and the empty Fuse(Scw)"""
     build("test_matcher_adaptor.cpp", EXE_M)
     r = run_matcher()
     assert r.returncode == 0 and b"MATCHER ADAPTOR OK" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,95 @@
+"""hs_comm_* — the config-5 exchange in C (an RCCL all-gather of the frame records, include/hyslam_amd.h) — through a C++ program with one
+process per rank and through the Python binding.  CPU-only boxes start the ranks and stop cleanly before ncclCommInitRank."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
+EXE = os.path.join(BUILD, "test_comm")
+
+
+def build():
+    os.makedirs(BUILD, exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_comm.cpp"), "-o", EXE, "-L" + os.path.join(ROOT, "hyslam_amd"), "-lhyslam_amd",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "hyslam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def run_world(world, tag):
+    id_file = os.path.join(BUILD, "comm_id_%s_%d" % (tag, os.getpid()))
+    if os.path.exists(id_file):
+        os.remove(id_file)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([EXE, id_file, str(world), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append((p.communicate(timeout=300)[0].decode(), p.returncode))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            outs.append(("timeout", 1))
+    if os.path.exists(id_file):
+        os.remove(id_file)
+    return outs
+
+
+def test_comm_two_processes_stop_cleanly_without_gpu_or_run():
+    """world 2 as two processes: without a GPU both ranks report NO DEVICE before ncclCommInitRank; with one GPU they report NOT ENOUGH
+    DEVICES (one device per rank); with two or more they gather each other's records"""
+    build()
+    outs = run_world(2, "w2")
+    for text, rc in outs:
+        assert rc == 0, outs
+        assert "NO DEVICE" in text or "NOT ENOUGH DEVICES" in text or "COMM OK" in text, outs
+
+
+def test_comm_binding_rejects_bad_arguments():
+    from hyslam_amd import _native as N
+    lib = N.lib()
+    assert lib.hs_comm_get_unique_id(None) == N.HS_ERR_INVALID
+    c = C.c_void_p()
+    ident = (C.c_uint8 * 128)()
+    assert lib.hs_comm_create(None, ident, 1, 0, C.byref(c)) == N.HS_ERR_INVALID and not c.value
+    assert lib.hs_comm_world(None) == 0 and lib.hs_comm_rank(None) == -1
+    lib.hs_comm_destroy(None)
+
+
+@pytest.mark.gpu
+def test_comm_world1_cpp_on_gpu(gpu):
+    build()
+    outs = run_world(1, "w1")
+    assert outs[0][1] == 0 and "COMM OK rank 0 of 1" in outs[0][0], outs
+
+
+@pytest.mark.gpu
+def test_comm_world1_extract_gather_match_on_one_stream(gpu):
+    """a config-5 step at world 1 through the C path only: extract straight into the record slot, hs_comm all-gather IN PLACE on the handle's
+    stream, 2-NN on the gathered buffer — no event, no host synchronisation in between; the gathered record equals the oracle's extraction"""
+    import hipmem
+    import oracle
+    import hyslam_amd as HS
+    from hyslam_amd import distributed as D
+    from hyslam_amd.synth import synth_image
+    W, H, NF = 640, 480, 1000
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    ex.reserve(W, H, 1)
+    cap = ex.max_keypoints()
+    rb = D.record_bytes(cap)
+    o_n, o_k, o_d = D.record_offsets(cap)
+    xc = D.RecordExchange(ex, D.RecordExchange.unique_id(), 1, 0)
+    img = synth_image(200, W, H)
+    d_f, recs = hipmem.DevBuf.from_numpy(img), hipmem.DevBuf(rb)
+    outs = [hipmem.DevBuf(cap * 4) for _ in range(3)]
+    ex.extract_batch_device(d_f.ptr, 1, W, H, W, W * H, recs.ptr + o_k, recs.ptr + o_d, recs.ptr + o_n, cap, 0)
+    xc.allgather(recs.ptr, recs.ptr, rb, 0)
+    D.records_knn2_device(ex, recs.ptr, rb, 1, 0, cap, outs[0].ptr, outs[1].ptr, outs[2].ptr, 0)
+    ex.synchronize()
+    k, d = D.unpack_record(recs.to_numpy(np.uint8, rb), cap)
+    ok, od = oracle.extract(oracle.default_params(NF), img)
+    assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
+    xc.close()

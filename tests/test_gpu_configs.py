@@ -120,6 +120,76 @@ def test_c5_records_and_cross_camera_knn2_world1(gpu):
     assert bi[1].max() < cap
 
 
+def test_c5_real_shape_8_records_1080p(gpu):
+    """BASELINE config 5 at the shape BASELINE names: 8 cameras x 1920x1080, 2000 features, cap = hs_orb_max_keypoints (2012), neighbouring
+    cameras overlapping (synth_rig).  Every frame is extracted straight into its all-gather record; then, FOR EVERY RANK 0..7, the cross-camera
+    brute-force 2-NN (hs_records_knn2_device) and the vocabulary-grouped BoW match (hs_records_bow_match_device, a synthetic vocabulary of
+    ORBvoc's shape: k = 10, L = 6, feature vectors 4 levels up) against all seven peers == oracle, bit for bit."""
+    from hyslam_amd.synth import synth_rig, synth_vocab_tree
+    W, H, NF, world = 1920, 1080, 2000, 8
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    ex.reserve(W, H, 1)
+    cap = ex.max_keypoints()
+    assert cap == 2012
+    rb = D.record_bytes(cap)
+    o_n, o_k, o_d = D.record_offsets(cap)
+    frames = synth_rig(200, world, W, H)
+    recs = hipmem.DevBuf(world * rb)
+    for i, f in enumerate(frames):
+        d_f = hipmem.DevBuf.from_numpy(f)
+        b = recs.ptr + i * rb
+        ex.extract_batch_device(d_f.ptr, 1, W, H, W, W * H, b + o_k, b + o_d, b + o_n, cap, 0)
+        ex.synchronize()
+    host = recs.to_numpy(np.uint8, world * rb).reshape(world, rb)
+    p = oracle.default_params(NF)
+    feats = []
+    for i, f in enumerate(frames):
+        k, d = D.unpack_record(host[i], cap)
+        ok, od = oracle.extract(p, f)
+        assert k.tobytes() == ok.tobytes() and np.array_equal(d, od), i
+        feats.append((k, d))
+    # ---- brute-force 2-NN, every rank against every peer
+    good = np.zeros((world, world), np.int64)
+    for rank in range(world):
+        outs = [hipmem.DevBuf(world * cap * 4) for _ in range(3)]
+        D.records_knn2_device(ex, recs.ptr, rb, world, rank, cap, outs[0].ptr, outs[1].ptr, outs[2].ptr, 0)
+        ex.synchronize()
+        bi, bd, sd = (o.to_numpy(np.int32, world * cap).reshape(world, cap) for o in outs)
+        nq = len(feats[rank][0])
+        for peer in range(world):
+            if peer == rank:
+                continue
+            obi, obd, osd = oracle.hamming_knn2(feats[rank][1], feats[peer][1])
+            assert np.array_equal(bi[peer, :nq], obi) and np.array_equal(bd[peer, :nq], obd) and np.array_equal(sd[peer, :nq], osd), (rank, peer)
+            good[rank, peer] = int(((obd < 50) & (obd < 0.8 * osd)).sum())
+    assert all(good[r, r + 1] > 200 for r in range(world - 1)), good          # neighbours share three quarters of their view
+    assert good[0, 7] < good[0, 1] // 4                                          # cameras 0 and 7 share nothing
+    # ---- vocabulary-grouped match, every rank against every peer
+    Tg, keep, n_words = synth_vocab_tree(10, 6, 23)
+    To = oracle.VocabTree(Tg.n_nodes, Tg.levels, Tg.child_begin, Tg.child_count, Tg.desc, Tg.word_id, Tg.weight, None)
+    voc = D.DeviceVocabulary(ex, Tg, 4, keep)
+    assert voc.groups == 100
+    fvs = [HS.ORBVocabulary.containers(*oracle.bow_transform(To, feats[i][1], 4))[1] for i in range(world)]
+    total = 0
+    for rank in range(world):
+        d_m, d_nm = hipmem.DevBuf(world * cap * 4), hipmem.DevBuf(world * 4)
+        voc.records_bow_match_device(recs.ptr, rb, world, rank, cap, 50.0, 0.8, True, d_m.ptr, d_nm.ptr, 0)
+        ex.synchronize()
+        gm = d_m.to_numpy(np.int32, world * cap).reshape(world, cap)
+        gn = d_nm.to_numpy(np.int32, world)
+        k1, d1 = feats[rank]
+        for peer in range(world):
+            if peer == rank:
+                assert gn[peer] == 0 and (gm[peer] == -1).all()
+                continue
+            k2, d2 = feats[peer]
+            om, on = oracle.search_by_bow(k1, d1, fvs[rank], k2, d2, fvs[peer], None, 50.0, 0.8, True)
+            assert gn[peer] == on and np.array_equal(gm[peer, :len(k1)], om), (rank, peer)
+            total += on
+    assert total > 1000
+    voc.close()
+
+
 def _device_frame(fa):
     """FrameView whose pointers are device addresses (+ the buffers that keep them alive)"""
     Fh, keep = oracle.make_frame_view(N.FrameView, **fa)

@@ -20,9 +20,12 @@ def write_text(path, k, L, parents, leaf, desc, weight):
             f.write("%d %d %s %.9g\n" % (parents[i], int(leaf[i]), " ".join(str(int(b)) for b in desc[i]), float(weight[i])))
 
 
-def write_binary(path, k, L, parents, leaf, desc, weight):
+def write_binary(path, k, L, parents, leaf, desc, weight, count_root=True):
+    """DBoW2 saveToBinaryFile (the ORB-SLAM2 fork tools/bin_vocabulary.cc links): nb_nodes = m_nodes.size() COUNTS the root, the record loop
+    starts at node 1, so the file holds nb_nodes - 1 records and the reader runs to EOF.  count_root=False writes the header round 2 of this
+    library wrote (records only), which the loader still accepts."""
     with open(path, "wb") as f:
-        f.write(struct.pack("<IIiiii", len(parents) - 1, 41, k, L, 0, 0))
+        f.write(struct.pack("<IIiiii", len(parents) if count_root else len(parents) - 1, 41, k, L, 0, 0))
         for i in range(1, len(parents)):
             f.write(struct.pack("<i", parents[i]) + bytes(bytearray(desc[i].tolist())) + struct.pack("<f", float(weight[i])) + bytes([int(leaf[i])]))
 
@@ -140,7 +143,29 @@ def test_load_and_transform(tmp_path, fmt, scramble):
     w2, wt2, nd2 = oracle.bow_transform(as_oracle_tree(T2), feats, 2)
     w1, wt1, nd1 = oracle.bow_transform(as_oracle_tree(T), feats, 2)
     assert np.array_equal(w1, w2) and np.array_equal(wt1, wt2) and np.array_equal(nd1, nd2)
+    if fmt == "txt":       # the binary file hs_vocab_save wrote counts the root in its header (DBoW2: nb_nodes = m_nodes.size()) and holds one record less
+        raw = other.read_bytes()
+        assert struct.unpack("<II", raw[:8]) == (len(parents), 41) and len(raw) == 24 + 41 * (len(parents) - 1)
     N.lib().hs_vocab_destroy(v); N.lib().hs_vocab_destroy(v2)
+
+
+def test_binary_header_both_node_count_conventions(tmp_path):
+    """DBoW2's writer announces m_nodes.size() (root included) and writes size - 1 records; files of this library's round 2 announced the
+    record count.  The loader goes by the file length, as DBoW2's reader does, and accepts both."""
+    k, L = 4, 3
+    parents, leaf, desc, weight = synthetic(k, L, 9, False)
+    trees = []
+    for count_root in (True, False):
+        p = tmp_path / ("v%d.bin" % count_root)
+        write_binary(p, k, L, parents, leaf, desc, weight, count_root)
+        st, v, T = load(p)
+        assert st == N.HS_OK and T.n_nodes == len(parents)
+        trees.append((v, T))
+    feats = np.random.default_rng(2).integers(0, 256, (100, 32), dtype=np.uint8)
+    a = oracle.bow_transform(as_oracle_tree(trees[0][1]), feats, 2); b = oracle.bow_transform(as_oracle_tree(trees[1][1]), feats, 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for v, _ in trees:
+        N.lib().hs_vocab_destroy(v)
 
 
 def test_from_tree_matches_make_vocab_tree():
@@ -162,6 +187,9 @@ def test_bad_files(tmp_path):
     assert load(p)[0] == N.HS_ERR_INVALID
     p = tmp_path / "trunc.bin"
     p.write_bytes(struct.pack("<IIiiii", 100, 41, 10, 6, 0, 0) + b"\0" * 50)
+    assert load(p)[0] == N.HS_ERR_INVALID
+    p = tmp_path / "count.bin"                                             # 100 nodes announced, 3 whole records present: neither nb nor nb - 1
+    p.write_bytes(struct.pack("<IIiiii", 100, 41, 10, 6, 0, 0) + b"\0" * (3 * 41))
     assert load(p)[0] == N.HS_ERR_INVALID
     p = tmp_path / "cycle.txt"
     p.write_text("2 2 0 0\n" + "2 0 " + "0 " * 32 + "0\n" + "1 1 " + "0 " * 32 + "1.0\n")       # node 1's parent is node 2 and vice versa: not a tree

@@ -5,12 +5,13 @@ TAG=${1:-x}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT      # a tag used before must not leave its files behind (summarize_profiles.py takes the first match)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 -c "import json; from hyslam_amd._native import source_digests; json.dump(source_digests(), open('$OUT/source_digests.json', 'w'))"
 timeout 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $OUT/bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 --pcie-seconds 0 --min-timed-ms 0 > $OUT/bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/pmc_traffic.py run > /dev/null 2>&1
 python3 tools/pmc_traffic.py report $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.csv
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/sq -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --pcie-seconds 0 --min-timed-ms 0 > /dev/null 2>&1
 timeout 300 python3 tools/bench_matchers.py > $OUT/matchers.json 2>/dev/null
 timeout 300 python3 tools/bench_pcie.py > $OUT/pcie.json 2>/dev/null
 timeout 300 python3 bench.py --config c3 --steps 20 --warmup 3 > $OUT/c3.json 2>/dev/null

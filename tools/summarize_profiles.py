@@ -8,7 +8,22 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hyslam_amd._native import source_digests          # noqa: E402  (no library load: the digests are of the source files)
+
 tag, rnd = sys.argv[1], sys.argv[2]
+try:                                # written on the GPU box by tools/collect_profiles.sh: the sources the counters were collected from
+    DIGESTS = json.load(open(os.path.join("gpurun_out/prof_" + tag, "source_digests.json")))
+except OSError:
+    DIGESTS = source_digests()
+
+
+def stamp(kernel):
+    for prefix, d in DIGESTS.items():
+        if kernel.startswith(prefix):
+            return d
+    return None
+
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
 PAIRS, HANDLES = 16, 1          # bench.py defaults: 16 pairs per step on one handle -> every launch sequence covers 32 frames
@@ -51,7 +66,7 @@ for r in csv.reader(l for l in open(os.path.join(src, "traffic.csv")) if not l.s
         continue
     # pmc_traffic.py runs 3 steps of one handle = 3 launch sequences
     tr[r[0].split("<")[0]] = {"read_MB": float(r[4]), "written_MB": float(r[5]), "frames_per_launch": int(r[6]), "launches": int(r[1]),
-                              "launches_per_sequence": int(r[1]) / 3.0}
+                              "launches_per_sequence": int(r[1]) / 3.0, "source_sha16": stamp(r[0])}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/pmc_traffic.py; FETCH_SIZE x2 (gfx950, calibrated on "
                      "a 1 GiB copy at 4 B/lane and 16 B/lane), WRITE_SIZE x1", "pairs_per_step": PAIRS, "kernels": tr},
           open("profiles/%s_hbm_traffic.json" % rnd, "w"), indent=1)
@@ -70,7 +85,8 @@ with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
         n = len(next(iter(d.values())))
         o.write(k.replace(",", ";") + "," + str(n) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names) + "\n")
         # 5 steps (1 warm-up + 4) x HANDLES launch sequences
-        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / (5.0 * HANDLES))
+        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / (5.0 * HANDLES),
+                                  source_sha16=stamp(k))
 json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
