@@ -70,6 +70,7 @@ EXPORTS = [
     "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_device", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
+    "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
     "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
@@ -179,6 +180,11 @@ def lib():
     L.hs_record_offsets.argtypes = [C.c_int, vp, vp, vp]
     L.hs_record_offsets.restype = None
     L.hs_records_knn2_device.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.hs_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.hs_host_free.argtypes = [vp]
+    L.hs_host_free.restype = None
+    L.hs_orb_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(i32)]
+    L.hs_orb_wait.argtypes = [vp, i32, vp, vp, vp, C.c_int, vp, vp]
     L.hs_comm_get_unique_id.argtypes = [vp]
     L.hs_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.hs_comm_destroy.argtypes = [vp]

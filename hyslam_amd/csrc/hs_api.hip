@@ -57,6 +57,18 @@ struct hs_orb {
     int last_batch = 0; HsImg0 last_img0{};
     // bump-allocated scratch for the host-pointer matcher entry points
     uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
+    // pipelined host ingest (hs_orb_submit_batch / hs_orb_wait): two staging slots, a copy-in and a copy-out stream next to the compute stream
+    struct IngestSlot {
+        uint8_t* d_in = nullptr; size_t in_bytes = 0;          // frames of the batch in HBM
+        uint8_t* d_out = nullptr; size_t out_bytes = 0;        // [counts | keypoints | descriptors | uRight | depth] in HBM
+        uint8_t* h_out = nullptr; size_t h_out_bytes = 0;      // the same block in page-locked host memory
+        hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+        int32_t ticket = 0; bool busy = false;
+        int batch = 0, pairs = 0, cap = 0;
+        size_t off_k = 0, off_d = 0, off_u = 0, off_z = 0, used = 0;
+    } slot[2];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    int32_t next_ticket = 1;
     // second lane (hs_orb_set_lanes): a child handle with its own workspace and stream, fenced against the caller's stream by two events
     hs_orb* lane2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling: events[i] marks the start of stage prof_stage[i]; the event after the last stage has stage -1
@@ -460,6 +472,17 @@ void hs_orb_destroy(hs_orb* h)
     hipFree(h->d_sm_kps); hipFree(h->d_sm_desc); hipFree(h->d_sm_n);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_pin_out) hipHostFree(h->h_pin_out);
+    if (h->s_in) hipStreamSynchronize(h->s_in);
+    if (h->s_out) hipStreamSynchronize(h->s_out);
+    for (auto& sl : h->slot) {
+        hipFree(sl.d_in); hipFree(sl.d_out);
+        if (sl.h_out) hipHostFree(sl.h_out);
+        if (sl.ev_in) hipEventDestroy(sl.ev_in);
+        if (sl.ev_done) hipEventDestroy(sl.ev_done);
+        if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    }
+    if (h->s_in) hipStreamDestroy(h->s_in);
+    if (h->s_out) hipStreamDestroy(h->s_out);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -712,6 +735,134 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     if (rc != HS_OK) return rc;
     run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
     HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+/* ---- pipelined host ingest ----
+ * The reference feeds its extractor from host memory through a bounded queue: System::TrackStereo pushes frames and throttles when more than two
+ * are waiting (src/main/System.cc:194-196), ImageProcessing pops, extracts, matches and pushes the features on (src/main/ImageProcessing.cpp:69-116).
+ * Here: submit(i+1) copies its frames in on the copy-in stream WHILE the kernels of batch i run on the compute stream and the results of batch i
+ * leave on the copy-out stream; two staging slots, so at most two tickets are in flight — the same bound as the reference's queue. */
+int hs_host_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return HS_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return HS_ERR_HIP; }
+    return HS_OK;
+}
+void hs_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride, const hs_stereo_params* sp, int32_t* ticket)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!imgs || !ticket || batch < 1 || batch > 65535 || w < 1 || h_px < 1 || stride < w || (sp && (batch & 1))) return fail(h, HS_ERR_INVALID, "bad argument");
+    for (int i = 0; i < batch; i++) if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
+    *ticket = 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hs_orb::IngestSlot* sl = nullptr;
+    for (auto& c : h->slot) if (!c.busy) { sl = &c; break; }
+    if (!sl) return fail(h, HS_ERR_INVALID, "both staging slots are in flight: hs_orb_wait for the oldest ticket first");
+    if (!h->s_in) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    }
+    if (!sl->ev_in) {
+        HIP_TRY(h, hipEventCreateWithFlags(&sl->ev_in, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&sl->ev_out, hipEventDisableTiming));
+    }
+    if (!(w == h->w && h_px == h->h && batch <= h->batch_cap)) {      // a new geometry rebuilds the shared workspace: nothing may be in flight on it
+        HIP_TRY(h, hipStreamSynchronize(h->s_in)); HIP_TRY(h, hipStreamSynchronize(h->s_out));
+    }
+    int rc = configure(h, w, h_px, batch);
+    if (rc != HS_OK) return rc;
+    const int cap = h->max_kp, pairs = sp ? batch / 2 : 0;
+    if (cap < 1) return fail(h, HS_ERR_INVALID, "this frame size yields no keypoints");
+    const size_t pitch = ((size_t)w + 63) & ~(size_t)63, per_img = pitch * h_px;
+    if (per_img * batch > sl->in_bytes) {
+        hipFree(sl->d_in); sl->d_in = nullptr; sl->in_bytes = 0;           // the slot is idle: its last batch was waited for
+        HIP_TRY(h, hipMalloc(&sl->d_in, per_img * batch));
+        sl->in_bytes = per_img * batch;
+    }
+    sl->off_k = pad256((size_t)batch * 4);
+    sl->off_d = sl->off_k + pad256((size_t)batch * cap * sizeof(hs_keypoint));
+    sl->off_u = sl->off_d + pad256((size_t)batch * cap * HS_DESC_BYTES);
+    sl->off_z = sl->off_u + pad256((size_t)std::max(pairs, 1) * cap * 4);
+    sl->used = sl->off_z + pad256((size_t)std::max(pairs, 1) * cap * 4);
+    if (sl->used > sl->out_bytes) {
+        hipFree(sl->d_out); sl->d_out = nullptr; sl->out_bytes = 0;
+        HIP_TRY(h, hipMalloc(&sl->d_out, sl->used));
+        sl->out_bytes = sl->used;
+    }
+    if (sl->used > sl->h_out_bytes) {
+        if (sl->h_out) hipHostFree(sl->h_out);
+        sl->h_out = nullptr; sl->h_out_bytes = 0;
+        HIP_TRY(h, hipHostMalloc((void**)&sl->h_out, sl->used, hipHostMallocDefault));
+        sl->h_out_bytes = sl->used;
+    }
+    if (sp) {
+        rc = ensure_stereo_scratch(h, (size_t)pairs * cap);
+        if (rc == HS_OK) rc = ensure_stereo_strips(h, pairs, cap, sp->n_rows);
+        if (rc != HS_OK) return rc;
+    }
+    // copy-in stream: page-locked frames (hs_host_alloc) go by DMA at link speed and the call returns at once; pageable frames go through the
+    // runtime's staging path (the call returns when they are staged) — either way the compute stream keeps running the previous batch
+    for (int i = 0; i < batch; i++)
+        HIP_TRY(h, hipMemcpy2DAsync(sl->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, h->s_in));
+    HIP_TRY(h, hipEventRecord(sl->ev_in, h->s_in));
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipStreamWaitEvent(s, sl->ev_in, 0));
+    int32_t* d_n = reinterpret_cast<int32_t*>(sl->d_out);
+    hs_keypoint* d_k = reinterpret_cast<hs_keypoint*>(sl->d_out + sl->off_k);
+    uint8_t* d_d = sl->d_out + sl->off_d;
+    if (sp) {      // images [0, pairs) are the left frames, [pairs, 2 pairs) the right ones (hs_stereo_frontend_batch_device's layout)
+        HsImg0 img0{ sl->d_in, sl->d_in + per_img * pairs, pairs, (uint64_t)pitch, (uint64_t)per_img };
+        HsOut out{ d_k, d_d, d_n, d_k + (size_t)pairs * cap, d_d + (size_t)pairs * cap * HS_DESC_BYTES, d_n + pairs, pairs, cap };
+        rc = run_extract(h, img0, batch, out, s);
+        if (rc != HS_OK) return rc;
+        run_stereo(h, out.kps, out.desc, out.n, out.kps2, out.desc2, out.n2, pairs, cap, *sp,
+                   reinterpret_cast<float*>(sl->d_out + sl->off_u), reinterpret_cast<float*>(sl->d_out + sl->off_z), s);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        HsImg0 img0{ sl->d_in, sl->d_in, batch, (uint64_t)pitch, (uint64_t)per_img };
+        HsOut out{ d_k, d_d, d_n, d_k, d_d, d_n, batch, cap };
+        rc = run_extract(h, img0, batch, out, s);
+        if (rc != HS_OK) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(sl->ev_done, s));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_out, sl->ev_done, 0));
+    HIP_TRY(h, hipMemcpyAsync(sl->h_out, sl->d_out, sl->used, hipMemcpyDeviceToHost, h->s_out));
+    HIP_TRY(h, hipEventRecord(sl->ev_out, h->s_out));
+    sl->busy = true; sl->batch = batch; sl->pairs = pairs; sl->cap = cap;
+    sl->ticket = h->next_ticket++;
+    if (h->next_ticket <= 0) h->next_ticket = 1;
+    *ticket = sl->ticket;
+    return HS_OK;
+}
+
+int hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int32_t* n, int cap, float* uRight, float* depth)
+{
+    if (!h) return HS_ERR_INVALID;
+    hs_orb::IngestSlot* sl = nullptr;
+    for (auto& c : h->slot) if (c.busy && c.ticket == ticket) sl = &c;
+    if (!sl || ticket <= 0) return fail(h, HS_ERR_INVALID, "unknown ticket");
+    if (!kps || !desc || !n || (sl->pairs && (!uRight || !depth))) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (cap < sl->cap) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(sl->ev_out));
+    const int B = sl->batch, c0 = sl->cap;
+    memcpy(n, sl->h_out, (size_t)B * 4);
+    for (int i = 0; i < B; i++) {            // only the keypoints that exist are copied, into the caller's [batch][cap] layout
+        const size_t cnt = (size_t)std::min(std::max(n[i], 0), c0);
+        memcpy(kps + (size_t)i * cap, sl->h_out + sl->off_k + (size_t)i * c0 * sizeof(hs_keypoint), cnt * sizeof(hs_keypoint));
+        memcpy(desc + (size_t)i * cap * HS_DESC_BYTES, sl->h_out + sl->off_d + (size_t)i * c0 * HS_DESC_BYTES, cnt * HS_DESC_BYTES);
+    }
+    for (int i = 0; i < sl->pairs; i++) {
+        const size_t cnt = (size_t)std::min(std::max(n[i], 0), c0);
+        memcpy(uRight + (size_t)i * cap, sl->h_out + sl->off_u + (size_t)i * c0 * 4, cnt * 4);
+        memcpy(depth + (size_t)i * cap, sl->h_out + sl->off_z + (size_t)i * c0 * 4, cnt * 4);
+    }
+    sl->busy = false;
     return HS_OK;
 }
 

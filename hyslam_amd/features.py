@@ -70,6 +70,9 @@ class ORBExtractor:
         if getattr(self, "_h", None) and self._h.value:
             self._lib.hs_orb_destroy(self._h)
             self._h = C.c_void_p()
+            for ptr in getattr(self, "_pinned", []):
+                self._lib.hs_host_free(ptr)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -138,6 +141,49 @@ class ORBExtractor:
                                                         kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
                                                         n.ctypes.data_as(C.c_void_p)))
         return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
+
+    # ---- pipelined host ingest (hs_orb_submit_batch / hs_orb_wait): at most two tickets in flight, like the reference's frame queue
+    # (System.cc:194-196).  The H2D copy of a submitted batch overlaps the kernels of the batch before it.
+    def submit_batch(self, images, sp=None):
+        """images: same-sized 2-D uint8 arrays with one common row stride (pinned_frames() gives page-locked ones); with `sp` (a StereoParams)
+        the first half are the left frames and the second half the right ones and the stereo matcher runs too.  Returns a ticket.
+        The arrays must stay alive and unchanged until wait(ticket) returns."""
+        b = len(images)
+        h, w = images[0].shape
+        for im in images:
+            if im.dtype != np.uint8 or im.ndim != 2 or im.shape != (h, w) or im.strides != images[0].strides or im.strides[1] != 1:
+                raise TypeError("frames must be 2-D uint8 of one size and one row stride")
+        ptrs = (C.c_void_p * b)(*[im.ctypes.data for im in images])
+        t = C.c_int32()
+        N.check(self._h, self._lib.hs_orb_submit_batch(self._h, ptrs, b, w, h, images[0].strides[0], C.byref(sp) if sp is not None else None, C.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = (b, sp is not None, images)
+        return t.value
+
+    def wait(self, ticket, out=None):
+        """-> (n[b], kps[b, cap], desc[b, cap, 32], uRight[b/2, cap] | None, depth[b/2, cap] | None); entries beyond n[i] are undefined.
+        `out` = a tuple of arrays from a previous call to reuse."""
+        b, stereo, _ = self._tickets.pop(ticket)
+        cap = self.max_keypoints()
+        if out is None:
+            out = (np.zeros(b, np.int32), np.zeros((b, cap), KP_DTYPE), np.zeros((b, cap, 32), np.uint8),
+                   np.zeros((b // 2, cap), np.float32) if stereo else None, np.zeros((b // 2, cap), np.float32) if stereo else None)
+        n, kps, desc, uR, depth = out
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        N.check(self._h, self._lib.hs_orb_wait(self._h, ticket, p(kps), p(desc), p(n), cap, p(uR), p(depth)))
+        return out
+
+    def pinned_frames(self, count, h, w):
+        """`count` h x w uint8 frames in page-locked host memory (hs_host_alloc): H2D copies from them are plain DMA, no staging.
+        The memory is released when the extractor is closed."""
+        ptr = C.c_void_p()
+        st = self._lib.hs_host_alloc(count * h * w, C.byref(ptr))
+        if st != N.HS_OK:
+            raise HsError(st, "hs_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(ptr)
+        buf = (C.c_uint8 * (count * h * w)).from_address(ptr.value)
+        return np.frombuffer(buf, np.uint8).reshape(count, h, w)
 
     # ---- device-resident entry points (pointers are plain integers, e.g. torch.Tensor.data_ptr())
     def reserve(self, w, h, batch):

@@ -106,6 +106,21 @@ int  hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, in
                                  size_t row_stride, size_t image_stride,
                                  hs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap, void* stream);
 
+/* ---- pipelined host ingest: the reference's bounded frame queue (System::TrackStereo throttles the producer at more than two waiting frames,
+ * src/main/System.cc:194-196; ImageProcessing pops, extracts, matches: src/main/ImageProcessing.cpp:69-116) ----
+ * hs_orb_submit_batch enqueues `batch` same-sized host frames and returns a ticket at once: the frames are copied in on a copy stream while the
+ * kernels of the previously submitted batch still run, the results leave on a third stream into page-locked memory of the handle.  With `sp`
+ * != NULL the batch is batch/2 stereo pairs — images [0, batch/2) left, [batch/2, batch) right — and the stereo matcher runs too.
+ * hs_orb_wait blocks until that ticket's results are on the host and copies them out: kps [batch][cap], desc [batch][cap][32], n [batch],
+ * uRight / depth [batch/2][cap] (stereo tickets only; NULL otherwise); cap >= hs_orb_max_keypoints().
+ * At most TWO tickets may be in flight (two staging slots): a third submit returns HS_ERR_INVALID until the oldest was waited for.
+ * Frames in page-locked memory (hs_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) are DMA'd at link speed; pageable frames
+ * work too and go through the runtime's staging path. */
+int  hs_host_alloc(size_t bytes, void** out);
+void hs_host_free(void* p);
+int  hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride, const hs_stereo_params* sp, int32_t* ticket);
+int  hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int32_t* n, int cap, float* uRight, float* depth);
+
 /* ---- stereo: replaces Stereomatcher::computeStereoMatches + getData, src/features/Stereomatcher.cpp:26-156 ---- */
 /* uRight[nL], depth[nL]: -1 where there is no stereo match (Stereomatcher.h:44-47). */
 int  hs_stereo_match(hs_orb* h, const hs_keypoint* kpsL, const uint8_t* descL, int nL,

@@ -1,0 +1,77 @@
+"""Pipelined host ingest of the C ABI (hs_orb_submit_batch / hs_orb_wait / hs_host_alloc): two tickets in flight, the H2D copy of the second
+under the kernels of the first — results bit-identical to the oracle whatever overlaps (ImageProcessing.cpp:69-116, System.cc:194-196)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import hyslam_amd as HS
+from hyslam_amd import _native as N
+from hyslam_amd.synth import synth_image, synth_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_stereo_tickets_in_flight_pinned_and_pageable(gpu):
+    W, H, NF, P = 640, 480, 1000, 3
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    cam = HS.Camera(fx=500.0, mbf=60.0, mnMaxY=float(H))
+    sp = HS.stereo_params(cam)
+    osp = oracle.stereo_params(fx=500.0, mbf=60.0, n_rows=H)
+    p = oracle.default_params(NF)
+    pin = ex.pinned_frames(2 * P, H, W)
+    page = np.zeros((2 * P, H, W + 24), np.uint8)[:, :, 7:7 + W]           # pageable, row-strided, unaligned views
+    pairs_a = [synth_stereo_pair(40 + i, W, H) for i in range(P)]
+    pairs_b = [synth_stereo_pair(50 + i, W, H) for i in range(P)]
+    for i in range(P):
+        pin[i], pin[P + i] = pairs_a[i]
+        page[i], page[P + i] = pairs_b[i]
+    ta = ex.submit_batch([pin[i] for i in range(2 * P)], sp)
+    tb = ex.submit_batch([page[i] for i in range(2 * P)], sp)              # enqueued while ticket a is still running
+    assert ta != tb and ta > 0 and tb > 0
+    with pytest.raises(HS.HsError):                                         # both staging slots are in flight
+        ex.submit_batch([pin[i] for i in range(2 * P)], sp)
+    # waiting out of order is allowed
+    rb = ex.wait(tb)
+    ra = ex.wait(ta)
+    for (n, k, d, uR, depth), pairs in ((ra, pairs_a), (rb, pairs_b)):
+        for i, (L, R) in enumerate(pairs):
+            okL, odL = oracle.extract(p, L); okR, odR = oracle.extract(p, R)
+            assert n[i] == len(okL) and n[P + i] == len(okR)
+            assert k[i, :n[i]].tobytes() == okL.tobytes() and np.array_equal(d[i, :n[i]], odL)
+            assert k[P + i, :n[P + i]].tobytes() == okR.tobytes() and np.array_equal(d[P + i, :n[P + i]], odR)
+            ouR, odepth, _, _ = oracle.stereo_match(okL, odL, okR, odR, osp)
+            assert np.array_equal(uR[i, :n[i]], ouR) and np.array_equal(depth[i, :n[i]], odepth)
+            assert (odepth > 0).sum() > 50
+    # a waited ticket is gone; slots are free again
+    dummy = [np.zeros(1, np.int32), np.zeros((1, 1), N.KP_DTYPE), np.zeros((1, 1, 32), np.uint8)]
+    assert ex._lib.hs_orb_wait(ex._h, ta, dummy[1].ctypes.data_as(C.c_void_p), dummy[2].ctypes.data_as(C.c_void_p), dummy[0].ctypes.data_as(C.c_void_p), 1, None, None) == N.HS_ERR_INVALID
+    tc = ex.submit_batch([pin[i] for i in range(2 * P)], sp)
+    rc = ex.wait(tc)
+    assert np.array_equal(rc[0], ra[0]) and rc[1].tobytes() == ra[1].tobytes()
+
+
+def test_mono_tickets_change_of_geometry_and_capacity_check(gpu):
+    NF = 800
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    p = oracle.default_params(NF)
+    a = [synth_image(60 + i, 512, 384) for i in range(3)]
+    b = [synth_image(70 + i, 800, 600) for i in range(2)]
+    t1 = ex.submit_batch(a)
+    t2 = ex.submit_batch(b)                                                # another frame size while the first ticket is in flight
+    r2 = ex.wait(t2); r1 = ex.wait(t1)
+    for (n, k, d, uR, depth), frames in ((r1, a), (r2, b)):
+        assert uR is None and depth is None
+        for i, f in enumerate(frames):
+            ok, od = oracle.extract(p, f)
+            assert n[i] == len(ok) and k[i, :n[i]].tobytes() == ok.tobytes() and np.array_equal(d[i, :n[i]], od)
+    # an odd batch cannot be a stereo batch; a too small output capacity is refused and the ticket stays waitable
+    with pytest.raises(HS.HsError):
+        ex.submit_batch(a, HS.stereo_params(HS.Camera(400.0, 48.0, 384.0)))
+    t3 = ex.submit_batch(a)
+    small = (np.zeros(3, np.int32), np.zeros((3, 10), N.KP_DTYPE), np.zeros((3, 10, 32), np.uint8))
+    st = ex._lib.hs_orb_wait(ex._h, t3, small[1].ctypes.data_as(C.c_void_p), small[2].ctypes.data_as(C.c_void_p), small[0].ctypes.data_as(C.c_void_p), 10, None, None)
+    assert st == N.HS_ERR_CAPACITY
+    r3 = ex.wait(t3)
+    assert np.array_equal(r3[0], r1[0])
