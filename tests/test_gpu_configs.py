@@ -130,8 +130,8 @@ def test_c5_real_shape_8_records_1080p(gpu):
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
     ex.reserve(W, H, 1)
     cap = ex.max_keypoints()
-    assert cap == 2012
     rb = D.record_bytes(cap)
+    assert cap == 2032 and rb == 113808                                   # 16 + 2032 * (24 + 32): the all-gather message of DESIGN.md §6
     o_n, o_k, o_d = D.record_offsets(cap)
     frames = synth_rig(200, world, W, H)
     recs = hipmem.DevBuf(world * rb)
