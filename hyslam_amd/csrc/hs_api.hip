@@ -20,6 +20,7 @@ struct hs_orb {
     uint16_t taps[7];
     HsFastKnobs fast_knobs{};          // HS_FAST_* environment knobs, read once in hs_orb_create
     uint32_t fast_epoch = 0;           // FAST launches on this workspace so far (selects the work-queue counter set)
+    bool qt_point_domain = false;      // HS_QT_POINT_DOMAIN=1 (read once): the quadtree's general point-domain passes only (parity tests of the fallback)
     bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
@@ -329,7 +330,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     }
     mark(h, 2, s);
     hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
-                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, s);
+                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0, s);
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->d_sel_perm, h->sel_img_stride, h->max_kp,
                        h->d_taps, out, s, h->fast_taps);
@@ -425,6 +426,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->p = *p; h->device = device;
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
+    { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
     static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
     for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];

@@ -22,8 +22,23 @@
 //     a 64-bit LDS atomicMax on score<<56 | ~order, where order = (cell, y, x) reproduces the reference's
 //     candidate order (cells row-major, cv::FAST's row-major scan inside a cell).
 //
-// Inputs are the per-cell candidate slots written by k_fast_rows (gathered into a dense list first).  Outputs per (image, level):
-// selected (x,y,score) in final list order + count.  Bound: LDS atomics / VALU; HBM traffic negligible.
+//   * COUNT DOMAIN (round 3).  Which node a point ends up in depends on geometry alone — its path through DivideNode's midpoints below its
+//     root — and everything the list bookkeeping needs from the points is COUNTS.  The gather sweep therefore also computes every point's
+//     geometric key (root, path to depth DH = 5 or 6) and a histogram of those keys; the per-depth counts are sums of it (a pyramid).  Then
+//       - phase 1 in CLOSED FORM: while every multi-point node is split, the list after pass p is
+//             R_p ++ finals(R_{p-1}) ++ ... ++ finals(R_0)
+//         (R_d = the depth-d nodes in reverse creation order, finals = its single-point nodes), R_d orders the depth-d cells by their path
+//         with every second digit complemented (push_front reverses the order once per pass), and the sizes S_p / nToExpand that decide when
+//         the reference stops or switches phase are sums over the pyramid: no replay, one scan over the concatenated sequences;
+//       - the size-ordered passes of phase 2 run on the list with the children's counts READ from the pyramid instead of counted by a sweep
+//         over the points, and without relabelling the points;
+//       - one sweep at the end maps every point's geometric key to its node.
+//     A node deeper than the pyramid (clustered points), more than 8 root nodes or more than 65535 points fall back to the point-domain
+//     passes (sweeps with LDS atomics), which remain the general algorithm.
+//
+// Inputs are the per-cell candidate slots written by k_fast_rows (gathered into a dense list first; its order is irrelevant: every
+// order-dependent decision uses the (cell, y, x) key of the reference's candidate order).  Outputs per (image, level):
+// selected (x,y,score) in final list order + count.  Bound: LDS latency / barriers; HBM traffic negligible.
 #include "hs_internal.h"
 #include <cstdlib>
 
@@ -31,24 +46,42 @@
 #define QT_M HS_QT_MAX_NODES
 #define QT_PTS 6144              // points kept in LDS (a 1080p level has ~5000 candidates); more fall back to the global arrays
 
-struct alignas(16) QtNodes {
-    int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M];
-    uint32_t cnt[QT_M];
+#define QT_HPYR 10928             // histogram pyramid entries (u16): n_ini * (4^(DH+1) - 1) / 3 <= 10922 for (n_ini <= 2, DH = 6) and (n_ini <= 8, DH = 5)
+
+// Node list, double buffered.  Rectangles are only kept in the point domain; in the count domain their LDS holds the histogram pyramid.
+struct alignas(16) QtRects { int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M]; };
+static_assert(2 * sizeof(QtRects) >= QT_HPYR * 2, "the histogram pyramid lives in the rectangle arrays");
+struct QtNodes {                 // a view of buffer `c`
+    int16_t *x0, *x1, *y0, *y1; uint32_t* cnt; uint16_t* ekey;
 };
 
-// exclusive scan of one int per thread over the 1024-thread block; returns prefix, writes total
-__device__ __forceinline__ int block_scan_excl(int v, int* s_wave /*[16]*/, int& total)
+// inclusive scan over the wavefront with DPP row shifts / row broadcasts (six VALU adds, no LDS crossbar round trips)
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);      // row_shr:8   -> inclusive within each row of 16
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ int wave_sum(int x) { return __builtin_amdgcn_readlane(wave_scan_incl(x), 63); }
+
+// exclusive scan of one int per thread over the 1024-thread block; returns prefix, writes total.  s_wave holds TWO sets of per-wave sums
+// used alternately (`flip`): a set is only rewritten two scans later, and the barrier of the scan in between orders that write after the
+// last read — one barrier per scan.
+__device__ __forceinline__ int block_scan_excl(int v, int* s_wave /*[2][16]*/, int& flip, int& total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
-    __syncthreads();                       // protect s_wave reuse
-    if (lane == 63) s_wave[wave] = incl;
+    const int incl = wave_scan_incl(v);
+    int* const sw = s_wave + 16 * (flip & 1);
+    flip ^= 1;
+    if (lane == 63) sw[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < QT_T / 64; w++) { int x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    for (int w = 0; w < QT_T / 64; w++) { int x = sw[w]; if (w < wave) base += x; tot += x; }
     total = tot;
     return base + incl - v;
 }
@@ -68,7 +101,7 @@ __device__ __forceinline__ void wave_agg_inc(uint32_t* arr, int key, bool valid)
     }
 }
 
-__device__ __forceinline__ int child_of(const QtNodes& N, int nd, int x, int y)
+__device__ __forceinline__ int child_of(const QtNodes N, int nd, int x, int y)
 {
     // DivideNode: halfX = ceil((UR.x-UL.x)/2); n1.UR.x = UL.x+halfX; n1.BR.y = UL.y+halfY
     int mx = N.x0[nd] + ((N.x1[nd] - N.x0[nd] + 1) >> 1);
@@ -89,20 +122,24 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride,
-                                                   uint16_t* __restrict__ sel_perm)
+                                                   uint16_t* __restrict__ sel_perm, int force_point_domain)
 {
-    __shared__ QtNodes nodes[2];
+    __shared__ QtRects s_rect[2];                  // point domain: node rectangles; count domain: the histogram pyramid (u16)
+    __shared__ uint32_t s_cnt[2][QT_M];            // points per node
+    __shared__ uint16_t s_ekey[2][QT_M];           // count domain: depth << 13 | cell index at that depth (root * 4^depth + path)
     __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
     __shared__ int16_t proc_rank[QT_M];            // processing rank of a node in this pass, -1 = not split
     __shared__ int16_t order_node[QT_M];           // rank -> node
     __shared__ uint16_t new_index[QT_M];           // surviving node -> index in the next list
     __shared__ uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
-    __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node, when there are <= QT_PTS of them:
-    __shared__ uint16_t s_pnode[QT_PTS];           // every pass walks the points twice, from LDS instead of through L2
-    __shared__ int s_wave[QT_T / 64];
+    __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node (count domain: their geometric key), when there
+    __shared__ uint16_t s_pnode[QT_PTS];           // are <= QT_PTS of them: every sweep walks the points from LDS instead of through L2
+    __shared__ int s_wave[2 * (QT_T / 64)];
     __shared__ int s_misc[8];
+    __shared__ uint32_t s_dcnt[8];                 // per depth: existing nodes | single-point nodes << 16
 
     const int tid = threadIdx.x;
+    int sflip = 0;           // which set of per-wave sums the next block scan uses
 #ifdef HS_QT_PROFILE
     int qt_k = 0;
 #endif
@@ -115,20 +152,46 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     uint16_t* pnode = pt_node_all + (size_t)img * cand_img_stride + L.cand_off;
     uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
     int32_t* out_n = &sel_count[img * nlevels + level];
+    auto view = [&](int c) { QtNodes v; v.x0 = s_rect[c].x0; v.x1 = s_rect[c].x1; v.y0 = s_rect[c].y0; v.y1 = s_rect[c].y1; v.cnt = s_cnt[c]; v.ekey = s_ekey[c]; return v; };
 
-    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list.
-    // The FAST kernel fills a cell's slots in no particular order; the reference's list order (vToDistributeKeys) is cell by cell and,
-    // inside a cell, cv::FAST's row-major scan = ascending (y<<16 | x) = ascending cand_xy.  Up to 4 * QT_T cells per round:
-    //   A  one thread per 4 cells: counts, block-wide exclusive scan, and the cell id of each of its records into LDS
-    //   B  one thread per RECORD: key -> LDS;  then rank inside its cell by counting smaller keys (LDS reads), scatter to the dense list.
-    // Record-parallel because the high pyramid levels have few cells with many records each (mean 20, up to 34 at level 7 of a 1080p
-    // frame): a per-cell thread loop was k dependent global round trips long.  The node arrays are not live yet: their LDS is the scratch.
+    const int nIni = L.n_ini;
+    const float hX = L.hx;
+    // ---- count domain set-up: pyramid depth, offsets (deepest level first so that it is 4-byte aligned for the packed atomics)
+    const bool cf_geom = nIni >= 1 && nIni <= 8 && !force_point_domain;       // uniform
+    const int DH = nIni <= 2 ? 6 : 5;
+    uint16_t* const hist = reinterpret_cast<uint16_t*>(s_rect);
+    auto hoff = [&](int d) { return nIni * (((1 << (2 * DH + 2)) - (1 << (2 * d + 2))) / 3); };     // entries of the levels deeper than d
+    // geometric key of a point: root << 2 DH | its DivideNode decisions down to depth DH (:121-177, :209)
+    auto geo_key = [&](int x, int y) {
+        const int r = min((int)((float)x / hX), nIni - 1);                      // vpIniNodes[kp.pt.x/hX]
+        int x0 = (int16_t)(int)(hX * (float)r), x1 = (int16_t)(int)(hX * (float)(r + 1)), y0 = 0, y1 = (int16_t)L.qt_h;
+        int path = 0;
+        for (int d = 0; d < DH; d++) {
+            const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+            const int c = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+            if (c & 1) x0 = mx; else x1 = mx;
+            if (c & 2) y0 = my; else y1 = my;
+            path = path * 4 + c;
+        }
+        return (r << (2 * DH)) | path;
+    };
+    if (cf_geom) {
+        uint32_t* const h32 = reinterpret_cast<uint32_t*>(s_rect);
+        for (int i = tid; i < QT_HPYR / 2; i += QT_T) h32[i] = 0;
+        if (tid < 8) s_dcnt[tid] = 0;
+    }
+    __syncthreads();
+    QT_MARK(20);
+
+    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list (its order is irrelevant).
+    // Up to 4 * QT_T cells per round: a thread per 4 cells for the counts and the block-wide exclusive scan, then one thread per RECORD
+    // (the high pyramid levels have few cells with many records each).  In the count domain the same thread computes the point's geometric
+    // key and adds it to the histogram.  The child-count / index arrays are not live yet: their LDS is the scratch.
     int n = 0;
     {
-        uint32_t* const s_key = reinterpret_cast<uint32_t*>(&nodes[0]);          // [QT_GKEYS]
         uint16_t* const s_cell = reinterpret_cast<uint16_t*>(ccount);            // [QT_GKEYS]
         uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [QT_T * CPT] exclusive offset of the round's cell
-        constexpr int QT_GKEYS = (int)(sizeof(nodes) / 4) < (int)(sizeof(ccount) / 2) ? (int)(sizeof(nodes) / 4) : (int)(sizeof(ccount) / 2);
+        constexpr int QT_GKEYS = (int)(sizeof(ccount) / 2);
         const int ncell = L.ncols * L.nrows;
         const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
@@ -136,20 +199,30 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
         constexpr int CPT = 4;                                     // cells per thread and round: the counts of a round are independent loads
         static_assert(sizeof(child_index) >= QT_T * CPT * 4, "s_pre scratch");
+        auto put = [&](int pos, uint32_t key, uint32_t sk) {
+            pxy[pos] = key; psk[pos] = sk;
+            if (pos < QT_PTS) s_pxy[pos] = key;
+            if (cf_geom) {
+                const int gk = geo_key(key & 0xFFFF, key >> 16);
+                if (pos < QT_PTS) s_pnode[pos] = (uint16_t)gk;
+                pnode[pos] = (uint16_t)gk;
+                atomicAdd(reinterpret_cast<uint32_t*>(s_rect) + (gk >> 1), 1u << ((gk & 1) * 16));
+            }
+        };
         int cpt = CPT;
         for (int c0 = 0; c0 < ncell;) {
-            // a round takes cpt cells per thread: as many as leave the round's records inside the scratch (dense frames: a 4000x3000 level
-            // has 3.3 records per cell and 4096 cells overflowed it — the per-cell fallback below then cost a quarter of the kernel);
-            // the next round starts from the density this one found
+            // a round takes cpt cells per thread: as many as leave the round's records inside the scratch; the next round starts from the
+            // density this one found
             int k[CPT], ksum, tot, pre;
             for (;;) {
                 ksum = 0;
 #pragma unroll
                 for (int q = 0; q < CPT; q++) { const int c = c0 + tid * cpt + q; k[q] = (q < cpt && c < ncell) ? min(ccnt[c], ccap) : 0; ksum += k[q]; }
-                pre = block_scan_excl(ksum, s_wave, tot);
+                pre = block_scan_excl(ksum, s_wave, sflip, tot);
                 if (tot <= QT_GKEYS || cpt == 1) break;
                 cpt >>= 1;
             }
+            QT_MARK(21);
             const int round_cells = QT_T * cpt;
             if (tot <= QT_GKEYS) {
 #pragma unroll
@@ -159,41 +232,34 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     pre += k[q];
                 }
                 __syncthreads();
-                for (int e = tid; e < tot; e += QT_T) {
-                    const int lc = s_cell[e];
-                    s_key[e] = sxy[(size_t)(c0 + lc) * ccap + (e - (int)s_pre[lc])];
-                }
-                __syncthreads();
-                for (int e = tid; e < tot; e += QT_T) {
-                    const int lc = s_cell[e];
-                    const int first = (int)s_pre[lc], i = e - first;
-                    const uint32_t sk = ssk[(size_t)(c0 + lc) * ccap + i];           // in flight during the rank loop
-                    const int last = (lc + 1 < round_cells) ? (int)s_pre[lc + 1] : tot;   // cells past the last one have k = 0: s_pre = tot
-                    const uint32_t key = s_key[e];
-                    int rank = 0;
-                    for (int j = first; j < last; j++) rank += s_key[j] < key;
-                    pxy[n + first + rank] = key; psk[n + first + rank] = sk;
-                    if (n + first + rank < QT_PTS) s_pxy[n + first + rank] = key;
+                QT_MARK(22);
+                for (int e0 = tid; e0 < tot; e0 += 4 * QT_T) {     // four records per thread in flight: the loads of all four before the first use
+                    uint32_t key[4], sk[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int e = e0 + u * QT_T;
+                        if (e < tot) {
+                            const int lc = s_cell[e];
+                            const size_t src = (size_t)(c0 + lc) * ccap + (e - (int)s_pre[lc]);
+                            key[u] = sxy[src]; sk[u] = ssk[src];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int e = e0 + u * QT_T; if (e < tot) put(n + e, key[u], sk[u]); }
                 }
                 __syncthreads();                                   // the scratch is reused by the next round
             } else {                                               // saturated image: more records than the scratch holds; one thread per cell
 #pragma unroll
                 for (int q = 0; q < CPT; q++) {                    // cpt == 1 here: k[1..] = 0
                     const size_t src = (size_t)min(c0 + tid * cpt + q, ncell - 1) * ccap;
-                    for (int i = 0; i < k[q]; i++) {
-                        const uint32_t key = sxy[src + i];
-                        int rank = 0;
-                        for (int j = 0; j < k[q]; j++) rank += sxy[src + j] < key;
-                        pxy[n + pre + rank] = key; psk[n + pre + rank] = ssk[src + i];
-                        if (n + pre + rank < QT_PTS) s_pxy[n + pre + rank] = key;
-                    }
+                    for (int i = 0; i < k[q]; i++) put(n + pre + i, sxy[src + i], ssk[src + i]);
                     pre += k[q];
                 }
             }
             n += tot;
             c0 += round_cells;
         }
-        __syncthreads();      // the dense list is complete (written and read by this workgroup only)
+        __syncthreads();      // the dense list and the histogram are complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
     QT_MARK(1);
@@ -202,178 +268,218 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     auto ld_node = [&](int p) -> int { return in_lds ? (int)s_pnode[p] : (int)pnode[p]; };
     auto st_node = [&](int p, int v) { if (in_lds) s_pnode[p] = (uint16_t)v; else pnode[p] = (uint16_t)v; };
 
-    const int nIni = L.n_ini;
-    const float hX = L.hx;
     if (n == 0 || nIni < 1 || nIni > QT_M / 4) { if (tid == 0) *out_n = 0; return; }
 
-    // ---- roots (:183-225): count, drop empty ones, keep list order = root order
-    for (int i = tid; i < nIni; i += QT_T) ccount[i] = 0;
-    __syncthreads();
-    for (int p = tid; p < n; p += QT_T) {
-        int x = ld_xy(p) & 0xFFFF;
-        int r = (int)((float)x / hX);               // vpIniNodes[kp.pt.x/hX]
-        r = min(r, nIni - 1);
-        wave_agg_inc(ccount, r, true);
-    }
-    __syncthreads();
-    int cur = 0;
-    if (tid == 0) {
-        int S = 0;
-        for (int i = 0; i < nIni; i++) {
-            if (ccount[i] > 0) {
-                nodes[0].x0[S] = (int16_t)(int)(hX * (float)i);
-                nodes[0].x1[S] = (int16_t)(int)(hX * (float)(i + 1));
-                nodes[0].y0[S] = 0; nodes[0].y1[S] = (int16_t)L.qt_h;
-                nodes[0].cnt[S] = ccount[i];
-                new_index[i] = (uint16_t)S;
-                S++;
-            }
-        }
-        s_misc[0] = S;
-    }
-    __syncthreads();
-    for (int p = tid; p < n; p += QT_T) {
-        int x = ld_xy(p) & 0xFFFF;
-        int r = min((int)((float)x / hX), nIni - 1);
-        st_node(p, new_index[r]);
-    }
-    int S = s_misc[0];
-    __syncthreads();
-
-    QT_MARK(2);
+    int cur = 0, S = 0;
     bool phase2 = false;     // uniform across the block
     int T_prev = 0;          // number of children created by the previous pass (they sit at list indices [0,T_prev))
-    bool finished = false;   // the distribution ended inside the fast-forward below
+    bool finished = false;
+    bool cm = cf_geom && n <= 65535;               // count domain: the pyramid's 16-bit counters cannot overflow
 
-    // ---- fast-forward of the first (up to three) breadth-first passes.  While the reference is in its first phase EVERY multi-point node
-    //      is split, so where a point ends up depends on geometry alone: its path through DivideNode's midpoints.  One sweep computes every
-    //      point's depth-3 cell and a histogram of those cells; the per-depth counts are sums of it; a single wavefront then replays the list
-    //      bookkeeping of the passes on those counts (a lane per node: which nodes split, which children exist, where they land in the
-    //      list, when the reference would stop or switch to its second phase), and a second sweep labels the points with their node.  The
-    //      generic pass below (a dozen block-wide steps with LDS atomics per pass) then only runs for what is left — normally the single
-    //      size-ordered pass of the second phase.  Applies when the list still fits a wavefront (<= 4 root nodes).
-    if (S <= 4) {
-        uint32_t* const hist3 = ccount;                    // [S*64] points per depth-3 cell
-        uint32_t* const cnt2 = ccount + 256;               // [S*16]
-        uint32_t* const cnt1 = ccount + 320;               // [S*4]
-        uint16_t* const idx_tab = child_index;             // [340] (depth, key) -> index in the final list, 0xFFFF = not a node of it
-        constexpr int TAB0 = 0, TAB1 = 4, TAB2 = 20, TAB3 = 84;
-        int16_t* const nkey = order_node;                  // per list entry: depth<<12 | key
-        __shared__ int16_t s_rootb[16];                    // the roots' rectangles (the node arrays are overwritten by the replay)
-        for (int i = tid; i < 340; i += QT_T) { ccount[i] = 0; idx_tab[i] = 0xFFFF; }
-        if (tid < S) { s_rootb[4 * tid] = nodes[0].x0[tid]; s_rootb[4 * tid + 1] = nodes[0].x1[tid]; s_rootb[4 * tid + 2] = nodes[0].y0[tid]; s_rootb[4 * tid + 3] = nodes[0].y1[tid]; }
+    // every point's node from its geometric key: the one list node on the point's root-to-leaf chain.  marks = (depth, cell) -> list index.
+    auto relabel_from_keys = [&](const QtNodes C) {
+        uint16_t* const mark = reinterpret_cast<uint16_t*>(ccount);
+        static_assert(sizeof(ccount) >= QT_HPYR * 2 && QT_HPYR % 8 == 0, "marks");
+        const int pyr = hoff(-1);
+        for (int i = tid; i < (pyr + 7) / 8; i += QT_T) reinterpret_cast<uint4*>(mark)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
-        // path of a point below root s: three DivideNode decisions
-        auto path_of = [&](int s, int x, int y) {
-            int x0 = s_rootb[4 * s], x1 = s_rootb[4 * s + 1], y0 = s_rootb[4 * s + 2], y1 = s_rootb[4 * s + 3];
-            int path = 0;
+        for (int i = tid; i < S; i += QT_T) { const int ek = C.ekey[i]; mark[hoff(ek >> 13) + (ek & 0x1FFF)] = (uint16_t)i; }
+        __syncthreads();
+        int o[7];
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-                const int c = (x < mx ? 0 : 1) + (y < my ? 0 : 2);
-                if (c & 1) x0 = mx; else x1 = mx;
-                if (c & 2) y0 = my; else y1 = my;
-                path = path * 4 + c;
-            }
-            return path;
+        for (int d = 0; d < 7; d++) o[d] = hoff(min(d, DH));
+        auto node_of_key = [&](int gk) {
+            int m[7];
+#pragma unroll
+            for (int d = 0; d < 7; d++) m[d] = mark[o[d] + (gk >> (2 * (DH - min(d, DH))))];      // independent reads; exactly one of them is a node
+            int e = m[0];
+#pragma unroll
+            for (int d = 1; d < 7; d++) if (m[d] != 0xFFFF) e = m[d];
+            return e;
         };
-        for (int p = tid; p < n; p += QT_T) {
-            const uint32_t xy = ld_xy(p);
-            const int s = ld_node(p);
-            atomicAdd(&hist3[s * 64 + path_of(s, xy & 0xFFFF, xy >> 16)], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int lane = tid;
-            if (lane < S * 16) cnt2[lane] = hist3[4 * lane] + hist3[4 * lane + 1] + hist3[4 * lane + 2] + hist3[4 * lane + 3];
-            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane < S * 4) cnt1[lane] = cnt2[4 * lane] + cnt2[4 * lane + 1] + cnt2[4 * lane + 2] + cnt2[4 * lane + 3];
-            if (lane < S) nkey[lane] = (int16_t)lane;                                     // depth 0, key = root list index
-            __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
-            int Sw = S, Tw = 0, ph2 = 0, fin = 0, curw = 0, passes = 0;
-            for (int pass = 1; pass <= 3; pass++) {
-                if (Sw > 64) break;                                                         // the list no longer fits a lane per node
-                QtNodes& Cw = nodes[curw]; QtNodes& Xw = nodes[curw ^ 1];
-                const bool have = lane < Sw;
-                const int cntv = have ? (int)Cw.cnt[lane] : 0;
-                const bool split = have && cntv > 1;
-                const int kd = have ? (int)(uint16_t)nkey[lane] : 0, key = kd & 0xFFF;
-                const uint32_t* ctab = pass == 1 ? cnt1 : (pass == 2 ? cnt2 : hist3);
-                int cc[4] = { 0, 0, 0, 0 };
-                if (split) { cc[0] = (int)ctab[4 * key]; cc[1] = (int)ctab[4 * key + 1]; cc[2] = (int)ctab[4 * key + 2]; cc[3] = (int)ctab[4 * key + 3]; }
-                const int nchild = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0);
-                const int nexp = (cc[0] > 1) + (cc[1] > 1) + (cc[2] > 1) + (cc[3] > 1);
-                int incl_c = nchild, incl_s = (have && !split) ? 1 : 0, sum_e = nexp;
+        if (in_lds) {
+            int gk[QT_PTS / QT_T];
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int a = __shfl_up(incl_c, o, 64), b = __shfl_up(incl_s, o, 64);
-                    if (lane >= o) { incl_c += a; incl_s += b; }
-                }
+            for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; gk[k] = p < n ? (int)s_pnode[p] : 0; }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum_e += __shfl_xor(sum_e, o, 64);
-                const int T = __builtin_amdgcn_readlane(incl_c, 63), nsurv = __builtin_amdgcn_readlane(incl_s, 63);
-                if (T == 0) { fin = 1; break; }                                             // nothing can be split: size == prevSize (:309)
-                if (T + nsurv > QT_M) { fin = 2; break; }
-                if (split) {
-                    const int x0 = Cw.x0[lane], x1 = Cw.x1[lane], y0 = Cw.y0[lane], y1 = Cw.y1[lane];
-                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-                    int ci = incl_c - nchild;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (cc[c] > 0) {
-                            const int pos = T - 1 - ci; ci++;
-                            Xw.x0[pos] = (int16_t)((c & 1) ? mx : x0); Xw.x1[pos] = (int16_t)((c & 1) ? x1 : mx);
-                            Xw.y0[pos] = (int16_t)((c & 2) ? my : y0); Xw.y1[pos] = (int16_t)((c & 2) ? y1 : my);
-                            Xw.cnt[pos] = (uint32_t)cc[c];
-                            new_index[pos] = (uint16_t)((pass << 12) | (4 * key + c));      // the next list's keys are staged here (nkey is still being read)
-                        }
-                    }
-                } else if (have) {
-                    const int pos = T + incl_s - 1;
-                    Xw.x0[pos] = Cw.x0[lane]; Xw.x1[pos] = Cw.x1[lane]; Xw.y0[pos] = Cw.y0[lane]; Xw.y1[pos] = Cw.y1[lane]; Xw.cnt[pos] = Cw.cnt[lane];
-                    new_index[pos] = (uint16_t)kd;
-                }
-                __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
-                const int prevS = Sw;
-                Sw = T + nsurv; Tw = T; curw ^= 1; passes = pass;
-                for (int i = lane; i < Sw; i += 64) nkey[i] = (int16_t)new_index[i];
-                __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f);
-                if (Sw >= N || Sw == prevS) { fin = 1; break; }                            // (:307-313)
-                if (Sw + sum_e * 3 > N) { ph2 = 1; break; }
-            }
-            // (depth, key) -> list index of every node of the resulting list
-            if (passes > 0 && fin != 2)
-                for (int i = lane; i < Sw; i += 64) {
-                    const int kd = (int)(uint16_t)nkey[i], d = kd >> 12, key = kd & 0xFFF;
-                    idx_tab[(d == 0 ? TAB0 : d == 1 ? TAB1 : d == 2 ? TAB2 : TAB3) + key] = (uint16_t)i;
-                }
-            if (lane == 0) { s_misc[2] = Sw; s_misc[3] = Tw; s_misc[4] = ph2; s_misc[5] = fin; s_misc[6] = curw; s_misc[7] = passes; }
-        }
-        __syncthreads();
-        const int passes = s_misc[7];
-        if (s_misc[5] == 2) { if (tid == 0) *out_n = 0; return; }                          // cannot happen for quota + 8 <= QT_M (host checks)
-        if (passes > 0) {
-            for (int p = tid; p < n; p += QT_T) {
-                const uint32_t xy = ld_xy(p);
-                const int s = ld_node(p);
-                const int path = path_of(s, xy & 0xFFFF, xy >> 16);
-                int e = idx_tab[TAB0 + s];
-                if (e == 0xFFFF) e = idx_tab[TAB1 + s * 4 + (path >> 4)];
-                if (e == 0xFFFF) e = idx_tab[TAB2 + s * 16 + (path >> 2)];
-                if (e == 0xFFFF) e = idx_tab[TAB3 + s * 64 + path];
-                st_node(p, e);
-            }
-            S = s_misc[2]; T_prev = s_misc[3]; phase2 = s_misc[4] != 0; finished = s_misc[5] == 1; cur = s_misc[6];
+            for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) s_pnode[p] = (uint16_t)node_of_key(gk[k]); }
         } else {
-            finished = s_misc[5] == 1;                                                      // no root can be split
+            for (int p = tid; p < n; p += QT_T) pnode[p] = (uint16_t)node_of_key((int)pnode[p]);
         }
+        __syncthreads();
+    };
+
+    if (cm) {
+        // ---- the pyramid: counts per cell of every depth; on the way, per depth, how many cells hold a point (nz) and how many hold exactly
+        //      one: a cell of depth d is a NODE of pass d's list iff it holds a point and its parent was split (held more than one), so
+        //          nodes_d = nz_d - one_{d-1},   single-point nodes_d = one_d - one_{d-1}
+        //      (a parent with one point has exactly one occupied child, with one point)
+        auto stat = [](uint32_t c) { return (c > 0 ? 1u : 0u) + (c == 1 ? 0x10000u : 0u); };
+        for (int d = DH - 1; d >= 0; d--) {
+            const int nbp = nIni << (2 * d), od = hoff(d), oc = hoff(d + 1);
+            const int per = nbp > QT_T ? 2 : 1;                                               // nbp <= 2048
+            uint32_t acc = 0;
+            if (tid * per < nbp) {
+                for (int j = 0; j < per; j++) {
+                    const int b = tid * per + j;
+                    const uint2 q = *reinterpret_cast<const uint2*>(&hist[oc + 4 * b]);      // four u16 children, 8-byte aligned
+                    const uint32_t c0 = q.x & 0xFFFF, c1 = q.x >> 16, c2 = q.y & 0xFFFF, c3 = q.y >> 16;
+                    hist[od + b] = (uint16_t)(c0 + c1 + c2 + c3);
+                    acc += stat(c0) + stat(c1) + stat(c2) + stat(c3);
+                }
+            }
+            if ((tid & ~63) * per < nbp) {                                                    // waves with work (uniform per wave)
+                const uint32_t tot = (uint32_t)wave_sum((int)acc);
+                if ((tid & 63) == 0 && tot) atomicAdd(&s_dcnt[d + 1], tot);
+            }
+            __syncthreads();
+        }
+        if (tid < 64) {
+            const uint32_t acc = (uint32_t)wave_sum((int)(tid < nIni ? stat(hist[hoff(0) + tid]) : 0u));
+            if (tid == 0) s_dcnt[0] = acc;
+        }
+        __syncthreads();
+        QT_MARK(30);
+        // ---- phase 1 in closed form (:246-313): sizes after every pass from the per-depth sums
+        int P = 0;
+        {
+            int A[8], F[8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const uint32_t v = d <= DH ? s_dcnt[d] : 0u, u = (d >= 1 && d <= DH) ? s_dcnt[d - 1] : 0u;
+                A[d] = (int)(v & 0xFFFF) - (int)(u >> 16); F[d] = (int)(v >> 16) - (int)(u >> 16);
+            }
+            S = A[0];
+            int fsum = 0, prevS = A[0];
+#pragma unroll
+            for (int p = 1; p <= 6; p++) {
+                if (p <= DH && !finished && !phase2 && P == p - 1) {
+                    if (A[p - 1] - F[p - 1] == 0) finished = true;                          // no multi-point node: the pass changes nothing (:309)
+                    else {
+                        fsum += F[p - 1];
+                        S = A[p] + fsum; P = p; T_prev = A[p];
+                        if (S >= N || S == prevS) finished = true;
+                        else if (S + 3 * (A[p] - F[p]) > N) phase2 = true;
+                        prevS = S;
+                    }
+                }
+            }
+        }
+        QT_MARK(31);
+        if (S > QT_M) { if (tid == 0) *out_n = 0; return; }                                    // cannot happen for quota + 8 <= QT_M (host checks)
+        // ---- the list after pass P: R_P ++ finals(R_{P-1}) ++ ... ++ finals(R_0) by ONE scan over the concatenated cell sequences; R_d walks
+        //      the depth-d cells with the root order reversed when d is odd and the digits at even distance from the last one complemented.
+        //      Depths >= 2: a thread takes 16 consecutive elements = one aligned block of 16 cells (element k <-> cell k ^ 3 of the block),
+        //      read with two 16-byte loads + the four parents; depths 1 and 0: a thread per element.
+        {
+            const QtNodes C = view(cur);
+            // which piece of the concatenation is this thread's?
+            int d = -1, j = 0, single = 0;                                                    // depth, block (or element) index inside the segment
+            {
+                int t = tid;
+                for (int dd = P; dd >= 0 && d < 0; dd--) {
+                    const int nb = nIni << (2 * dd), units = dd >= 2 ? nb >> 4 : nb;
+                    if (t < units) { d = dd; j = t; single = dd < 2; }
+                    else t -= units;
+                }
+            }
+            uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };                                       // the block's 16 counts (u16 pairs)
+            uint32_t flags = 0;                                                               // bit k: element k of this thread's piece is in the list
+            int bblock = 0;
+            if (d >= 2) {
+                const int sh = 2 * d, i0 = j << 4;
+                const int rr = i0 >> sh, r = (d & 1) ? nIni - 1 - rr : rr;
+                bblock = ((r << sh) | ((i0 & ((1 << sh) - 1)) ^ (0x330 & ((1 << sh) - 1)))) >> 4;
+                const uint4 qa = *reinterpret_cast<const uint4*>(&hist[hoff(d) + 16 * bblock]), qb = *reinterpret_cast<const uint4*>(&hist[hoff(d) + 16 * bblock + 8]);
+                const uint2 qp = *reinterpret_cast<const uint2*>(&hist[hoff(d - 1) + 4 * bblock]);
+                w[0] = qa.x; w[1] = qa.y; w[2] = qa.z; w[3] = qa.w; w[4] = qb.x; w[5] = qb.y; w[6] = qb.z; w[7] = qb.w;
+                const uint32_t par[4] = { qp.x & 0xFFFF, qp.x >> 16, qp.y & 0xFFFF, qp.y >> 16 };
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int kk = k ^ 3;
+                    const uint32_t c = (w[kk >> 1] >> (16 * (kk & 1))) & 0xFFFF;
+                    if (c > 0 && par[kk >> 2] > 1 && (d == P || c == 1)) flags |= 1u << k;
+                }
+            } else if (d >= 0) {
+                const int sh = 2 * d;
+                const int rr = j >> sh, r = (d & 1) ? nIni - 1 - rr : rr;
+                bblock = (r << sh) | ((j & ((1 << sh) - 1)) ^ (0x3 & ((1 << sh) - 1)));      // the cell itself
+                const uint32_t c = hist[hoff(d) + bblock];
+                const bool ex = c > 0 && (d == 0 || hist[hoff(0) + (bblock >> 2)] > 1);
+                w[0] = c;
+                if (ex && (d == P || c == 1)) flags = 1u;
+            }
+            int tot; int pre = block_scan_excl(__popc(flags), s_wave, sflip, tot);
+            if (single) { if (flags) { C.ekey[pre] = (uint16_t)((d << 13) | bblock); C.cnt[pre] = w[0]; } }
+            else if (flags) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (flags & (1u << k)) {
+                        const int kk = k ^ 3;
+                        C.ekey[pre] = (uint16_t)((d << 13) | (16 * bblock + kk)); C.cnt[pre] = (w[kk >> 1] >> (16 * (kk & 1))) & 0xFFFF; pre++;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- point domain from the start: roots (:183-225): count, drop empty ones, keep list order = root order
+        const QtNodes C = view(0);
+        for (int i = tid; i < nIni; i += QT_T) ccount[i] = 0;
+        __syncthreads();
+        for (int p = tid; p < n; p += QT_T) {
+            int x = ld_xy(p) & 0xFFFF;
+            int r = (int)((float)x / hX);               // vpIniNodes[kp.pt.x/hX]
+            r = min(r, nIni - 1);
+            wave_agg_inc(ccount, r, true);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int Sr = 0;
+            for (int i = 0; i < nIni; i++) {
+                if (ccount[i] > 0) {
+                    C.x0[Sr] = (int16_t)(int)(hX * (float)i);
+                    C.x1[Sr] = (int16_t)(int)(hX * (float)(i + 1));
+                    C.y0[Sr] = 0; C.y1[Sr] = (int16_t)L.qt_h;
+                    C.cnt[Sr] = ccount[i];
+                    new_index[i] = (uint16_t)Sr;
+                    Sr++;
+                }
+            }
+            s_misc[0] = Sr;
+        }
+        __syncthreads();
+        for (int p = tid; p < n; p += QT_T) {
+            int x = ld_xy(p) & 0xFFFF;
+            int r = min((int)((float)x / hX), nIni - 1);
+            st_node(p, new_index[r]);
+        }
+        S = s_misc[0];
         __syncthreads();
     }
     QT_MARK(5);
     // ---- main loop
     for (int iter = 0; iter < 64 && !finished; iter++) {
-        QtNodes& C = nodes[cur];
-        QtNodes& X = nodes[cur ^ 1];
+        // leave the count domain when a node that may be split has no children in the pyramid: label the points, build the rectangles
+        if (cm && (!phase2 || (T_prev > 0 && (int)(s_ekey[cur][0] >> 13) >= DH))) {
+            const QtNodes C = view(cur);
+            relabel_from_keys(C);                       // the pyramid is dead from here on: its LDS becomes the rectangles
+            for (int i = tid; i < S; i += QT_T) {
+                const int ek = C.ekey[i], d = ek >> 13, g = ek & 0x1FFF, r = g >> (2 * d);
+                int x0 = (int16_t)(int)(hX * (float)r), x1 = (int16_t)(int)(hX * (float)(r + 1)), y0 = 0, y1 = (int16_t)L.qt_h;
+                for (int j = d - 1; j >= 0; j--) {
+                    const int c = (g >> (2 * j)) & 3;
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                    if (c & 1) x0 = mx; else x1 = mx;
+                    if (c & 2) y0 = my; else y1 = my;
+                }
+                C.x0[i] = (int16_t)x0; C.x1[i] = (int16_t)x1; C.y0[i] = (int16_t)y0; C.y1[i] = (int16_t)y1;
+            }
+            __syncthreads();
+            cm = false;
+        }
+        const QtNodes C = view(cur);
+        const QtNodes X = view(cur ^ 1);
         const int prevSize = S;
         int E;               // number of nodes considered for splitting this pass
 
@@ -388,7 +494,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 flags[k] = (i < S && C.cnt[i] > 1) ? 1 : 0;
                 local += flags[k];
             }
-            int tot; int pre = block_scan_excl(local, s_wave, tot);
+            int tot; int pre = block_scan_excl(local, s_wave, sflip, tot);
 #pragma unroll
             for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
                 int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
@@ -399,39 +505,64 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             }
             E = tot;
         } else {
-            // multi-point nodes created by the previous pass, sorted by (size desc, list index asc) (:321-325, D1)
+            // multi-point nodes created by the previous pass, sorted by (size desc, list index asc) (:321-325, D1): rank = number of candidates
+            // that go first.  All 1024 threads: candidate i = t % W is compared against the G-th part of the list by thread t, the partial
+            // ranks meet in LDS (the child-index array is free here).
+            uint32_t* const rank_acc = reinterpret_cast<uint32_t*>(child_index);      // [T_prev]
+            uint32_t* const okey = ccount;                                             // [T_prev + 3] count << 16 | ~index: j goes before i <=> okey[j] > okey[i]
             for (int i = tid; i < S; i += QT_T) proc_rank[i] = -1;
-            __syncthreads();
-            int tot_local = 0;
-            for (int i = tid; i < T_prev; i += QT_T) {
-                uint32_t ci = C.cnt[i];
-                if (ci > 1) {
-                    int r = 0;
-                    const uint4* c4 = reinterpret_cast<const uint4*>(C.cnt);          // four counts per LDS read
-                    int j = 0;
-                    for (; j + 4 <= T_prev; j += 4) {
-                        const uint4 q = c4[j >> 2];
-                        r += (q.x > 1) && (q.x > ci || (q.x == ci && j < i));
-                        r += (q.y > 1) && (q.y > ci || (q.y == ci && j + 1 < i));
-                        r += (q.z > 1) && (q.z > ci || (q.z == ci && j + 2 < i));
-                        r += (q.w > 1) && (q.w > ci || (q.w == ci && j + 3 < i));
-                    }
-                    for (; j < T_prev; j++) {
-                        uint32_t cj = C.cnt[j];
-                        r += (cj > 1) && (cj > ci || (cj == ci && j < i));
-                    }
-                    proc_rank[i] = (int16_t)r; order_node[r] = (int16_t)i;
-                    tot_local++;
-                }
+            for (int i = tid; i < T_prev + 3; i += QT_T) {
+                if (i < T_prev) { rank_acc[i] = 0; okey[i] = (min(C.cnt[i], 0xFFFFu) << 16) | (0xFFFFu - (uint32_t)i); }
+                else okey[i] = 0;                                                      // padding of the last group of four
             }
-            int tot; block_scan_excl(tot_local, s_wave, tot);
-            E = tot;
+            if (tid == 0) s_misc[2] = 0;
+            __syncthreads();
+            const int W = T_prev, G = (W > 0 && W <= QT_T / 2) ? QT_T / W : 1;        // G threads per candidate
+            const int part = (((W + G - 1) / G) + 3) & ~3;                             // list entries per thread, a multiple of 4
+            int mine = 0;
+            for (int i0 = 0; i0 < W; i0 += QT_T) {
+                const int i = G > 1 ? tid % W : i0 + tid, g = G > 1 ? tid / W : 0;
+                if (i < W && g < G) {
+                    const uint32_t ki = okey[i];
+                    if (ki >= (2u << 16)) {                                            // a multi-point node
+                        const int j0 = g * part, j1 = min((W + 3) & ~3, j0 + part);
+                        int r = 0;
+                        const uint4* k4 = reinterpret_cast<const uint4*>(okey);       // four keys per LDS read
+                        for (int j = j0; j < j1; j += 4) {
+                            const uint4 q = k4[j >> 2];
+                            r += (q.x > ki) + (q.y > ki) + (q.z > ki) + (q.w > ki);
+                        }
+                        if (G > 1) { if (r) atomicAdd(&rank_acc[i], (uint32_t)r); } else rank_acc[i] = (uint32_t)r;
+                        mine += g == 0;
+                    }
+                }
+                if (G > 1) break;
+            }
+            {   // number of candidates
+                const unsigned long long bal = __ballot(mine > 0);
+                int cntw = mine;
+                if (W > QT_T) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) cntw += __shfl_xor(cntw, o, 64);
+                } else cntw = (int)__popcll(bal);
+                if ((tid & 63) == 0 && cntw) atomicAdd(&s_misc[2], cntw);
+            }
+            __syncthreads();
+            for (int i = tid; i < W; i += QT_T)
+                if (C.cnt[i] > 1) { const int r = (int)rank_acc[i]; proc_rank[i] = (int16_t)r; order_node[r] = (int16_t)i; }
+            E = s_misc[2];
         }
         __syncthreads();
         QT_MARK(10 + (phase2 ? 100 : 0));
         if (E == 0) break;                          // nothing can be split: size == prevSize (:309,374)
 
         // -- count the four children of every candidate node
+        if (cm) {                                   // count domain: read them from the pyramid
+            for (int i = tid; i < 4 * E; i += QT_T) {
+                const int ek = C.ekey[order_node[i >> 2]], d = ek >> 13, g = ek & 0x1FFF;
+                ccount[i] = hist[hoff(d + 1) + 4 * g + (i & 3)];
+            }
+        } else {
         for (int i = tid; i < 4 * E; i += QT_T) ccount[i] = 0;
         __syncthreads();
         if (in_lds) {
@@ -460,68 +591,75 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 }
             }
         }
+        }
         __syncthreads();
 
         QT_MARK(11);
-        // -- how many of them are actually split this pass
-        int P = E;
-        if (phase2) {
-            // size after splitting the first k nodes = S + sum_{i<k}(children_i - 1); stop at the first k with size >= N
-            int local = 0; int add[(QT_M + QT_T - 1) / QT_T];
-#pragma unroll
-            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
-                int r = tid * ((QT_M + QT_T - 1) / QT_T) + k;
-                int a = 0;
-                if (r < E) a = (ccount[4 * r] > 0) + (ccount[4 * r + 1] > 0) + (ccount[4 * r + 2] > 0) + (ccount[4 * r + 3] > 0) - 1;
-                add[k] = a; local += a;
-            }
-            int tot; int pre = block_scan_excl(local, s_wave, tot);
-            if (tid == 0) s_misc[1] = E;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
-                int r = tid * ((QT_M + QT_T - 1) / QT_T) + k;
-                if (r < E) {
-                    int before = S + pre, after = before + add[k];
-                    if (before < N && after >= N) s_misc[1] = r + 1;      // unique r: size is non-decreasing
-                    pre = after - S;
-                }
-            }
-            __syncthreads();
-            P = s_misc[1];
-        }
-
-        QT_MARK(12);
-        // -- lay out the next list: children of processed nodes in reverse creation order, then survivors
-        int T, nToExpand;
+        // -- how many of them are split this pass, and where their children go: ONE scan over the candidates in processing order of
+        //    (occupied children | children with more than one point << 16).  Phase 2 stops at the first k whose split takes the list to >= N
+        //    nodes: size after the first k splits = S + sum_{r<k} (children_r - 1).  Children sit at the front of the next list in reverse
+        //    creation order.
+        int P = E, T, nToExpand;
         {
-            int local = 0, lexp = 0;
-            int fl[4 * ((QT_M + QT_T - 1) / QT_T)];
+            constexpr int RPT = (QT_M + QT_T - 1) / QT_T;
+            uint32_t nc[RPT], local = 0;
+            uint4 cc4[RPT];
 #pragma unroll
-            for (int k = 0; k < 4 * ((QT_M + QT_T - 1) / QT_T); k++) {
-                int i = tid * (4 * ((QT_M + QT_T - 1) / QT_T)) + k;
-                uint32_t cc = (i < 4 * P) ? ccount[i] : 0;
-                fl[k] = cc > 0; local += fl[k]; lexp += cc > 1;
+            for (int k = 0; k < RPT; k++) {
+                const int r = tid * RPT + k;
+                cc4[k] = r < E ? *reinterpret_cast<const uint4*>(&ccount[4 * r]) : make_uint4(0, 0, 0, 0);
+                nc[k] = (cc4[k].x > 0) + (cc4[k].y > 0) + (cc4[k].z > 0) + (cc4[k].w > 0) + (((cc4[k].x > 1) + (cc4[k].y > 1) + (cc4[k].z > 1) + (cc4[k].w > 1)) << 16);
+                local += nc[k];
             }
-            int pre = block_scan_excl(local, s_wave, T);
-            block_scan_excl(lexp, s_wave, nToExpand);
+            int tot; const int pre0 = block_scan_excl((int)local, s_wave, sflip, tot);
+            if (tid == 0) { s_misc[1] = E; s_misc[3] = tot; }
+            __syncthreads();
+            if (phase2) {
+                uint32_t pre = (uint32_t)pre0;
 #pragma unroll
-            for (int k = 0; k < 4 * ((QT_M + QT_T - 1) / QT_T); k++) {
-                int i = tid * (4 * ((QT_M + QT_T - 1) / QT_T)) + k;
-                if (i < 4 * P && fl[k]) {
-                    int pos = T - 1 - pre; pre++;
-                    child_index[i] = (uint16_t)pos;
-                    int nd = order_node[i >> 2], c = i & 3;
-                    int x0 = C.x0[nd], x1 = C.x1[nd], y0 = C.y0[nd], y1 = C.y1[nd];
-                    int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-                    if (pos < QT_M) {
-                        X.x0[pos] = (int16_t)((c & 1) ? mx : x0); X.x1[pos] = (int16_t)((c & 1) ? x1 : mx);
-                        X.y0[pos] = (int16_t)((c & 2) ? my : y0); X.y1[pos] = (int16_t)((c & 2) ? y1 : my);
-                        X.cnt[pos] = ccount[i];
+                for (int k = 0; k < RPT; k++) {
+                    const int r = tid * RPT + k;
+                    if (r < E) {
+                        const int before = S + (int)(pre & 0xFFFF) - r, after = before + (int)(nc[k] & 0xFFFF) - 1;
+                        pre += nc[k];
+                        if (before < N && after >= N) { s_misc[1] = r + 1; s_misc[3] = (int)pre; }      // unique r: the size never decreases
                     }
                 }
+                __syncthreads();
+            }
+            P = s_misc[1];
+            T = s_misc[3] & 0xFFFF; nToExpand = s_misc[3] >> 16;
+            uint32_t pre = (uint32_t)pre0;
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int r = tid * RPT + k;
+                if (r < P) {
+                    const int nd = order_node[r];
+                    int ci = (int)(pre & 0xFFFF);
+                    const uint32_t cv[4] = { cc4[k].x, cc4[k].y, cc4[k].z, cc4[k].w };
+                    int ek = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0, mx = 0, my = 0;
+                    if (cm) ek = C.ekey[nd];
+                    else { x0 = C.x0[nd]; x1 = C.x1[nd]; y0 = C.y0[nd]; y1 = C.y1[nd]; mx = x0 + ((x1 - x0 + 1) >> 1); my = y0 + ((y1 - y0 + 1) >> 1); }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (cv[c] > 0) {
+                            const int pos = T - 1 - ci; ci++;
+                            child_index[4 * r + c] = (uint16_t)pos;
+                            if (pos < QT_M) {
+                                X.cnt[pos] = cv[c];
+                                if (cm) X.ekey[pos] = (uint16_t)((((ek >> 13) + 1) << 13) | (4 * (ek & 0x1FFF) + c));
+                                else {
+                                    X.x0[pos] = (int16_t)((c & 1) ? mx : x0); X.x1[pos] = (int16_t)((c & 1) ? x1 : mx);
+                                    X.y0[pos] = (int16_t)((c & 2) ? my : y0); X.y1[pos] = (int16_t)((c & 2) ? y1 : my);
+                                }
+                            }
+                        }
+                    }
+                }
+                pre += nc[k];
             }
         }
+        QT_MARK(12);
         int nsurv;
         {
             int local = 0; int fl[(QT_M + QT_T - 1) / QT_T];
@@ -532,7 +670,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 fl[k] = (i < S) && !(r >= 0 && r < P);
                 local += fl[k];
             }
-            int pre = block_scan_excl(local, s_wave, nsurv);
+            int pre = block_scan_excl(local, s_wave, sflip, nsurv);
 #pragma unroll
             for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++) {
                 int i = tid * ((QT_M + QT_T - 1) / QT_T) + k;
@@ -540,8 +678,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                     int pos = T + pre; pre++;
                     new_index[i] = (uint16_t)pos;
                     if (pos < QT_M) {
-                        X.x0[pos] = C.x0[i]; X.x1[pos] = C.x1[i]; X.y0[pos] = C.y0[i]; X.y1[pos] = C.y1[i];
                         X.cnt[pos] = C.cnt[i];
+                        if (cm) X.ekey[pos] = C.ekey[i];
+                        else { X.x0[pos] = C.x0[i]; X.x1[pos] = C.x1[i]; X.y0[pos] = C.y0[i]; X.y1[pos] = C.y1[i]; }
                     }
                 }
             }
@@ -550,8 +689,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         if (T + nsurv > QT_M) { if (tid == 0) *out_n = 0; return; }     // cannot happen for quota+8 <= QT_M (host checks)
 
         QT_MARK(13);
-        // -- relabel the points
-        if (in_lds) {
+        // -- relabel the points (point domain; in the count domain the points keep their geometric keys until the end)
+        if (cm) {
+        } else if (in_lds) {
             int nd[QT_PTS / QT_T], rk[QT_PTS / QT_T];
 #pragma unroll
             for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; nd[k] = p < n ? (int)s_pnode[p] : 0; }
@@ -587,19 +727,29 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         if (S >= N || S == prevSize) break;
         if (!phase2 && (S + nToExpand * 3) > N) phase2 = true;
     }
+    if (cm) relabel_from_keys(view(cur));           // the distribution ended in the count domain: label the points now
 
     QT_MARK(3);
     // ---- keep the best point of every node (:381-400), emit in list order
     unsigned long long* best = reinterpret_cast<unsigned long long*>(ccount);      // QT_M * 8 bytes <= sizeof(ccount)
     for (int i = tid; i < S; i += QT_T) best[i] = 0ull;
     __syncthreads();
-    for (int p = tid; p < n; p += QT_T) {
-        uint32_t xy = ld_xy(p), sk = psk[p];
+    auto offer = [&](uint32_t xy, uint32_t sk, int node) {
         unsigned long long order = ((unsigned long long)(sk & 0xFFFFFFu) << 32) | xy;          // (cell, y, x)
         unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
-        atomicMax(&best[ld_node(p)], key);
+        atomicMax(&best[node], key);
+    };
+    if (in_lds) {
+        uint32_t sk[QT_PTS / QT_T];
+#pragma unroll
+        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; sk[k] = p < n ? psk[p] : 0u; }      // global loads, all in flight
+#pragma unroll
+        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) offer(s_pxy[p], sk[k], (int)s_pnode[p]); }
+    } else {
+        for (int p = tid; p < n; p += QT_T) offer(pxy[p], psk[p], (int)pnode[p]);
     }
     __syncthreads();
+    QT_MARK(40);
     for (int i = tid; i < S; i += QT_T) {
         if (i < L.sel_cap) {
             unsigned long long key = best[i];
@@ -611,6 +761,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
     }
     if (tid == 0) *out_n = min(S, L.sel_cap);
+    QT_MARK(41);
     // ---- spatial order of the kept keypoints for the describe stage: perm[rank] = list index, ranked by 64-px tile (row-major) and list
     //      index.  The describe kernel walks the keypoints of an image in this order (neighbouring patches share their 128-byte lines in one
     //      XCD's L2) but writes every result to its list-order slot, so the output order stays the reference's.
@@ -641,7 +792,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             int c[TPT], local = 0;
 #pragma unroll
             for (int k = 0; k < TPT; k++) { const int t = tid * TPT + k; c[k] = t < ntiles ? (int)tcnt[t] : 0; local += c[k]; }
-            int tot; int pre = block_scan_excl(local, s_wave, tot);
+            int tot; int pre = block_scan_excl(local, s_wave, sflip, tot);
 #pragma unroll
             for (int k = 0; k < TPT; k++) { const int t = tid * TPT + k; if (t < ntiles) tcnt[t] = (uint32_t)pre; pre += c[k]; }
             __syncthreads();
@@ -661,9 +812,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, hipStream_t s)
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, hipStream_t s)
 {
     dim3 grid(nlevels, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain);
 }

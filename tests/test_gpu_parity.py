@@ -192,7 +192,7 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
-@pytest.mark.parametrize("env", [{}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
+@pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
     """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, and NMS driven from the score
@@ -202,6 +202,34 @@ def test_fast_kernel_variants_in_subprocess(gpu, env):
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fast_variant_check.py")], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_quadtree_count_domain_and_its_fallbacks(gpu):
+    """DistributeOctTree in the count domain (histogram pyramid of the points' geometric keys, phase 1 in closed form) and every way out of it:
+    clustered corners that need nodes deeper than the pyramid (switch to the point-domain passes in the middle of the distribution), 3..8 root
+    nodes (pyramid depth 5), more than 8 root nodes (point domain from the start), quotas the first pass already exceeds, single-point roots"""
+    rng = np.random.default_rng(21)
+    frames = []
+    flat = np.full((480, 640), 90, np.uint8)
+    a = flat.copy(); a[200:290, 300:420] = rng.integers(0, 256, (90, 120), dtype=np.uint8)                      # one dense cluster
+    b = flat.copy()
+    for (y, x) in ((40, 50), (60, 500), (380, 90), (300, 330)):
+        b[y:y + 40, x:x + 56] = rng.integers(0, 256, (40, 56), dtype=np.uint8)                                   # four clusters, far apart
+    c = synth_image(5, 640, 480); c[100:160, 100:200] = rng.integers(0, 256, (60, 100), dtype=np.uint8)         # a scene with a hot spot
+    frames += [(a, 3000, 8), (a, 300, 8), (b, 2500, 8), (b, 40, 4), (c, 4000, 8), (c, 60, 8)]
+    frames += [(synth_image(31, 1200, 300), 1500, 6), (synth_image(32, 1500, 220), 900, 4), (synth_image(33, 1900, 200), 1200, 3)]   # 4, 7 and 11 roots
+    d = flat.copy(); d[100:104, 100:104] = 255; d[300:304, 500:504] = 0                                          # a handful of corners: single-point roots
+    frames += [(d, 500, 3), (rng.integers(0, 256, (300, 420), dtype=np.uint8), 5000, 5)]
+    for img, nf, nl in frames:
+        p = oracle.default_params(nf); p.nlevels = nl
+        s = settings(nf); s.nLevels = nl
+        ex = HS.ORBExtractor(s)
+        ok, od = oracle.extract(p, img)
+        gk, gd = ex(img)
+        assert_same_features(gk, gd, ok, od)
+        for l in range(nl):                                        # the selection of every level, in list order
+            assert len(ex.debug_selected(0, l)) == (ok["octave"] == l).sum(), (img.shape, nf, l)
+    assert len(ok) > 0
 
 
 def test_batch_equals_singles_and_is_deterministic(gpu):
