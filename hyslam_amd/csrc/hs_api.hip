@@ -40,7 +40,7 @@ struct hs_orb {
     uint32_t* d_fast_ovf = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
-    uint32_t *d_cand_xy = nullptr, *d_cand_sk = nullptr, *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
+    uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
     int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
     uint32_t* d_sel = nullptr;
     uint16_t* d_sel_perm = nullptr;    // spatial order of every level's selection (describe stage)
@@ -106,8 +106,8 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_tables); h->d_tables = nullptr;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
-    hipFree(h->d_cand_xy); hipFree(h->d_cand_sk); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
-    h->d_cand_xy = h->d_cand_sk = h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
+    hipFree(h->d_cand); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
+    h->d_cand = nullptr; h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
     hipFree(h->d_sel); h->d_sel = nullptr;
     hipFree(h->d_sel_perm); h->d_sel_perm = nullptr;
@@ -212,8 +212,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     HIP_TRY(h, hipMalloc(&h->d_tables, std::max<size_t>(tables.size() * sizeof(int16_t), 256)));
     if (!tables.empty()) HIP_TRY(h, hipMemcpy(h->d_tables, tables.data(), tables.size() * sizeof(int16_t), hipMemcpyHostToDevice));
     const size_t ce = std::max<uint64_t>(cand * batch, 64);
-    HIP_TRY(h, hipMalloc(&h->d_cand_xy, ce * 4));
-    HIP_TRY(h, hipMalloc(&h->d_cand_sk, ce * 4));
+    HIP_TRY(h, hipMalloc(&h->d_cand, ce * 8));
     HIP_TRY(h, hipMalloc(&h->d_pts_xy, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_pts_sk, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_pt_node, ce * 2));
@@ -320,7 +319,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     {   // launch N uses work-queue counter set N & 1 and relies on launch N - 1 having zeroed it: the epoch advances only when a launch was
         // enqueued without error; after a failed launch both sets are zeroed again so that the next one starts from a known state
         const bool launched = hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                                             h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs, s);
+                                             h->d_cand, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs, s);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             (void)hipMemsetAsync(h->d_fast_ovf, 0, 2 * HS_FAST_QUEUE_DWORDS * 4, s);
@@ -329,7 +328,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         if (launched) h->fast_epoch++;
     }
     mark(h, 2, s);
-    hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand_xy, h->d_cand_sk, h->d_cell_count, h->cand_img_stride,
+    hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
                        h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0, s);
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->d_sel_perm, h->sel_img_stride, h->max_kp,

@@ -133,12 +133,12 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[su
 struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
-                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                    uint2* cand /*{y<<16|x, score<<24|cell} per slot*/, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
                     const HsFastKnobs& knobs, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
-                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
+                        const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, hipStream_t s);
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,

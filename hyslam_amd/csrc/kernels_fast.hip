@@ -27,11 +27,11 @@
 // corners to a per-wave area in global memory; they come back into the score tile before the NMS, which then walks the non-zero
 // bytes of the tile instead of the list.  Saturated images stay correct and merely lose batching.  Work distribution, geometry table
 // and LDS budget: see the kernel and its launcher.
-// Output: each cell owns a fixed slot range (no global atomics), filled in NO particular order (the quadtree kernel orders a cell's
-// records by (y, x), which is cv::FAST's scan order, when it gathers them):
-//   cand_xy[cell slot] = y<<16 | x         (coordinates relative to (16,16), as in vToDistributeKeys)
-//   cand_sk[cell slot] = score<<24 | cell  (cell = row-major cell index of the level)
-//   cell_count[image][global cell] = number of slots used.
+// Output: each ITEM owns a fixed slot range (the slots of its cells, contiguous; no global atomics), filled from its first slot upwards in NO
+// particular order — every order-dependent decision downstream uses the (cell, y, x) key of the reference's candidate order:
+//   cand[slot] = { y<<16 | x,  score<<24 | cell }   (coordinates relative to (16,16), as in vToDistributeKeys; cell = row-major cell index
+//                                                    of the level); one 8-byte store per survivor, ~20 records = two cache lines per item
+//   cell_count[image][first global cell of the item] = number of slots used (the entries of the item's other cells are not written).
 // Bound: instruction issue (integer VALU + LDS byte reads); HBM bytes = P per frame.
 #include "hs_internal.h"
 #include <algorithm>
@@ -175,7 +175,7 @@ __device__ __forceinline__ int wave_scan_incl(int x)
 // TR = tile rows held in LDS (6 + 8*RS*blocks); the item's tile (th <= TR rows) is fetched with 16-byte loads, 64/LPR rows per load
 template <int LC, int TR>
 __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
-                                                  uint32_t* __restrict__ cand_xy, uint32_t* __restrict__ cand_sk,
+                                                  uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
                                                   uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch)
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     for (; w >= 0;) {
         int32_t* const cnt_out = &cell_count[(size_t)g.img * total_cells + g.gcell0];
         if (!g.valid) {
-            if (tid < g.ncell) cnt_out[tid] = 0;
+            if (tid == 0) cnt_out[0] = 0;
             w = resolve(raw_next);
             if (w >= 0) { g = row_geom(items, img0, items_per_img, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
             continue;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_T(t1);
         FR_ACC(0, t0, t1);
         const RowGeom cur = g;
-        const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1, ccap = cur.ccap;
+        const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1;
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
         // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
         const int w_next = resolve(raw_next);
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         int npx = 0;                                             // wave-uniform list length
         int n_done = 0, n_ovf = 0;                               // scored corners at the head of the list (entries [n_done, npx) are scan codes); corners spilled
+        int n_emit = 0;                                          // survivors of the item so far (wave-uniform)
 
         // ---- pixel list -> corners -> scores
         // ---- scan codes [n_done, npx) of the list -> corners -> scores; the scored corners stay at the head of the list
@@ -402,13 +403,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 // all eight neighbours are read before any is compared (&&-chains compile to eight dependent LDS round trips)
                 const int n0 = p[-PITCH - 1], n1 = p[-PITCH], n2 = p[-PITCH + 1], n3 = p[-1], n4 = p[1], n5 = p[PITCH - 1], n6 = p[PITCH], n7 = p[PITCH + 1];
                 const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-                if (act & (s > nmax)) {
+                const bool keep = act & (s > nmax);
+                const int slot = wave_append(keep, n_emit);     // one running count per ITEM: its records are contiguous from slot0
+                if (keep) {
                     const int gc = ((sc - 1) * inv_w1) >> 16;
                     const int px = sc - 1 - gc;                  // interior column within the item
-                    const uint32_t slot = atomicAdd(&cellcnt[gc], 1u);
-                    const size_t o = slot_base + (size_t)gc * ccap + slot;
-                    cand_xy[o] = ((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff);
-                    cand_sk[o] = ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc);
+                    cand[slot_base + (size_t)slot] = make_uint2(((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff),
+                                                        ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc));
                 }
             }
             npx = 0;
@@ -529,8 +530,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_FENCE();
         FR_T(t5);
         FR_ACC(6, t4, t5);
-        // ---- per-cell counts; reset the counters
-        if (tid < cur.ncell) cnt_out[tid] = (int32_t)cellcnt[tid];
+        // ---- the item's count (kept at its first cell's entry); reset the counter
+        if (tid == 0) cnt_out[0] = (int32_t)n_emit;
         FR_FENCE();
         if (tid < FR_MAXG) cellcnt[tid] = 0;
 #ifdef HS_FAST_PROFILE
@@ -655,7 +656,7 @@ size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKno
 }
 
 static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
-                             uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                             uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
                              int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)max_wcell;
@@ -666,7 +667,7 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
-#define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand_xy, cand_sk, \
+#define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
@@ -677,10 +678,10 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 // returns whether a kernel was enqueued: a launch consumes one work-queue counter set (`epoch` & 1) and zeroes it for the launch after next,
 // so the caller advances its epoch only for launches that happened
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
-                    uint32_t* cand_xy, uint32_t* cand_sk, int32_t* cell_count, uint64_t cand_img_stride,
+                    uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0) return false;
-    return launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand_xy, cand_sk, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
+    return launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
 }

@@ -36,7 +36,7 @@
 //     A node deeper than the pyramid (clustered points), more than 8 root nodes or more than 65535 points fall back to the point-domain
 //     passes (sweeps with LDS atomics), which remain the general algorithm.
 //
-// Inputs are the per-cell candidate slots written by k_fast_rows (gathered into a dense list first; its order is irrelevant: every
+// Inputs are the per-item candidate slots written by k_fast_rows (gathered into a dense list first; its order is irrelevant: every
 // order-dependent decision uses the (cell, y, x) key of the reference's candidate order).  Outputs per (image, level):
 // selected (x,y,score) in final list order + count.  Bound: LDS latency / barriers; HBM traffic negligible.
 #include "hs_internal.h"
@@ -117,7 +117,7 @@ extern "C" void hs_debug_qt_profile(unsigned long long* out128) { (void)hipDevic
 #define QT_MARK(tag)
 #endif
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
-                                                   const uint32_t* __restrict__ cand_xy, const uint32_t* __restrict__ cand_sk,
+                                                   const uint2* __restrict__ cand,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
@@ -128,9 +128,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     __shared__ uint32_t s_cnt[2][QT_M];            // points per node
     __shared__ uint16_t s_ekey[2][QT_M];           // count domain: depth << 13 | cell index at that depth (root * 4^depth + path)
     __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
-    __shared__ int16_t proc_rank[QT_M];            // processing rank of a node in this pass, -1 = not split
-    __shared__ int16_t order_node[QT_M];           // rank -> node
-    __shared__ uint16_t new_index[QT_M];           // surviving node -> index in the next list
+    __shared__ alignas(16) int16_t s_idx3[3 * QT_M];   // three per-node index arrays (12 KB, idle during the gather: the geometric-key tables live here then)
+    int16_t* const proc_rank = s_idx3;                                                  // processing rank of a node in this pass, -1 = not split
+    int16_t* const order_node = s_idx3 + QT_M;                                          // rank -> node
+    uint16_t* const new_index = reinterpret_cast<uint16_t*>(s_idx3 + 2 * QT_M);         // surviving node -> index in the next list
     __shared__ uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
     __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node (count domain: their geometric key), when there
     __shared__ uint16_t s_pnode[QT_PTS];           // are <= QT_PTS of them: every sweep walks the points from LDS instead of through L2
@@ -161,9 +162,45 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     const int DH = nIni <= 2 ? 6 : 5;
     uint16_t* const hist = reinterpret_cast<uint16_t*>(s_rect);
     auto hoff = [&](int d) { return nIni * (((1 << (2 * DH + 2)) - (1 << (2 * d + 2))) / 3); };     // entries of the levels deeper than d
-    // geometric key of a point: root << 2 DH | its DivideNode decisions down to depth DH (:121-177, :209)
+    // geometric key of a point: root << 2 DH | its DivideNode decisions down to depth DH (:121-177, :209).  DivideNode halves x and y
+    // independently, so the key is the bit-interleave of two one-dimensional cell indices: TABLES (a byte per pixel column of every root and
+    // per pixel row, built once per workgroup in LDS that is idle during the gather) replace the six-step descent per point; the root comes
+    // from comparisons with the first column that the reference's float division assigns to each root.
+    uint8_t* const xtab = reinterpret_cast<uint8_t*>(s_idx3);             // [qt_w + 1] cell index along x within the column's root
+    uint8_t* const ytab = xtab + 8192;                                   // [qt_h + 1]
+    __shared__ int s_rbound[8];                                          // first x of root i (i >= 1)
+    static_assert(sizeof(s_idx3) >= 8192 + 4096, "geometric-key tables");
+    const bool use_tab = cf_geom && L.qt_w < 8192 && L.qt_h < 4096;
+    auto descend = [&](int x, int x0, int x1) {                          // the DH halvings of [x0, x1) that contain x -> cell index
+        int idx = 0;
+        for (int d = 0; d < DH; d++) {
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            if (x < mx) { x1 = mx; idx = 2 * idx; } else { x0 = mx; idx = 2 * idx + 1; }
+        }
+        return idx;
+    };
+    auto root_of = [&](int x) { return min((int)((float)x / hX), nIni - 1); };      // vpIniNodes[kp.pt.x/hX]
+    if (use_tab) {
+        if (tid >= 1 && tid < nIni) {                                    // smallest x that lands in root tid: around tid * hX
+            int bnd = (int)(hX * (float)tid);
+            while (bnd > 0 && root_of(bnd - 1) >= tid) bnd--;
+            while (root_of(bnd) < tid) bnd++;
+            s_rbound[tid] = bnd;
+        }
+        for (int x = tid; x <= L.qt_w; x += QT_T) {
+            const int r = root_of(x);
+            xtab[x] = (uint8_t)descend(x, (int16_t)(int)(hX * (float)r), (int16_t)(int)(hX * (float)(r + 1)));
+        }
+        for (int y = tid; y <= L.qt_h; y += QT_T) ytab[y] = (uint8_t)descend(y, 0, (int16_t)L.qt_h);
+    }
+    auto spread = [](uint32_t v) { v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u; return v; };   // bit i -> bit 2i
     auto geo_key = [&](int x, int y) {
-        const int r = min((int)((float)x / hX), nIni - 1);                      // vpIniNodes[kp.pt.x/hX]
+        if (use_tab) {
+            int r = 0;
+            for (int i = 1; i < nIni; i++) r += x >= s_rbound[i];
+            return (int)(((uint32_t)r << (2 * DH)) | spread(xtab[min(x, L.qt_w)]) | (spread(ytab[min(y, L.qt_h)]) << 1));
+        }
+        const int r = root_of(x);
         int x0 = (int16_t)(int)(hX * (float)r), x1 = (int16_t)(int)(hX * (float)(r + 1)), y0 = 0, y1 = (int16_t)L.qt_h;
         int path = 0;
         for (int d = 0; d < DH; d++) {
@@ -183,22 +220,19 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     __syncthreads();
     QT_MARK(20);
 
-    // ---- gather this level's candidates from the per-cell slots the FAST kernel filled into one dense list (its order is irrelevant).
-    // Up to 4 * QT_T cells per round: a thread per 4 cells for the counts and the block-wide exclusive scan, then one thread per RECORD
-    // (the high pyramid levels have few cells with many records each).  In the count domain the same thread computes the point's geometric
-    // key and adds it to the histogram.  The child-count / index arrays are not live yet: their LDS is the scratch.
+    // ---- gather this level's candidates from the slot ranges the FAST kernel filled into one dense list (its order is irrelevant).
+    // The FAST kernel packs the survivors of one work ITEM (a group of <= 8 cells of one cell row) from the item's first slot upwards:
+    // ~20 records = two cache lines per item.  Per round of <= 1024 items: a thread per item for the count and the block-wide exclusive
+    // scan, then a thread per RECORD, which finds its item by binary search over the scan and fetches the record with one 8-byte load.
+    // In the count domain the same thread computes the point's geometric key and adds it to the histogram.
     int n = 0;
     {
-        uint16_t* const s_cell = reinterpret_cast<uint16_t*>(ccount);            // [QT_GKEYS]
-        uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [QT_T * CPT] exclusive offset of the round's cell
-        constexpr int QT_GKEYS = (int)(sizeof(ccount) / 2);
-        const int ncell = L.ncols * L.nrows;
+        uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [round items + 1] exclusive offsets of the round's items
+        static_assert(sizeof(child_index) >= (QT_T + 1) * 4, "s_pre scratch");
+        const int nitem = L.nrows * L.ngroups;
         const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
-        const uint32_t* sxy = cand_xy + (size_t)img * cand_img_stride + L.cand_off;
-        const uint32_t* ssk = cand_sk + (size_t)img * cand_img_stride + L.cand_off;
-        constexpr int CPT = 4;                                     // cells per thread and round: the counts of a round are independent loads
-        static_assert(sizeof(child_index) >= QT_T * CPT * 4, "s_pre scratch");
+        const uint2* src = cand + (size_t)img * cand_img_stride + L.cand_off;
         auto put = [&](int pos, uint32_t key, uint32_t sk) {
             pxy[pos] = key; psk[pos] = sk;
             if (pos < QT_PTS) s_pxy[pos] = key;
@@ -209,63 +243,73 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 atomicAdd(reinterpret_cast<uint32_t*>(s_rect) + (gk >> 1), 1u << ((gk & 1) * 16));
             }
         };
-        int cpt = CPT;
-        for (int c0 = 0; c0 < ncell;) {
-            // a round takes cpt cells per thread: as many as leave the round's records inside the scratch; the next round starts from the
-            // density this one found
-            int k[CPT], ksum, tot, pre;
-            for (;;) {
-                ksum = 0;
-#pragma unroll
-                for (int q = 0; q < CPT; q++) { const int c = c0 + tid * cpt + q; k[q] = (q < cpt && c < ncell) ? min(ccnt[c], ccap) : 0; ksum += k[q]; }
-                pre = block_scan_excl(ksum, s_wave, sflip, tot);
-                if (tot <= QT_GKEYS || cpt == 1) break;
-                cpt >>= 1;
+        for (int i0 = 0; i0 < nitem; i0 += QT_T) {
+            const int ni = min(QT_T, nitem - i0);
+            int k = 0, c0 = 0;
+            if (tid < ni) {                                        // item -> its first cell, its capacity
+                const int it = i0 + tid, ci = it / L.ngroups, gj = it - ci * L.ngroups;
+                c0 = ci * L.ncols + gj * L.grp_cells;
+                k = min(max(ccnt[c0], 0), min(L.grp_cells, L.ncols - gj * L.grp_cells) * ccap);
             }
-            QT_MARK(21);
-            const int round_cells = QT_T * cpt;
-            if (tot <= QT_GKEYS) {
+            int tot; const int pre = block_scan_excl(k, s_wave, sflip, tot);
+            if (tid < ni) s_pre[tid] = (uint32_t)pre;
+            if (tid == 0) s_pre[ni] = (uint32_t)tot;
+            __syncthreads();
+            QT_MARK(22);
+            // Every wave takes a CONTIGUOUS run of the round's records, 64 at a time: the item of a run's first record comes from one
+            // wave-uniform binary search, after that the item index only moves forward — a block of the next eight offsets is read at
+            // wave-uniform addresses (LDS broadcast, no bank conflicts) and every lane counts how many of them its record has passed.
+            // (A per-record binary search cost 10 dependent, scattered LDS reads per record: 6 600 cycles per 4 records.)
+            {
+                const int lane = tid & 63, wave = tid >> 6;
+                const int per_wave = ((tot + QT_T - 1) / QT_T) * 64;                  // a multiple of 64
+                const int e_begin = wave * per_wave, e_end = min(tot, e_begin + per_wave);
+                if (e_begin < e_end) {
+                    int cur = 0;
+                    { int lo = 0, hi = ni; for (int step = 0; step < 10; step++) { const int mid = (lo + hi) >> 1; if (hi - lo > 1) { if ((int)s_pre[mid] <= e_begin) lo = mid; else hi = mid; } } cur = lo; }
+                    for (int e0 = e_begin; e0 < e_end; e0 += 4 * 64) {               // four records per lane in flight
+                        int item[4];
 #pragma unroll
-                for (int q = 0; q < CPT; q++) {
-                    if (q < cpt) s_pre[tid * cpt + q] = (uint32_t)pre;
-                    for (int i = 0; i < k[q]; i++) s_cell[pre + i] = (uint16_t)(tid * cpt + q);
-                    pre += k[q];
-                }
-                __syncthreads();
-                QT_MARK(22);
-                for (int e0 = tid; e0 < tot; e0 += 4 * QT_T) {     // four records per thread in flight: the loads of all four before the first use
-                    uint32_t key[4], sk[4];
+                        for (int u = 0; u < 4; u++) {
+                            const int e = e0 + 64 * u + lane;
+                            const bool on = e0 + 64 * u < e_end;                     // wave-uniform
+                            const int e_last = min(e0 + 64 * u + 63, e_end - 1);
+                            int it = cur;
+                            if (on) {
+                                for (int base = cur;; base += 8) {
+                                    int c = 0, c_last = 0;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int e = e0 + u * QT_T;
-                        if (e < tot) {
-                            const int lc = s_cell[e];
-                            const size_t src = (size_t)(c0 + lc) * ccap + (e - (int)s_pre[lc]);
-                            key[u] = sxy[src]; sk[u] = ssk[src];
+                                    for (int j = 1; j <= 8; j++) { const int v = (int)s_pre[min(base + j, ni)]; c += v <= e; c_last += v <= e_last; }
+                                    it += c;
+                                    if (c_last < 8) { cur = base + c_last; break; }
+                                }
+                            }
+                            item[u] = it;
                         }
+                        QT_MARK(23);
+                        uint2 rec[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int e = e0 + 64 * u + lane;
+                            if (e < e_end) {
+                                const int itg = i0 + item[u], ci = itg / L.ngroups, gj = itg - ci * L.ngroups;
+                                rec[u] = src[(size_t)(ci * L.ncols + gj * L.grp_cells) * ccap + (e - (int)s_pre[item[u]])];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int e = e0 + 64 * u + lane; if (e < e_end) put(n + e, rec[u].x, rec[u].y); }
+                        QT_MARK(25);
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const int e = e0 + u * QT_T; if (e < tot) put(n + e, key[u], sk[u]); }
-                }
-                __syncthreads();                                   // the scratch is reused by the next round
-            } else {                                               // saturated image: more records than the scratch holds; one thread per cell
-#pragma unroll
-                for (int q = 0; q < CPT; q++) {                    // cpt == 1 here: k[1..] = 0
-                    const size_t src = (size_t)min(c0 + tid * cpt + q, ncell - 1) * ccap;
-                    for (int i = 0; i < k[q]; i++) put(n + pre + i, sxy[src + i], ssk[src + i]);
-                    pre += k[q];
                 }
             }
             n += tot;
-            c0 += round_cells;
+            __syncthreads();                                       // the scratch is reused by the next round
         }
-        __syncthreads();      // the dense list and the histogram are complete (written and read by this workgroup only)
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
     QT_MARK(1);
     const bool in_lds = n <= QT_PTS;               // uniform
     auto ld_xy = [&](int p) -> uint32_t { return in_lds ? s_pxy[p] : pxy[p]; };
-    auto ld_node = [&](int p) -> int { return in_lds ? (int)s_pnode[p] : (int)pnode[p]; };
     auto st_node = [&](int p, int v) { if (in_lds) s_pnode[p] = (uint16_t)v; else pnode[p] = (uint16_t)v; };
 
     if (n == 0 || nIni < 1 || nIni > QT_M / 4) { if (tid == 0) *out_n = 0; return; }
@@ -304,7 +348,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 #pragma unroll
             for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) s_pnode[p] = (uint16_t)node_of_key(gk[k]); }
         } else {
-            for (int p = tid; p < n; p += QT_T) pnode[p] = (uint16_t)node_of_key((int)pnode[p]);
+            for (int p0 = tid; p0 < n; p0 += 8 * QT_T) {              // points in global memory: eight loads in flight per thread
+                int gk[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; gk[k] = p < n ? (int)pnode[p] : 0; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; if (p < n) pnode[p] = (uint16_t)node_of_key(gk[k]); }
+            }
         }
         __syncthreads();
     };
@@ -746,7 +796,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 #pragma unroll
         for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) offer(s_pxy[p], sk[k], (int)s_pnode[p]); }
     } else {
-        for (int p = tid; p < n; p += QT_T) offer(pxy[p], psk[p], (int)pnode[p]);
+        for (int p0 = tid; p0 < n; p0 += 8 * QT_T) {                  // points in global memory: eight records in flight per thread
+            uint32_t xy[8], sk[8]; int nd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; const bool on = p < n; xy[k] = on ? pxy[p] : 0u; sk[k] = on ? psk[p] : 0u; nd[k] = on ? (int)pnode[p] : 0; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; if (p < n) offer(xy[k], sk[k], nd[k]); }
+        }
     }
     __syncthreads();
     QT_MARK(40);
@@ -810,11 +866,11 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 }
 
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
-                        const uint32_t* cand_xy, const uint32_t* cand_sk, const int32_t* cell_count, uint64_t cand_img_stride,
+                        const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, hipStream_t s)
 {
     dim3 grid(nlevels, batch, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand_xy, cand_sk, cell_count, cand_img_stride,
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
                        pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain);
 }
