@@ -88,6 +88,38 @@ __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict_
     *reinterpret_cast<uint32_t*>(drow + dx0) = packed;   // pitch is a multiple of 64: padding bytes may be written
 }
 
+// ---- the two passes of the LDS-staged kernels, written for the VALU (the kernels are bound by instruction issue, not by HBM):
+//   horizontal  H = S[sx]*a0 + S[sx+1]*a1 is needed as (H >> 4) in 16 bits.  The coefficient pair is pre-multiplied by 16 (a <= 2048, so
+//               16 a fits 16 bits), v_dot2_u32_u16 then yields H << 4 whose bytes 1..2 ARE (H >> 4) & 0xFFFF: one v_perm_b32 packs two of them.
+//               Per value: one v_perm (byte pair -> two 16-bit fields) + one v_dot2; per pair one more v_perm.  (Before: + a shift per value
+//               and a shift-or per pair.)
+//   vertical    ((b0*H0) >> 16) + ((b1*H1) >> 16) + 2) >> 2: two 24-bit multiplies, one v_perm that takes the high halves of both
+//               products, one v_dot2 against (1,1) with the rounding constant as its accumulator, one shift.
+typedef unsigned short hs_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pyr_hpair(uint32_t whi, uint32_t wlo, uint32_t sel0, uint32_t sel1, uint32_t coef0, uint32_t coef1)
+{
+    const uint32_t h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, sel0)), __builtin_bit_cast(hs_us2, coef0), 0u, false);
+    const uint32_t h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, sel1)), __builtin_bit_cast(hs_us2, coef1), 0u, false);
+    return __builtin_amdgcn_perm(h1, h0, 0x06050201u);         // (H1 >> 4) << 16 | (H0 >> 4)
+}
+__device__ __forceinline__ uint32_t pyr_vpix4(uint32_t h0, uint32_t h1, uint32_t b0, uint32_t b1)     // h0, h1: 16-bit values; returns 4 * pixel + (0..3)
+{
+    const uint32_t p0 = __umul24(h0, b0), p1 = __umul24(h1, b1);
+    const uint32_t hi = __builtin_amdgcn_perm(p1, p0, 0x07060302u);                                    // (p1 >> 16) << 16 | (p0 >> 16)
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, hi), __builtin_bit_cast(hs_us2, 0x00010001u), 2u, false);
+}
+__device__ __forceinline__ uint32_t pyr_vquad(uint2 H0, uint2 H1, uint32_t b0, uint32_t b1)
+{
+    const uint32_t v0 = pyr_vpix4(H0.x & 0xFFFFu, H1.x & 0xFFFFu, b0, b1), v1 = pyr_vpix4(H0.x >> 16, H1.x >> 16, b0, b1);
+    const uint32_t v2 = pyr_vpix4(H0.y & 0xFFFFu, H1.y & 0xFFFFu, b0, b1), v3 = pyr_vpix4(H0.y >> 16, H1.y >> 16, b0, b1);
+    // every value is < 1024: two per register as 16-bit fields, one packed shift for both, one byte permute for all four
+    uint32_t a = v0 | (v1 << 16), c = v2 | (v3 << 16), a2, c2;
+    const uint32_t two = 0x00020002u;                           // a shift count per 16-bit field (an inline constant would only reach the low one)
+    asm("v_pk_lshrrev_b16 %0, %2, %1" : "=v"(a2) : "v"(a), "v"(two));
+    asm("v_pk_lshrrev_b16 %0, %2, %1" : "=v"(c2) : "v"(c), "v"(two));
+    return __builtin_amdgcn_perm(c2, a2, 0x06040200u);                                                  // bytes 0 and 2 of both
+}
+
 // LDS-staged variant (the fast path): a workgroup produces a 256 x LT_ROWS destination tile in three steps.
 //   A  the source rectangle it needs is fetched once with 16-byte coalesced loads into LDS (each source row is read from HBM/L2 once
 //      per tile instead of once per destination row)
@@ -100,7 +132,6 @@ __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict_
 // prefetched the next tile's vectors into registers was measured slower: 0.164 vs 0.146 ms for the 7 levels of 32 frames.)
 // Needs 16-byte aligned source rows and a scale <= 2 (the 4 columns of a lane then span <= 8 source bytes).
 #define LT_ROWS 16
-typedef unsigned short hs_us2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restrict__ lv, int level, HsImg0 img0, int lds_pitch, int lds_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_src[];
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     for (int i = 0; i < 4; i++) {
         const uint32_t q = (uint32_t)(t[i].sx - t[0].sx);       // 0..6: bytes q, q+1 of the window (a1 == 0 wherever sx+1 is past the row)
         sel[i] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
-        coef[i] = (uint32_t)(uint16_t)t[i].a0 | ((uint32_t)(uint16_t)t[i].a1 << 16);
+        coef[i] = ((uint32_t)(uint16_t)t[i].a0 << 4) | ((uint32_t)(uint16_t)t[i].a1 << 20);      // 16 a0 | 16 a1 << 16
     }
     __syncthreads();
     // ---- B
@@ -155,32 +186,27 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_src[r * lds_pitch + wbase]);
         const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
         const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, wshift);
-        uint32_t h[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, sel[i])), __builtin_bit_cast(hs_us2, coef[i]), 0u, false) >> 4;
-        *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(whi, wlo, sel[0], sel[1], coef[0], coef[1]), pyr_hpair(whi, wlo, sel[2], sel[3], coef[2], coef[3]));
     }
     __syncthreads();
     // ---- C: the destination row of a wave is uniform, so its source rows and weights come from scalar loads
     if (dx0 >= D.w) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t* const dimg = D.base + (size_t)img * D.img_stride;
+    int sy4[LT_ROWS / 4]; uint32_t b4[LT_ROWS / 4];                    // the four rows' parameters (scalar loads) before the first use
+#pragma unroll
+    for (int rr = 0; rr < LT_ROWS / 4; rr++) { const int dy = min(dy_tile + wave + 4 * rr, D.h - 1); sy4[rr] = hs_cload_i16(D.yofs, dy); b4[rr] = hs_cload<uint32_t>(D.ibeta + 2 * dy); }
 #pragma unroll
     for (int rr = 0; rr < LT_ROWS / 4; rr++) {
         const int dy = dy_tile + wave + 4 * rr;
         if (dy >= D.h) break;
-        const int sy = hs_cload_i16(D.yofs, dy);
-        const uint32_t b01 = hs_cload<uint32_t>(D.ibeta + 2 * dy);
+        const int sy = sy4[rr];
+        const uint32_t b01 = b4[rr];
         const uint32_t b0 = b01 & 0xFFFFu, b1 = b01 >> 16;
         const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
         const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
         const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
-        const uint32_t v0 = (((b0 * (H0.x & 0xFFFFu)) >> 16) + ((b1 * (H1.x & 0xFFFFu)) >> 16) + 2) >> 2;
-        const uint32_t v1 = (((b0 * (H0.x >> 16)) >> 16) + ((b1 * (H1.x >> 16)) >> 16) + 2) >> 2;
-        const uint32_t v2 = (((b0 * (H0.y & 0xFFFFu)) >> 16) + ((b1 * (H1.y & 0xFFFFu)) >> 16) + 2) >> 2;
-        const uint32_t v3 = (((b0 * (H0.y >> 16)) >> 16) + ((b1 * (H1.y >> 16)) >> 16) + 2) >> 2;
-        hs_gstore<uint32_t>(dimg + (size_t)dy * D.pitch + dx0, v0 | (v1 << 8) | (v2 << 16) | (v3 << 24));   // every v <= 255; pitch is a multiple of 64: padding bytes may be written
+        hs_gstore<uint32_t>(dimg + (size_t)dy * D.pitch + dx0, pyr_vquad(H0, H1, b0, b1));   // pitch is a multiple of 64: padding bytes may be written
     }
 }
 
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __rest
         for (int i = 0; i < 4; i++) {
             const uint32_t q = (uint32_t)(t[i].sx - t[0].sx);
             c.sel[i] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
-            c.coef[i] = (uint32_t)(uint16_t)t[i].a0 | ((uint32_t)(uint16_t)t[i].a1 << 16);
+            c.coef[i] = ((uint32_t)(uint16_t)t[i].a0 << 4) | ((uint32_t)(uint16_t)t[i].a1 << 20);  // 16 a0 | 16 a1 << 16
         }
         return c;
     };
@@ -265,21 +291,13 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __rest
             const uint32_t* w = reinterpret_cast<const uint32_t*>(&src[r * pitch + c.wbase]);
             const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
             const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, c.wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, c.wshift);
-            uint32_t h[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                h[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(hs_us2, __builtin_amdgcn_perm(whi, wlo, c.sel[i])), __builtin_bit_cast(hs_us2, c.coef[i]), 0u, false) >> 4;
-            *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(whi, wlo, c.sel[0], c.sel[1], c.coef[0], c.coef[1]), pyr_hpair(whi, wlo, c.sel[2], c.sel[3], c.coef[2], c.coef[3]));
         }
     };
     auto v_combine = [&](int r0, int r1, uint32_t b0, uint32_t b1) -> uint32_t {
         const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
         const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
-        const uint32_t v0 = (((b0 * (H0.x & 0xFFFFu)) >> 16) + ((b1 * (H1.x & 0xFFFFu)) >> 16) + 2) >> 2;
-        const uint32_t v1 = (((b0 * (H0.x >> 16)) >> 16) + ((b1 * (H1.x >> 16)) >> 16) + 2) >> 2;
-        const uint32_t v2 = (((b0 * (H0.y & 0xFFFFu)) >> 16) + ((b1 * (H1.y & 0xFFFFu)) >> 16) + 2) >> 2;
-        const uint32_t v3 = (((b0 * (H0.y >> 16)) >> 16) + ((b1 * (H1.y >> 16)) >> 16) + 2) >> 2;
-        return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+        return pyr_vquad(H0, H1, b0, b1);
     };
     const ColData cA = col_data(xtA, ax0 + 4 * tx, A.w - 1, col0);
     __syncthreads();
@@ -291,9 +309,14 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __rest
         uint8_t* const aimg = A.base + (size_t)img * A.img_stride;
         const int acol = ax0 + 4 * tx;
         const bool own_col = acol < own_x1;
+        // the row parameters are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic
+        int sy_n = hs_cload_i16(A.yofs, min(ay0 + wave, ay_last));
+        uint32_t b01_n = hs_cload<uint32_t>(A.ibeta + 2 * min(ay0 + wave, ay_last));
         for (int ay = ay0 + wave; ay <= ay_last; ay += 4) {
-            const int sy = hs_cload_i16(A.yofs, ay);
-            const uint32_t b01 = hs_cload<uint32_t>(A.ibeta + 2 * ay);
+            const int sy = sy_n;
+            const uint32_t b01 = b01_n;
+            sy_n = hs_cload_i16(A.yofs, min(ay + 4, ay_last));
+            b01_n = hs_cload<uint32_t>(A.ibeta + 2 * min(ay + 4, ay_last));
             const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
             const uint32_t px = v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16);
             *reinterpret_cast<uint32_t*>(&s_a[(ay - ay0) * FZ_APITCH + 4 * tx]) = px;
@@ -308,12 +331,15 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __rest
     // ---- 5: the level-B tile
     if (4 * tx < TBX && bx0 + 4 * tx < B.w) {
         uint8_t* const bimg = B.base + (size_t)img * B.img_stride;
+        int sy4[FZ_ROWS / 4]; uint32_t b4[FZ_ROWS / 4];                // the four rows' parameters (scalar loads) before the first use
+#pragma unroll
+        for (int rr = 0; rr < FZ_ROWS / 4; rr++) { const int by = min(by0 + wave + 4 * rr, B.h - 1); sy4[rr] = hs_cload_i16(B.yofs, by); b4[rr] = hs_cload<uint32_t>(B.ibeta + 2 * by); }
 #pragma unroll
         for (int rr = 0; rr < FZ_ROWS / 4; rr++) {
             const int by = by0 + wave + 4 * rr;
             if (by >= B.h) break;
-            const int sy = hs_cload_i16(B.yofs, by);
-            const uint32_t b01 = hs_cload<uint32_t>(B.ibeta + 2 * by);
+            const int sy = sy4[rr];
+            const uint32_t b01 = b4[rr];
             const int r0 = min(max(sy, 0), A.h - 1) - ay0, r1 = min(max(sy + 1, 0), A.h - 1) - ay0;
             hs_gstore<uint32_t>(bimg + (size_t)by * B.pitch + bx0 + 4 * tx, v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16));
         }
