@@ -20,5 +20,20 @@ timeout 300 python3 bench.py --config c5 --steps 50 --warmup 5 > $OUT/c5.json 2>
 timeout 300 python3 bench.py --config c5 --c5-match bow --steps 50 --warmup 5 > $OUT/c5_bow.json 2>/dev/null
 for b in 1 4 64; do timeout 300 python3 bench.py --pairs $b --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_pairs$b.json; done
 for hn in 2 3; do timeout 300 python3 bench.py --handles $hn --steps 30 --warmup 3 --cpu-seconds 0 2>/dev/null | tail -1 > $OUT/bench_handles$hn.json; done
+timeout 300 python3 bench.py --density 3 --steps 100 --cpu-seconds 0 --pcie-seconds 0 2>/dev/null | tail -1 > $OUT/bench_density3.json
+# what hySLAM's call sites would see through the C++ adaptors (tests/cpp/bench_adaptor.cpp)
+python3 - <<PY
+import subprocess, sys
+sys.path.insert(0, "tests")
+import test_adaptor as t
+t.build("bench_adaptor.cpp", t.EXE_B)
+r = t.run_bench(1920, 1080, 30, 50000)
+open("$OUT/adaptor.json", "w").write(r.stdout.decode())
+PY
+# batch-1 kernel timeline (un-instrumented steps)
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt1 -- python3 bench.py --pairs 1 --steps 30 --warmup 5 --cpu-seconds 0 --pcie-seconds 0 --min-timed-ms 0 --profile-steps 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt16 -- python3 bench.py --steps 30 --warmup 5 --cpu-seconds 0 --pcie-seconds 0 --min-timed-ms 0 --profile-steps 0 > /dev/null 2>&1
+[ -f hyslam_amd/libhyslam_amd_qprof.so ] && HYSLAM_AMD_LIB=$PWD/hyslam_amd/libhyslam_amd_qprof.so timeout 300 python3 tools/quadtree_phase_profile.py > $OUT/qt_phase_1080p.txt 2>&1
+[ -f hyslam_amd/libhyslam_amd_qprof.so ] && HYSLAM_AMD_LIB=$PWD/hyslam_amd/libhyslam_amd_qprof.so timeout 300 python3 tools/quadtree_phase_profile.py 4000 3000 3000 1.4 > $OUT/qt_phase_4000x3000.txt 2>&1
 timeout 120 tools/micro/valu_peak > $OUT/valu_issue_rates.txt 2>&1
 tail -1 $OUT/bench.json | cut -c1-400

@@ -90,11 +90,15 @@ with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
 json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
-for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof"):
+for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof",
+             "bench_density3", "adaptor"):
     p = os.path.join(src, name + ".json")
     try:
-        line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
-        summary[name] = json.loads(line)
+        text = open(p).read()
+        try:
+            summary[name] = json.loads(text)                     # a multi-line JSON object (the adaptor bench)
+        except ValueError:
+            summary[name] = json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
     except Exception:
         summary[name] = None
 json.dump(summary, open("profiles/%s_bench_lines.json" % rnd, "w"), indent=1)
@@ -104,5 +108,39 @@ try:
         "".join(l for l in open(os.path.join(src, "valu_issue_rates.txt")) if l.startswith("v_")))
 except Exception:
     pass
+# un-instrumented kernel timelines (one step each) and the quadtree's phase stamps
+def timeline(d, out):
+    kt = first(d + "/**/*kernel_trace.csv")
+    if not kt:
+        return
+    rows = []
+    for r in csv.DictReader(open(kt)):
+        n = short(r["Kernel_Name"])
+        if n.startswith("k_"):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:28]))
+    rows.sort()
+    firsts = [i for i, r in enumerate(rows) if r[2].startswith("k_resize") and (i == 0 or not rows[i - 1][2].startswith("k_resize"))]
+    if len(firsts) < 3:
+        return
+    a, b2 = firsts[-3], firsts[-2]
+    t0, prev, busy = rows[a][0], None, 0
+    for s_, e_, n in rows[a:b2]:
+        out.write("%-30s start %7.1f us  dur %6.1f us  gap %5.1f\n" % (n, (s_ - t0) / 1e3, (e_ - s_) / 1e3, 0 if prev is None else (s_ - prev) / 1e3))
+        prev = e_; busy += e_ - s_
+    out.write("step period %.1f us, kernels busy %.1f us\n" % ((rows[b2][0] - t0) / 1e3, busy / 1e3))
+
+
+with open("profiles/%s_kernel_timeline.txt" % rnd, "w") as o:
+    o.write("# rocprofv3 --kernel-trace of bench.py without stage events (--profile-steps 0): one step of the timed loop, tag %s\n" % tag)
+    o.write("## --pairs 1 (one stereo pair per call)\n"); timeline("kt1", o)
+    o.write("## default (16 stereo pairs per call)\n"); timeline("kt16", o)
+for name in ("qt_phase_1080p", "qt_phase_4000x3000"):
+    try:
+        open("profiles/%s_%s.txt" % (rnd, name), "w").write(
+            "# tools/quadtree_phase_profile.py: shader-clock stamps of the level-0 quadtree workgroup of image 0 (HS_QT_PROFILE build); tags: 20 set-up, 22 item scan, 23/25 record run\n"
+            "# (search / fetch+key+histogram), 1 gather done, 30 pyramid, 31 closed form, 5 list built, 110 order, 11 child counts, 12 cut+children, 13 survivors, 14 relabel (point domain),\n"
+            "# 3 geometric keys -> nodes, 40 best point per node, 41 emitted, 4 tile order\n" + open(os.path.join(src, name + ".txt")).read())
+    except OSError:
+        pass
 b = summary["bench"]
 print("value", b["value"], b["stage_ms_per_step"], b["roofline"])
