@@ -72,7 +72,7 @@ EXPORTS = [
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
-    "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_for_initialization",
+    "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
@@ -158,6 +158,8 @@ def lib():
                                    vp, f32, f32, C.c_int, vp, vp]
     L.hs_search_by_bow_ex.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                       vp, vp, vp, f32, f32, f32, f32, C.c_int, vp, vp]
+    L.hs_search_by_bow_legacy.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                          vp, vp, f32, f32, C.c_int, vp, vp]
     L.hs_search_for_initialization.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FrameView), vp, C.c_int, f32, f32, vp, vp]
     L.hs_vocab_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.hs_vocab_from_tree.argtypes = [C.POINTER(VocabTree), C.c_int, C.POINTER(vp)]

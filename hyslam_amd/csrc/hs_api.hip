@@ -1054,7 +1054,7 @@ int hs_search_by_bow(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, i
                                keep1, nullptr, nullptr, 31.f, 1.f, score_threshold, second_best_ratio, check_rotation, match12, n_matches);
 }
 
-int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+static int bow_host(hs_orb* h, int legacy, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
                         const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
                         const hs_keypoint* kps2, const uint8_t* desc2, int n2,
                         const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
@@ -1082,7 +1082,7 @@ int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = scratch_begin(h, pad256((size_t)n1 * sizeof(hs_keypoint)) + pad256((size_t)n2 * sizeof(hs_keypoint)) + pad256((size_t)n1 * 32) + pad256((size_t)n2 * 32) +
                               pad256((size_t)(nn1 + 1) * 4) + pad256((size_t)(nn2 + 1) * 4) + pad256((size_t)std::max(m1, 1) * 4) + pad256((size_t)std::max(m2, 1) * 4) +
-                              2 * pad256((size_t)std::max(np, 1) * 4) + pad256(n1) + pad256(n2) + 3 * pad256((size_t)n1 * 4) + 256);
+                              2 * pad256((size_t)std::max(np, 1) * 4) + pad256(n1) + pad256(n2) + 3 * pad256((size_t)n1 * 4) + pad256((size_t)n2 * 4) + 256);
     if (rc != HS_OK) return rc;
     hipStream_t s = h->stream;
     hs_keypoint* d_k1 = carve<hs_keypoint>(h, n1); hs_keypoint* d_k2 = carve<hs_keypoint>(h, n2);
@@ -1093,6 +1093,7 @@ int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1
     uint8_t* d_keep = carve<uint8_t>(h, n1); uint8_t* d_keep2 = carve<uint8_t>(h, n2);
     int32_t* d_m = carve<int32_t>(h, n1); float* d_ang = carve<float>(h, n1); int32_t* d_self = carve<int32_t>(h, n1);
     int32_t* d_nm = carve<int32_t>(h, 1);
+    uint32_t* d_taken2 = carve<uint32_t>(h, n2);
     HIP_TRY(h, hipMemcpyAsync(d_k1, kps1, (size_t)n1 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(d_k2, kps2, (size_t)n2 * sizeof(hs_keypoint), hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(d_d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
@@ -1104,14 +1105,41 @@ int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1
     if (np) { HIP_TRY(h, hipMemcpyAsync(d_pa, pa.data(), (size_t)np * 4, hipMemcpyHostToDevice, s)); HIP_TRY(h, hipMemcpyAsync(d_pb, pb.data(), (size_t)np * 4, hipMemcpyHostToDevice, s)); }
     if (keep1) HIP_TRY(h, hipMemcpyAsync(d_keep, keep1, n1, hipMemcpyHostToDevice, s));
     if (keep2) HIP_TRY(h, hipMemcpyAsync(d_keep2, keep2, n2, hipMemcpyHostToDevice, s));
-    hs_launch_bow(d_pa, d_pb, np, d_p1, d_i1, d_p2, d_i2, d_d1, d_d2, keep1 ? d_keep : nullptr, keep2 ? d_keep2 : nullptr,
-                  F12, size_ref, sigma_ref, score_threshold, second_best_ratio,
-                  d_m, n1, d_k1, d_k2, d_ang, check_rotation, d_self, d_nm, s);
+    if (legacy)
+        hs_launch_bow_legacy(d_pa, d_pb, np, d_p1, d_i1, d_p2, d_i2, d_d1, d_d2, keep1 ? d_keep : nullptr, keep2 ? d_keep2 : nullptr,
+                             score_threshold, second_best_ratio, d_m, n1, n2, d_k1, d_k2, d_ang, check_rotation, d_self, d_taken2, d_nm, s);
+    else
+        hs_launch_bow(d_pa, d_pb, np, d_p1, d_i1, d_p2, d_i2, d_d1, d_d2, keep1 ? d_keep : nullptr, keep2 ? d_keep2 : nullptr,
+                      F12, size_ref, sigma_ref, score_threshold, second_best_ratio,
+                      d_m, n1, d_k1, d_k2, d_ang, check_rotation, d_self, d_nm, s);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(match12, d_m, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return HS_OK;
+}
+
+int hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                        const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                        const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                        const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                        const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
+                        float score_threshold, float second_best_ratio, int check_rotation,
+                        int32_t* match12, int32_t* n_matches)
+{
+    return bow_host(h, 0, kps1, desc1, n1, node_id1, node_ptr1, idx1, nn1, kps2, desc2, n2, node_id2, node_ptr2, idx2, nn2, keep1, keep2, F12, size_ref, sigma_ref,
+                    score_threshold, second_best_ratio, check_rotation, match12, n_matches);
+}
+
+int hs_search_by_bow_legacy(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                            const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                            const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                            const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                            const uint8_t* keep1, const uint8_t* keep2, float th_low, float nnratio, int check_orientation,
+                            int32_t* match12, int32_t* n_matches)
+{
+    return bow_host(h, 1, kps1, desc1, n1, node_id1, node_ptr1, idx1, nn1, kps2, desc2, n2, node_id2, node_ptr2, idx2, nn2, keep1, keep2, nullptr, 31.f, 1.f,
+                    th_low, nnratio, check_orientation, match12, n_matches);
 }
 
 int hs_search_for_initialization(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1, const hs_frame_view* F2,

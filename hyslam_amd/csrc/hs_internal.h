@@ -177,6 +177,11 @@ void hs_launch_sim3_search(const hs_frame_view& F1, const hs_keypoint* d_kps1, c
 void hs_launch_knn2_records(const uint8_t* d_recs, size_t stride, int world, int rank, int cap, size_t off_desc,
                             int32_t* d_bi, int32_t* d_bd, int32_t* d_sd, hipStream_t s);
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s);
+void hs_launch_bow_legacy(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
+                          const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
+                          const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, const uint8_t* d_keep2, float thr, float ratio,
+                          int32_t* d_match12, int n1, int n2, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle1_scratch,
+                          int check_orientation, int32_t* d_self_scratch, uint32_t* d_taken2, int32_t* d_n_matches, hipStream_t s);
 void hs_launch_bow_transform(int n, const uint8_t* d_desc, const int32_t* d_cb, const int32_t* d_cc, const uint8_t* d_ndesc, const int32_t* d_word,
                              const float* d_weight, int levels, int levelsup, int32_t* d_out_word, float* d_out_weight, int32_t* d_out_node, hipStream_t s);
 void hs_launch_search_init(const hs_frame_view& F2, const hs_keypoint* d_kps2, const uint8_t* d_desc2, const int8_t* d_cell2,

@@ -394,6 +394,47 @@ __global__ __launch_bounds__(256) void k_bow_match(const int32_t* __restrict__ p
     }
 }
 
+// The legacy SearchByBoW(pKF1, pKF2, vpMatches12) (FeatureMatcher.cc:938-1077): like k_bow_match, but a side-2 feature that an earlier side-1
+// feature matched is no longer a candidate (vbMatched2).  That makes the side-1 loop of a node SEQUENTIAL; the nodes stay independent because a
+// feature belongs to exactly one node of the feature vector.  One wavefront per shared node walks the node's side-1 list in order, its lanes
+// cover the side-2 list; `taken2` (zeroed by the launcher) is written and read by this wave only — through L2 (atomic load / store at agent scope):
+// the vector L1 is not coherent with a wave's own earlier stores.
+__global__ __launch_bounds__(64) void k_bow_match_exclusive(const int32_t* __restrict__ pair_a, const int32_t* __restrict__ pair_b,
+                                                            const int32_t* __restrict__ ptr1, const int32_t* __restrict__ idx1,
+                                                            const int32_t* __restrict__ ptr2, const int32_t* __restrict__ idx2,
+                                                            const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
+                                                            const uint8_t* __restrict__ keep1, const uint8_t* __restrict__ keep2,
+                                                            float score_threshold, float ratio, int32_t* __restrict__ match12, uint32_t* __restrict__ taken2)
+{
+    const int lane = threadIdx.x;
+    const int a = pair_a[blockIdx.x], b = pair_b[blockIdx.x];
+    const int p0 = ptr1[a], p1 = ptr1[a + 1], q0 = ptr2[b], q1 = ptr2[b + 1];
+    for (int p = p0; p < p1; p++) {
+        const int i1 = idx1[p];
+        if (keep1 && !keep1[i1]) continue;                                   // !pMP1 || pMP1->isBad() (:985-990)
+        const unsigned long long* d1 = reinterpret_cast<const unsigned long long*>(desc1 + (size_t)i1 * 32);
+        unsigned long long best = NO_KEY; int second = NO_DIST;
+        for (int q = q0 + lane; q < q1; q += 64) {
+            const int i2 = idx2[q];
+            if (keep2 && !keep2[i2]) continue;
+            if (__hip_atomic_load(&taken2[i2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;      // vbMatched2[idx2] (:999)
+            const int d = hamming256(d1, reinterpret_cast<const unsigned long long*>(desc2 + (size_t)i2 * 32));
+            const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(q - q0);     // list order breaks ties
+            if (key < best) { second = min(second, (int)(best >> 32)); best = key; }
+            else second = min(second, d);
+        }
+        wave_best2(best, second);                                            // every lane holds the result
+        if (best != NO_KEY) {
+            const float bd1 = (float)(int)(best >> 32), bd2 = second == NO_DIST ? FLT_MAX : (float)second;
+            if (bd1 < score_threshold && bd1 < __fmul_rn(ratio, bd2)) {
+                const int i2 = idx2[q0 + (int)(best & 0xFFFFFFFFu)];
+                if (lane == 0) { match12[i1] = i2; __hip_atomic_store(&taken2[i2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                __builtin_amdgcn_s_waitcnt(0x0f70);                          // vmcnt(0): the flag is in L2 before the next feature's loads
+            }
+        }
+    }
+}
+
 // one wavefront: 2-NN of query descriptor i over the train set (first minimum wins; second = second smallest of the multiset)
 __device__ __forceinline__ void knn2_wave(const uint8_t* __restrict__ q, int i, const uint8_t* __restrict__ t, int nt,
                                           int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
@@ -622,6 +663,7 @@ void hs_launch_search_projection(const hs_frame_view& F, const hs_keypoint* d_kp
     }
 }
 
+__global__ void k_iota_all(int n, int32_t* __restrict__ out) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = i; }
 __global__ void k_gather_angle(int n, const int32_t* __restrict__ match, const hs_keypoint* __restrict__ kps2, float* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -658,6 +700,29 @@ void hs_launch_bow(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs
         hipLaunchKernelGGL(k_iota_where, dim3(g), dim3(256), 0, s, n1, d_match12, d_self_scratch);
         hipLaunchKernelGGL(k_rotation_filter, dim3(1), dim3(1024), 0, s, n1, d_self_scratch, d_angle2_scratch, d_kps1, (int32_t*)nullptr, 0, 0, d_n_matches);
         hipLaunchKernelGGL(k_mask_by, dim3(g), dim3(256), 0, s, n1, d_self_scratch, d_match12);
+    } else {
+        hipLaunchKernelGGL(k_count_matches, dim3(1), dim3(1024), 0, s, n1, d_match12, d_n_matches);
+    }
+}
+
+// legacy SearchByBoW(KF, KF): exclusive matching, then the rotation histogram on angle1 - angle2 (FeatureMatcher.cc:1031: the opposite sign of
+// RotationConsistencyBoW), entries of the minority bins removed from match12
+void hs_launch_bow_legacy(const int32_t* d_pair_a, const int32_t* d_pair_b, int n_pairs,
+                          const int32_t* d_ptr1, const int32_t* d_idx1, const int32_t* d_ptr2, const int32_t* d_idx2,
+                          const uint8_t* d_desc1, const uint8_t* d_desc2, const uint8_t* d_keep1, const uint8_t* d_keep2, float thr, float ratio,
+                          int32_t* d_match12, int n1, int n2, const hs_keypoint* d_kps1, const hs_keypoint* d_kps2, float* d_angle1_scratch,
+                          int check_orientation, int32_t* d_self_scratch, uint32_t* d_taken2, int32_t* d_n_matches, hipStream_t s)
+{
+    hipMemsetAsync(d_match12, 0xFF, (size_t)n1 * 4, s);
+    hipMemsetAsync(d_taken2, 0, (size_t)n2 * 4, s);
+    if (n_pairs > 0)
+        hipLaunchKernelGGL(k_bow_match_exclusive, dim3(n_pairs), dim3(64), 0, s, d_pair_a, d_pair_b, d_ptr1, d_idx1, d_ptr2, d_idx2, d_desc1, d_desc2,
+                           d_keep1, d_keep2, thr, ratio, d_match12, d_taken2);
+    if (check_orientation && n1 > 0) {
+        const int g = (n1 + 255) / 256;
+        hipLaunchKernelGGL(k_iota_all, dim3(g), dim3(256), 0, s, n1, d_self_scratch);
+        hipLaunchKernelGGL(k_gather_angle, dim3(g), dim3(256), 0, s, n1, d_self_scratch, d_kps1, d_angle1_scratch);      // angle of side-1 feature i
+        hipLaunchKernelGGL(k_rotation_filter, dim3(1), dim3(1024), 0, s, n1, d_match12, d_angle1_scratch, d_kps2, (int32_t*)nullptr, 0, 0, d_n_matches);
     } else {
         hipLaunchKernelGGL(k_count_matches, dim3(1), dim3(1024), 0, s, n1, d_match12, d_n_matches);
     }

@@ -369,6 +369,23 @@ class FeatureMatcher:
         return self.SearchByBoW(kps1, desc1, featvec1, kps2, desc2, featvec2, keep1, True, keep2=keep2, F12=F12, ratio=1.0,
                                 size_ref=size_ref, sigma_ref=sigma_ref)
 
+    def SearchByBoWLegacy(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, keep2=None):
+        """the legacy SearchByBoW(pKF1, pKF2, vpMatches12) (FeatureMatcher.cc:938-1077): a key-frame-2 feature is matched at most once, the
+        orientation histogram takes angle1 - angle2.  keep1 / keep2 = views with a good landmark.  Returns (match12, nmatches)."""
+        ex = self._ex
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in featvec1]; b = [np.ascontiguousarray(x, np.int32) for x in featvec2]
+        kp1 = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+        kp2 = None if keep2 is None else np.ascontiguousarray(keep2, np.uint8)
+        m = np.full(len(k1), -1, np.int32)
+        n = C.c_int32()
+        p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+        N.check(ex._h, ex._lib.hs_search_by_bow_legacy(ex._h, p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                                       p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                                       p(kp1), p(kp2), self.TH_LOW, self.mfNNratio, int(self.mbCheckOrientation), p(m), C.byref(n)))
+        return m, n.value
+
     def SearchByBoW(self, kps1, desc1, featvec1, kps2, desc2, featvec2, keep1=None, check_rotation=True, keep2=None, F12=None, ratio=None,
                     size_ref=31.0, sigma_ref=1.0):
         """The matching core of SearchByBoW / SearchByBoW2 (FeatureMatcher.cc:216-371).  featvec = (node_id, node_ptr, idx) CSR arrays."""

@@ -11,10 +11,10 @@
 //   search   one C-ABI call (GPU)
 //   replay   Frame::associateLandMark(idx, lm, true) for every match, in that same address order (FeatureMatcher.cc:113-118) — a later
 //            landmark that picked the same keypoint overwrites the earlier one, exactly as in the reference.
-// Overridden: the four SearchByProjection overloads, SearchByBoW(KF, Frame), SearchByBoW2, SearchForTriangulation, SearchForInitialization,
-// Fuse(pKF, points, ...), Fuse(pKF, Scw, ...) (an empty body in the reference, FeatureMatcher.cc:523-624) and SearchBySim3 — every entry point
-// that has a call site in hySLAM.  Not overridden: SearchByBoW(KF, KF, vpMatches12) (FeatureMatcher.cc:938-1077), which no file of hySLAM calls
-// ("aim to replace this with SearchByBoW2", :939); it stays the reference's CPU code.
+// Overridden: all twelve search entry points of FeatureMatcher (src/features/FeatureMatcher.h:114-150) — the four SearchByProjection overloads,
+// SearchByBoW(KF, Frame), SearchByBoW(KF, KF) (legacy: no call site in hySLAM, "aim to replace this with SearchByBoW2", FeatureMatcher.cc:939),
+// SearchByBoW2, SearchForTriangulation, SearchForInitialization, Fuse(pKF, points, ...), Fuse(pKF, Scw, ...) (an empty body in the reference,
+// :523-624) and SearchBySim3.
 #pragma once
 #ifdef HYSLAM_AMD_WITH_HYSLAM
 #include <FeatureMatcher.h>
@@ -113,6 +113,25 @@ public:
         check(hs_search_by_projection(h, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n), "Fuse");
         for (size_t i = 0; i < lms.size(); i++) if (midx[i] >= 0) fuse_matches.insert(std::make_pair((size_t)midx[i], lms[i]));
         return (int)fuse_matches.size();
+    }
+
+    // SearchByBoW(pKF1, pKF2, vpMatches12) — the legacy key-frame matcher (FeatureMatcher.cc:938-1077; no call site in hySLAM): a KF2 view is matched at
+    // most once (vbMatched2), the orientation histogram takes angle1 - angle2; views take part when they have a landmark that is not bad.
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override {
+        const FeatureViews& v1 = pKF1->getViews(); const FeatureViews& v2 = pKF2->getViews();
+        Views a = gather_views(v1), b = gather_views(v2);
+        Csr f1 = gather_featvec(pKF1->mFeatVec), f2 = gather_featvec(pKF2->mFeatVec);
+        const std::vector<MapPoint*> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
+        std::vector<uint8_t> keep1(std::max<size_t>(mp1.size(), 1), 0), keep2(std::max<size_t>(mp2.size(), 1), 0);
+        for (size_t i = 0; i < mp1.size(); i++) keep1[i] = mp1[i] && !mp1[i]->isBad();
+        for (size_t i = 0; i < mp2.size(); i++) keep2[i] = mp2[i] && !mp2[i]->isBad();
+        std::vector<int32_t> m12(std::max<size_t>(a.kps.size(), 1), -1); int32_t n = 0;
+        check(hs_search_by_bow_legacy(h, a.kps.data(), a.desc.data(), (int)a.kps.size(), f1.id.data(), f1.ptr.data(), f1.idx.data(), (int)f1.ptr.size() - 1,
+                                      b.kps.data(), b.desc.data(), (int)b.kps.size(), f2.id.data(), f2.ptr.data(), f2.idx.data(), (int)f2.ptr.size() - 1,
+                                      keep1.data(), keep2.data(), TH_LOW, mfNNratio, mbCheckOrientation ? 1 : 0, m12.data(), &n), "SearchByBoW(KF, KF)");
+        vpMatches12 = std::vector<MapPoint*>(mp1.size(), static_cast<MapPoint*>(NULL));          // :957
+        for (size_t i = 0; i < mp1.size() && i < a.kps.size(); i++) if (m12[i] >= 0) vpMatches12[i] = mp2[m12[i]];
+        return n;
     }
 
     // SearchByBoW2(pKF1, pKF2, vpMatches12) — LoopClosing.cc:275 (FeatureMatcher.cc:346-371): _SearchByBoW_ with PreviouslyMatchedIndexCriterion(true) on

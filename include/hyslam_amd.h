@@ -259,6 +259,17 @@ int  hs_search_by_bow_ex(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc
                          float score_threshold, float second_best_ratio, int check_rotation,
                          int32_t* match12, int32_t* n_matches);
 
+/* The legacy FeatureMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (FeatureMatcher.cc:938-1077; hySLAM never calls it — "aim to replace this with
+ * SearchByBoW2" — bound for completeness of the FeatureMatcher surface): as hs_search_by_bow_ex without the epipolar gate, but a side-2 feature
+ * can be matched only once (vbMatched2: the side-1 features of a node are processed in list order, one wavefront per shared node) and the
+ * orientation histogram takes angle1 - angle2.  keep1 / keep2 = the view has a landmark that is not bad. */
+int  hs_search_by_bow_legacy(hs_orb* h, const hs_keypoint* kps1, const uint8_t* desc1, int n1,
+                             const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int n_nodes1,
+                             const hs_keypoint* kps2, const uint8_t* desc2, int n2,
+                             const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int n_nodes2,
+                             const uint8_t* keep1, const uint8_t* keep2, float th_low, float nnratio, int check_orientation,
+                             int32_t* match12, int32_t* n_matches);
+
 /* FeatureMatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (FeatureMatcher.cc:404-462; monocular map
  * initialisation, MonoInitializer.cpp:83).  Inherently sequential over F1's keypoints — a later keypoint takes over an F2 keypoint only
  * with a strictly smaller distance (MatchCriteria.cpp:525-549) — so one workgroup walks F1 in order and parallelises the window search

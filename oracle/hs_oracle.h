@@ -213,6 +213,11 @@ int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1,
                          const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
                          const uint8_t* keep1, const uint8_t* keep2, const float* F12, float size_ref, float sigma_ref,
                          float score_threshold, float second_best_ratio, int check_rotation, int32_t* match12);
+/* the legacy FeatureMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (FeatureMatcher.cc:938-1077): like the above, but a side-2 feature can be matched
+ * only once (sequential inside a node) and the rotation check takes angle1 - angle2 */
+int hso_search_by_bow_legacy(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                             const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                             const uint8_t* keep1, const uint8_t* keep2, float th_low, float nnratio, int check_orientation, int32_t* match12);
 /* DBoW2::TemplatedVocabulary<FORB>::transform(features, bow, fv, levelsup) as called by Frame::ComputeBoW (Frame.cc:472-479) through
  * ORBVocabulary::transform (ORBVocabulary.cpp:31-42).  DBoW2 is NOT in the reference tree; restated from its published
  * algorithm: descend from the root, at each level take the child with the smallest Hamming distance (first minimum wins);

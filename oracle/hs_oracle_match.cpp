@@ -352,6 +352,63 @@ int hso_search_by_bow_ex(const hso_keypoint* kps1, const uint8_t* desc1, int n1,
     return (int)matches_internal.size();
 }
 
+/* FeatureMatcher::SearchByBoW(pKF1, pKF2, vpMatches12) — the legacy key-frame / key-frame matcher (FeatureMatcher.cc:938-1077; no call site in
+ * hySLAM, "aim to replace this with SearchByBoW2").  Differences from _SearchByBoW_: a side-2 feature that an earlier side-1 feature matched is
+ * out of the game (vbMatched2, :959,999,1027: sequential inside a node; the nodes' index sets are disjoint), and the rotation histogram takes
+ * angle1 - angle2 (:1031), the opposite sign of RotationConsistencyBoW.  keep1 / keep2 = the view has a landmark that is not bad (:985-990,1001-1005). */
+int hso_search_by_bow_legacy(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* node_id1, const int32_t* node_ptr1, const int32_t* idx1, int nn1,
+                             const hso_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* node_id2, const int32_t* node_ptr2, const int32_t* idx2, int nn2,
+                             const uint8_t* keep1, const uint8_t* keep2, float th_low, float nnratio, int check_orientation, int32_t* match12)
+{
+    const int HISTO_LENGTH = 30;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    std::vector<bool> vbMatched2(std::max(n2, 1), false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (node_id1[a] == node_id2[b]) {
+            for (int p = node_ptr1[a]; p < node_ptr1[a + 1]; p++) {
+                const int i1 = idx1[p];
+                if (keep1 && !keep1[i1]) continue;                                  // !pMP1 || pMP1->isBad()
+                float bestDist1 = std::numeric_limits<float>::max(), bestDist2 = std::numeric_limits<float>::max();
+                int bestIdx2 = -1;
+                for (int q = node_ptr2[b]; q < node_ptr2[b + 1]; q++) {
+                    const int i2 = idx2[q];
+                    if (vbMatched2[i2] || (keep2 && !keep2[i2])) continue;          // vbMatched2[idx2] || !pMP2 || pMP2->isBad()
+                    const float dist = ORBDistance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < th_low && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    match12[i1] = bestIdx2;
+                    vbMatched2[bestIdx2] = true;
+                    if (check_orientation) {
+                        float rot = kps1[i1].angle - kps2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(i1);
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (node_id1[a] < node_id2[b]) { while (a < nn1 && node_id1[a] < node_id2[b]) a++; }
+        else { while (b < nn2 && node_id2[b] < node_id1[a]) b++; }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 int hso_search_for_initialization(const hso_keypoint* kps1, const uint8_t* desc1, int n1, const hso_frame_view* F2v,
                                   float* prev_matched_xy, int window, float th_low, float nnratio, int32_t* matches12)
 {

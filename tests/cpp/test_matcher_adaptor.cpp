@@ -447,6 +447,17 @@ int main(int argc, char** argv)
                                                     k2.data(), d2.data(), n, i2.data(), p2.data(), x2.data(), (int)i2.size(), keep1.data(), keep2.data(),
                                                     variant == 2 ? nullptr : Ff, 31.f, 1.f, 50.f, variant == 2 ? 0.8f : 1.0f, 1, om.data());
             if (variant == 2) {
+                {   // the legacy SearchByBoW(KF1, KF2) on the same key frames: exclusive use of KF2's views, angle1 - angle2 histogram
+                    std::vector<int32_t> ol(n, -1);
+                    const int nl_want = hso_search_by_bow_legacy(s.kps.data(), s.desc.data(), n, i1.data(), p1.data(), x1.data(), (int)i1.size(),
+                                                                 k2.data(), d2.data(), n, i2.data(), p2.data(), x2.data(), (int)i2.size(), keep1.data(), keep2.data(), 50.f, 0.8f, 1, ol.data());
+                    std::vector<MapPoint*> wl(n, nullptr), gl;
+                    for (int i = 0; i < n; i++) if (ol[i] >= 0) wl[i] = K2.hasAssociation(ol[i]);
+                    const int nl_got = matcher->SearchByBoW(&K1, &K2, gl);
+                    if (nl_got != nl_want || nl_want < 20) FAIL(29, "SearchByBoW(KF, KF): %d matches, expected %d", nl_got, nl_want);
+                    if (gl != wl) FAIL(30, "SearchByBoW(KF, KF): vpMatches12 differs");
+                    total_matches += nl_got;
+                }
                 std::vector<MapPoint*> want(n, nullptr), got;
                 for (int i = 0; i < n; i++) if (om[i] >= 0) want[i] = K2.hasAssociation(om[i]);
                 const int n_got = matcher->SearchByBoW2(&K1, &K2, got);
@@ -470,6 +481,6 @@ int main(int argc, char** argv)
             if (matcher->Fuse(&K1, Tcw, mp1, 4.f, repl) != 0 || repl != std::vector<MapPoint*>(3, mp1[0])) FAIL(28, "Fuse(Scw) touched its output");
         }
     }
-    printf("MATCHER ADAPTOR OK %d keypoints, %d landmarks, %d matches over 9 searches\n", s.n_kp, s.n_lm, total_matches);
+    printf("MATCHER ADAPTOR OK %d keypoints, %d landmarks, %d matches over 10 searches\n", s.n_kp, s.n_lm, total_matches);
     return 0;
 }

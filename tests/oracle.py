@@ -342,6 +342,22 @@ def search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, thr, ratio, check_rotation, k
     return m, n
 
 
+def search_by_bow_legacy(k1, d1, fv1, k2, d2, fv2, keep1, keep2, th_low, nnratio, check_orientation):
+    """the legacy SearchByBoW(pKF1, pKF2, vpMatches12), FeatureMatcher.cc:938-1077"""
+    k1 = np.ascontiguousarray(k1, KP_DTYPE); k2 = np.ascontiguousarray(k2, KP_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    a = [np.ascontiguousarray(x, np.int32) for x in fv1]
+    b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+    kp1 = None if keep1 is None else np.ascontiguousarray(keep1, np.uint8)
+    kp2 = None if keep2 is None else np.ascontiguousarray(keep2, np.uint8)
+    m = np.full(len(k1), -1, np.int32)
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    n = lib().hso_search_by_bow_legacy(p(k1), p(d1), len(k1), p(a[0]), p(a[1]), p(a[2]), len(a[0]),
+                                       p(k2), p(d2), len(k2), p(b[0]), p(b[1]), p(b[2]), len(b[0]),
+                                       p(kp1), p(kp2), C.c_float(th_low), C.c_float(nnratio), int(check_orientation), p(m))
+    return m, n
+
+
 def hamming_knn2(q, t):
     q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
     bi, bd, sd = (np.zeros(len(q), np.int32) for _ in range(3))

@@ -101,6 +101,28 @@ def test_bow_grouped_search(matcher):
     assert gn == 0 and (gm == -1).all()
 
 
+def test_legacy_key_frame_bow(matcher):
+    """hs_search_by_bow_legacy — the legacy SearchByBoW(KF1, KF2) (FeatureMatcher.cc:938-1077): every key-frame-2 feature matched at most once
+    (sequential inside a node), orientation histogram on angle1 - angle2"""
+    sc = scenes.projection_scene(39, 640, 480, nfeat=1000, copies=1)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(7)
+    k2 = np.concatenate([k1, k1]); d2 = np.concatenate([d1, d1]).copy()
+    d2[len(k1):, 3] ^= 0x05                                                    # two candidates per feature compete for the same partners
+    perm = rng.permutation(len(k2)); k2, d2 = k2[perm].copy(), d2[perm].copy()
+    k2["angle"] = (k2["angle"] + rng.normal(0, 4, len(k2)) + (rng.random(len(k2)) < 0.2) * 90) % 360
+    for nodes in (17, 300):
+        fv1, fv2 = scenes.synthetic_featvec(d1, nodes, 21), scenes.synthetic_featvec(d2, nodes, 21)
+        keep1 = (rng.random(len(k1)) < 0.9).astype(np.uint8); keep2 = (rng.random(len(k2)) < 0.9).astype(np.uint8)
+        for ori, kp1, kp2 in ((True, keep1, keep2), (False, None, None)):
+            m = HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=0.9, checkOri=ori), matcher._ex)
+            gm, gn = m.SearchByBoWLegacy(k1, d1, fv1, k2, d2, fv2, kp1, kp2)
+            om, on = oracle.search_by_bow_legacy(k1, d1, fv1, k2, d2, fv2, kp1, kp2, 50.0, 0.9, ori)
+            assert on > 200 and gn == on and np.array_equal(gm, om), (nodes, ori)
+            got = gm[gm >= 0]
+            assert len(np.unique(got)) == len(got)
+
+
 def test_search_for_triangulation_core(matcher):
     from hyslam_amd.synth import synth_stereo_pair
     matcher = HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=0.8, TH_LOW=90.0), matcher._ex)

@@ -3,6 +3,7 @@ scene, known answers for ComputeThreeMaxima / the rotation histogram quirk, and 
 import numpy as np
 
 import oracle
+import pyref
 import scenes
 
 
@@ -200,6 +201,67 @@ def test_bow_core_properties():
     keep1 = (np.arange(len(k1)) % 2 == 0).astype(np.uint8)
     m2, n2 = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, keep1, 50.0, 0.9, True)
     assert (m2[keep1 == 0] < 0).all() and 0 < n2 <= (keep1 == 1).sum()
+
+
+def test_legacy_key_frame_bow_matches_each_side2_feature_once():
+    """the legacy SearchByBoW(KF1, KF2) (FeatureMatcher.cc:938-1077) against a pure-python restatement written from the reference text: exclusive
+    use of key-frame-2 features (vbMatched2), strict < on both thresholds, orientation histogram on angle1 - angle2 with ComputeThreeMaxima"""
+    sc = scenes.projection_scene(29, 320, 240, nfeat=500, copies=1, fx=260.0)
+    k1, d1 = sc["kps"], sc["desc"]
+    rng = np.random.default_rng(6)
+    # key frame 2: every feature of key frame 1 twice (a near copy and a noisier one), shuffled: the two copies compete for the same partners
+    k2 = np.concatenate([k1, k1]); d2 = np.concatenate([d1, d1]).copy()
+    d2[len(k1):, 3] ^= 0x05
+    perm = rng.permutation(len(k2)); k2, d2 = k2[perm].copy(), d2[perm].copy()
+    k2["angle"] = (k2["angle"] + rng.normal(0, 4, len(k2)) + (rng.random(len(k2)) < 0.2) * 90) % 360
+    fv1, fv2 = scenes.synthetic_featvec(d1, 23, 4), scenes.synthetic_featvec(d2, 23, 4)
+    keep1 = (rng.random(len(k1)) < 0.9).astype(np.uint8); keep2 = (rng.random(len(k2)) < 0.9).astype(np.uint8)
+    for ori in (0, 1):
+        m, n = oracle.search_by_bow_legacy(k1, d1, fv1, k2, d2, fv2, keep1, keep2, 50.0, 0.9, ori)
+        # ---- restatement
+        want = np.full(len(k1), -1, np.int64); taken = np.zeros(len(k2), bool); hist = [[] for _ in range(30)]
+        ids2 = {int(v): j for j, v in enumerate(fv2[0])}
+        for a, node in enumerate(fv1[0]):
+            b = ids2.get(int(node))
+            if b is None:
+                continue
+            for i1 in fv1[2][fv1[1][a]:fv1[1][a + 1]]:
+                if not keep1[i1]:
+                    continue
+                best1 = best2 = float("inf"); bi = -1
+                for i2 in fv2[2][fv2[1][b]:fv2[1][b + 1]]:
+                    if taken[i2] or not keep2[i2]:
+                        continue
+                    dist = float(pyref.hamming(d1[i1], d2[i2]))
+                    if dist < best1:
+                        best2, best1, bi = best1, dist, i2
+                    elif dist < best2:
+                        best2 = dist
+                if best1 < 50.0 and np.float32(best1) < np.float32(0.9) * np.float32(best2 if best2 != float("inf") else 3.4e38):
+                    want[i1] = bi; taken[bi] = True
+                    if ori:
+                        rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                        if rot < 0:
+                            rot = np.float32(rot + np.float32(360.0))
+                        bn = int(np.floor(np.float32(rot * np.float32(1.0 / 30)) + 0.5))
+                        hist[0 if bn == 30 else bn].append(i1)
+        if ori:
+            sizes = [len(h) for h in hist]
+            order = sorted(range(30), key=lambda i: (-sizes[i], i))
+            i1_, i2_, i3_ = order[0], order[1], order[2]
+            keepb = {i1_}
+            lim = np.float32(0.1) * np.float32(sizes[i1_])                      # `max2 < 0.1f * (float)max1` in float
+            if not (np.float32(sizes[i2_]) < lim) and sizes[i2_] > 0:
+                keepb.add(i2_)
+                if not (np.float32(sizes[i3_]) < lim) and sizes[i3_] > 0:
+                    keepb.add(i3_)
+            for bn in range(30):
+                if bn not in keepb:
+                    for i1 in hist[bn]:
+                        want[i1] = -1
+        assert n == (want >= 0).sum() > 100 and np.array_equal(m, want), ori
+        got = m[m >= 0]
+        assert len(np.unique(got)) == len(got)                                   # a key-frame-2 feature is used at most once
 
 
 def test_triangulation_core_epipolar_gate():
