@@ -133,6 +133,8 @@ def spawn_ranks(args):
 
 
 def dry_run(args, rank, world):
+    if os.environ.get("HS_BENCH_TEST_FAIL_RANK") == str(rank):       # tests: a rank that dies before the rendezvous
+        sys.exit(3)
     import torch
     import torch.distributed as dist
     if world > 1:

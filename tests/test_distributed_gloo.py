@@ -3,6 +3,7 @@ gathered bytes and identical cross-camera match lists (the matcher used here is 
 product's GPU 2-NN is covered in tests/test_gpu_matchers.py)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -110,3 +111,14 @@ def test_bench_gpus_flag_spawns_the_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env2, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_spawned_bench_fails_fast_when_a_rank_dies():
+    """`python bench.py --gpus 2` must not report success (or hang until the process-group timeout) when one of the ranks it started dies:
+    the parent polls all children, stops the survivors and exits non-zero"""
+    import time
+    env = dict(os.environ, HS_BENCH_TEST_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "a rank failed" in r.stderr, r.stdout + r.stderr
+    assert time.time() - t0 < 120
