@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised matcher parity sweep (runs on the GPU box): projection search in its three Frame variants and Fuse, the BoW-grouped search
-with and without the epipolar gate, mono initialisation and brute-force 2-NN, on random scenes, sensors, radii, thresholds and ratios,
+with and without the epipolar gate, the legacy exclusive key-frame search, mono initialisation and brute-force 2-NN, on random scenes, sensors, radii, thresholds and ratios,
 against the oracle.   python3 tools/fuzz_matchers.py --cases 60 --seed 1     (exit code 1 on the first mismatch)"""
 import argparse
 import os
@@ -79,6 +79,16 @@ def one_case(rng, i, ex):
     gm, gn = m.SearchForTriangulation(ka, da, fva, kb, db, fvb, F12, keep, keep2)
     om, on = oracle.search_by_bow(ka, da, fva, kb, db, fvb, keep, th_low, 1.0, True, keep2=keep2, F12=F12)
     res.append(("tri %d" % on, gn == on and np.array_equal(gm, om)))
+    # the legacy key-frame / key-frame search: side 2 holds every feature twice, so the copies compete for the same partners (exclusive matching)
+    kc = np.concatenate([kb, kb]); dc = np.concatenate([db, db]).copy()
+    dc[len(kb):, int(rng.integers(0, 32))] ^= int(rng.integers(1, 16))
+    pc = rng.permutation(len(kc)); kc, dc = kc[pc].copy(), dc[pc].copy()
+    fvc = scenes.synthetic_featvec(dc, nodes, seed & 0xFFFF)
+    keepc = (rng.random(len(kc)) < 0.85).astype(np.uint8) if rng.random() < 0.7 else None
+    ml = HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=nnratio, TH_HIGH=th_high, TH_LOW=th_low, checkOri=rot), ex)
+    gm, gn = ml.SearchByBoWLegacy(ka, da, fva, kc, dc, fvc, keep, keepc)
+    om, on = oracle.search_by_bow_legacy(ka, da, fva, kc, dc, fvc, keep, keepc, th_low, nnratio, rot)
+    res.append(("legacy %d" % on, gn == on and np.array_equal(gm, om)))
     # mono initialisation window search
     prev = np.stack([ka["x"] + rng.normal(0, 6, len(ka)), ka["y"] + rng.normal(0, 6, len(ka))], 1).astype(np.float32)
     window = int(rng.choice([10, 20, 50, 100]))

@@ -33,6 +33,13 @@ def make_image(rng, kind, w, h, seed):
             x, y, s = int(rng.integers(0, w - 8)), int(rng.integers(0, h - 8)), int(rng.integers(3, 9))
             img[y:y + s, x:x + s] += int(rng.integers(60, 120))
         return np.clip(img, 0, 255).astype(np.uint8)
+    if kind == "cluster":                      # a flat frame with a few dense patches: the quadtree needs nodes deeper than its histogram pyramid
+        img = np.full((h, w), int(rng.integers(40, 200)), np.int32) + rng.integers(0, 4, (h, w))
+        for _ in range(int(rng.integers(1, 6))):
+            pw, ph = int(rng.integers(12, max(13, w // 4))), int(rng.integers(12, max(13, h // 4)))
+            x, y = int(rng.integers(0, max(1, w - pw))), int(rng.integers(0, max(1, h - ph)))
+            img[y:y + ph, x:x + pw] = rng.integers(0, 256, img[y:y + ph, x:x + pw].shape)
+        return np.clip(img, 0, 255).astype(np.uint8)
     # gradient + mid-frequency texture
     yy, xx = np.mgrid[0:h, 0:w]
     img = 128 + 60 * np.sin(xx / float(rng.integers(3, 40))) * np.cos(yy / float(rng.integers(3, 40))) + (xx * 40.0 / w) + rng.normal(0, float(rng.uniform(0, 12)), (h, w))
@@ -40,7 +47,7 @@ def make_image(rng, kind, w, h, seed):
 
 
 def one_case(rng, i):
-    kind = ["scene", "scene", "noise", "checker", "flat", "texture"][int(rng.integers(0, 6))]
+    kind = ["scene", "scene", "noise", "checker", "flat", "texture", "cluster"][int(rng.integers(0, 7))]
     w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
     h = int(rng.integers(64, 1100)) if rng.random() < 0.85 else int(rng.integers(1100, 1700))
     if rng.random() < 0.95:
