@@ -180,4 +180,80 @@ private:
     std::vector<float> mvuRight, mvDepth;
 };
 
+// HipStereoFrontend — OPTIONAL one-call replacement for the body of ImageProcessing::ProcessStereoImage (src/main/ImageProcessing.cpp:80-103): left and
+// right extraction and the stereo match as ONE ticket of the pipelined ingest (hs_orb_submit_batch / hs_orb_wait): both frames go through one launch
+// sequence, the features never return to the device a second time (the drop-in path extracts, copies out, builds FeatureViews, and HipStereomatcher
+// gathers the descriptors again and uploads them), and with submit() / collect() the upload of pair i+1 runs under the kernels of pair i — the
+// shape of the reference's own bounded queue (System.cc:194-196).  Results are the same bits as HipORBExtractor x 2 + HipStereomatcher.
+//   FeatureViews views = frontend.process(imLeft, imRight);          // keys, keysR, uRight, depth, descriptors, descriptorsR
+// A maintainer swaps it in with ~10 lines; nothing else in hySLAM changes.
+class HipStereoFrontend {
+public:
+    HipStereoFrontend(std::shared_ptr<DescriptorDistance> dist_func_, FeatureExtractorSettings settings, Camera cam_data, FeatureMatcherSettings matcher, int device = 0)
+        : dist_func(dist_func_), orb_params(settings) {
+        hs_orb_params p;
+        hs_orb_default_params(&p);
+        p.nfeatures = settings.nFeatures; p.scale_factor = settings.fScaleFactor; p.nlevels = settings.nLevels;
+        p.cell_px = settings.N_CELLS; p.ini_th_fast = settings.init_threshold; p.min_th_fast = settings.min_threshold;
+        int st = hs_orb_create(&p, device, &h);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipStereoFrontend: ") + hs_status_string(st));
+        // what Stereomatcher::Stereomatcher reads (Stereomatcher.cpp:7-24); ImageProcessing passes default-constructed FeatureExtractorSettings to
+        // FeatureViews, so size_ref is 31 there (ImageProcessing.cpp:85,100) — `views_params` reproduces that
+        sp.fx = cam_data.fx(); sp.mbf = cam_data.mbf; sp.n_rows = (int)cam_data.mnMaxY;
+        sp.th_high = matcher.TH_HIGH; sp.th_low = matcher.TH_LOW; sp.size_ref = views_params.size_ref;
+    }
+    ~HipStereoFrontend() { hs_orb_destroy(h); }
+    HipStereoFrontend(const HipStereoFrontend&) = delete;
+    HipStereoFrontend& operator=(const HipStereoFrontend&) = delete;
+
+    // enqueue one pair (the images must stay valid until collect); at most two tickets in flight
+    int32_t submit(const cv::Mat& imLeft, const cv::Mat& imRight) {
+        if (imLeft.empty() || imRight.empty() || imLeft.type() != CV_8UC1 || imRight.type() != CV_8UC1 || imLeft.cols != imRight.cols || imLeft.rows != imRight.rows ||
+            imLeft.step != imRight.step)
+            throw std::runtime_error("HipStereoFrontend: two CV_8UC1 images of one size and row step");
+        const uint8_t* imgs[2] = { imLeft.ptr(0), imRight.ptr(0) };
+        int32_t t = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = hs_orb_submit_batch(h, imgs, 2, imLeft.cols, imLeft.rows, (int)imLeft.step, &sp, &t);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipStereoFrontend: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        timing.gather_ms = hip_detail::ms_since(t0);
+        return t;
+    }
+    // wait for a ticket and build the stereo FeatureViews (keys, keysR, uRight, depth, descriptors, descriptorsR — FeatureViews.h:20-81)
+    FeatureViews collect(int32_t ticket) {
+        const int cap = hs_orb_max_keypoints(h);
+        if ((int)kps.size() < 2 * cap) { kps.resize(2 * (size_t)cap); desc.resize(2 * (size_t)cap * HS_DESC_BYTES); uR.resize(cap); depth.resize(cap); }
+        int32_t n[2] = { 0, 0 };
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = hs_orb_wait(h, ticket, kps.data(), desc.data(), n, cap, uR.data(), depth.data());
+        if (st != HS_OK) throw std::runtime_error(std::string("HipStereoFrontend: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        timing.abi_ms = hip_detail::ms_since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::vector<cv::KeyPoint> keys[2]; std::vector<FeatureDescriptor> descs[2];
+        for (int s = 0; s < 2; s++) {
+            keys[s].reserve(n[s]); descs[s].reserve(n[s]);
+            for (int i = 0; i < n[s]; i++) {
+                const hs_keypoint& q = kps[(size_t)s * cap + i];
+                cv::KeyPoint k;
+                k.pt.x = q.x; k.pt.y = q.y; k.size = q.size; k.angle = q.angle; k.response = q.response; k.octave = q.octave; k.class_id = -1;
+                keys[s].push_back(k);
+                descs[s].push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + ((size_t)s * cap + i) * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
+            }
+        }
+        FeatureViews views(keys[0], keys[1], std::vector<float>(uR.begin(), uR.begin() + n[0]), std::vector<float>(depth.begin(), depth.begin() + n[0]),
+                           descs[0], descs[1], views_params);
+        timing.scatter_ms = hip_detail::ms_since(t1);
+        return views;
+    }
+    FeatureViews process(const cv::Mat& imLeft, const cv::Mat& imRight) { return collect(submit(imLeft, imRight)); }
+    hs_orb* handle() { return h; }
+    HipCallTiming timing;             // gather = submit (H2D enqueue), abi = wait, scatter = FeatureViews construction
+
+private:
+    hs_orb* h = nullptr; hs_stereo_params sp;
+    std::shared_ptr<DescriptorDistance> dist_func;
+    FeatureExtractorSettings orb_params, views_params;     // views_params: default-constructed, like ImageProcessing.cpp:85
+    std::vector<hs_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> uR, depth;
+};
+
 }  // namespace HYSLAM

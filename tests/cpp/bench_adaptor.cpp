@@ -91,6 +91,28 @@ int main(int argc, char** argv)
     const int n_kp = last_views.numViews();
     int n_stereo = 0; for (int i = 0; i < n_kp; i++) n_stereo += last_views.depth(i) > 0;
 
+    // ---- the optional one-call front end (HipStereoFrontend): one ticket per pair, synchronous, then two tickets in flight
+    std::vector<double> f_total, f_abi, f_scatter, f_pipe;
+    {
+        HipStereoFrontend fe(factory->getDistanceFunc(), per_type["SLAM"], cam, FeatureMatcherSettings(), 0);
+        for (int r = 0; r < reps + 3; r++) {
+            const auto t0 = clk::now();
+            FeatureViews v = fe.process(imL, imR);
+            const auto t1 = clk::now();
+            if (r >= 3) { f_total.push_back(ms(t0, t1)); f_abi.push_back(fe.timing.gather_ms + fe.timing.abi_ms); f_scatter.push_back(fe.timing.scatter_ms); }
+            if (v.numViews() != n_kp) { printf("front end: %d views, extractors: %d\n", v.numViews(), n_kp); return 5; }
+        }
+        int32_t tk = fe.submit(imL, imR);
+        const auto p0 = clk::now();
+        for (int r = 0; r < reps; r++) {                      // submit pair r+1, then collect pair r: the upload of one runs under the kernels of the other
+            const int32_t nx = fe.submit(imL, imR);
+            FeatureViews v = fe.collect(tk);
+            tk = nx;
+        }
+        f_pipe.push_back(ms(p0, clk::now()) / reps);
+        fe.collect(tk);
+    }
+
     // ---- TrackLocalMap: a local map of n_lm landmarks = the frame's keypoints back-projected at their stereo depth (or a seeded one), several noisy copies
     std::shared_ptr<DescriptorDistance> dist = factory->getDistanceFunc();
     cv::Mat Tcw(4, 4, CV_32F);
@@ -146,11 +168,12 @@ int main(int argc, char** argv)
         }
     }
     printf("{\"frame\": \"%dx%d\", \"keypoints\": %d, \"stereo_matches\": %d, \"reps\": %d,\n"
+           " \"HipStereoFrontend_ms\": {\"process_total\": %.3f, \"submit_plus_wait\": %.3f, \"FeatureViews_build\": %.3f, \"pipelined_per_pair\": %.3f},\n"
            " \"ProcessStereoImage_ms\": {\"total\": %.3f, \"extract_LR_threads\": %.3f, \"extract_c_abi\": %.3f, \"extract_scatter\": %.3f, \"FeatureViews_ctor\": %.3f,"
            " \"stereo_gather\": %.3f, \"stereo_c_abi\": %.3f, \"getData\": %.3f},\n"
            " \"TrackLocalMap_SearchByProjection_ms\": {\"landmarks\": %d, \"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f, \"scatter\": %.3f},\n"
            " \"SearchForTriangulation_ms\": {\"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f}}\n",
-           w, h, n_kp, n_stereo, reps, median(t_total), median(t_extract), median(t_exL_abi), median(t_exL_scatter), median(t_views), median(t_sm_gather), median(t_sm_abi),
+           w, h, n_kp, n_stereo, reps, median(f_total), median(f_abi), median(f_scatter), median(f_pipe), median(t_total), median(t_extract), median(t_exL_abi), median(t_exL_scatter), median(t_views), median(t_sm_gather), median(t_sm_abi),
            median(t_getdata), n_lm, n_proj, median(p_total), median(p_gather), median(p_abi), median(p_scatter), n_tri, median(q_total), median(q_gather), median(q_abi));
     return 0;
 }

@@ -53,6 +53,32 @@ int main(int argc, char** argv)
     for (int i = 0; i < nL; i++) { if (uR[i] != ouR[i] || depth[i] != odepth[i]) { printf("stereo %d differs\n", i); return 10; } matches += depth[i] > 0; }
     std::vector<float> sf = exL.GetScaleFactors();
     if (exL.GetLevels() != 8 || sf.size() != 8 || sf[1] != 1.2f) return 11;
+    // ---- HipStereoFrontend: the same pair as ONE ticket (extract L+R + stereo match), synchronously and with two tickets in flight
+    {
+        Camera cam; cam.sensor = 1;
+        for (int i = 0; i < 9; i++) cam.K.at<float>(i / 3, i % 3) = 0.f;
+        cam.K.at<float>(0, 0) = 500.f; cam.K.at<float>(1, 1) = 500.f; cam.K.at<float>(2, 2) = 1.f;
+        cam.mbf = 60.f; cam.mnMaxX = (float)W; cam.mnMaxY = (float)H;
+        HipStereoFrontend fe(dist, s, cam, ms);
+        auto same = [&](const FeatureViews& v, const char* what) {
+            if (v.numViews() != nL || (int)v.getKeysR().size() != nR || !v.isStereo()) { printf("%s: counts differ\n", what); return false; }
+            const std::vector<cv::KeyPoint> kr = v.getKeysR(); const std::vector<FeatureDescriptor> dr = v.getDescriptorsR();
+            for (int i = 0; i < nL; i++) {
+                const cv::KeyPoint k = v.keypt(i);
+                if (k.pt.x != okL[i].x || k.pt.y != okL[i].y || k.angle != okL[i].angle || k.octave != okL[i].octave || k.size != okL[i].size || k.response != okL[i].response ||
+                    memcmp(v.descriptor(i).rawDescriptor().ptr(0), &odL[i * 32], 32) || v.uR(i) != ouR[i] || v.depth(i) != odepth[i]) { printf("%s: left view %d differs\n", what, i); return false; }
+            }
+            for (int i = 0; i < nR; i++)
+                if (kr[i].pt.x != okR[i].x || kr[i].pt.y != okR[i].y || kr[i].angle != okR[i].angle || memcmp(dr[i].rawDescriptor().ptr(0), &odR[i * 32], 32)) { printf("%s: right view %d differs\n", what, i); return false; }
+            return true;
+        };
+        if (!same(fe.process(L, R), "frontend process")) return 12;
+        const int32_t t1 = fe.submit(L, R), t2 = fe.submit(L, R);            // two tickets in flight
+        bool threw = false;
+        try { fe.submit(L, R); } catch (const std::exception&) { threw = true; }
+        if (!threw) { printf("a third ticket was accepted\n"); return 13; }
+        if (!same(fe.collect(t2), "frontend ticket 2") || !same(fe.collect(t1), "frontend ticket 1")) return 14;
+    }
     printf("ADAPTOR OK %d %d keypoints, %d stereo matches\n", nL, nR, matches);
     return 0;
 }
