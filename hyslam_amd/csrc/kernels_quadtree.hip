@@ -132,7 +132,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     int16_t* const proc_rank = s_idx3;                                                  // processing rank of a node in this pass, -1 = not split
     int16_t* const order_node = s_idx3 + QT_M;                                          // rank -> node
     uint16_t* const new_index = reinterpret_cast<uint16_t*>(s_idx3 + 2 * QT_M);         // surviving node -> index in the next list
-    __shared__ uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
+    __shared__ alignas(16) uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
     __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node (count domain: their geometric key), when there
     __shared__ uint16_t s_pnode[QT_PTS];           // are <= QT_PTS of them: every sweep walks the points from LDS instead of through L2
     __shared__ int s_wave[2 * (QT_T / 64)];
@@ -228,18 +228,20 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     int n = 0;
     {
         uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [round items + 1] exclusive offsets of the round's items
-        static_assert(sizeof(child_index) >= (QT_T + 1) * 4, "s_pre scratch");
+        uint32_t* const s_src0 = s_pre + QT_T + 4;                               // [round items] first slot of the item minus its offset: record e sits at s_src0[item] + e
+        static_assert(sizeof(child_index) >= (2 * QT_T + 4) * 4, "s_pre / s_src0 scratch");
         const int nitem = L.nrows * L.ngroups;
         const int ccap = hs_cell_cap(L.wcell, L.hcell);
         const int32_t* ccnt = cell_count + (size_t)img * total_cells + L.cell_begin;
         const uint2* src = cand + (size_t)img * cand_img_stride + L.cand_off;
+        bool keys_to_global = true;                                // false once it is certain that all points fit the LDS copy (one round, <= QT_PTS records)
         auto put = [&](int pos, uint32_t key, uint32_t sk) {
             pxy[pos] = key; psk[pos] = sk;
             if (pos < QT_PTS) s_pxy[pos] = key;
             if (cf_geom) {
                 const int gk = geo_key(key & 0xFFFF, key >> 16);
                 if (pos < QT_PTS) s_pnode[pos] = (uint16_t)gk;
-                pnode[pos] = (uint16_t)gk;
+                if (keys_to_global) pnode[pos] = (uint16_t)gk;
                 atomicAdd(reinterpret_cast<uint32_t*>(s_rect) + (gk >> 1), 1u << ((gk & 1) * 16));
             }
         };
@@ -252,8 +254,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 k = min(max(ccnt[c0], 0), min(L.grp_cells, L.ncols - gj * L.grp_cells) * ccap);
             }
             int tot; const int pre = block_scan_excl(k, s_wave, sflip, tot);
-            if (tid < ni) s_pre[tid] = (uint32_t)pre;
+            if (tid < ni) { s_pre[tid] = (uint32_t)pre; s_src0[tid] = (uint32_t)(c0 * ccap - pre); }      // (no division per record later)
             if (tid == 0) s_pre[ni] = (uint32_t)tot;
+            if (nitem <= QT_T && tot <= QT_PTS) keys_to_global = false;
             __syncthreads();
             QT_MARK(22);
             // Every wave takes a CONTIGUOUS run of the round's records, 64 at a time: the item of a run's first record comes from one
@@ -291,10 +294,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const int e = e0 + 64 * u + lane;
-                            if (e < e_end) {
-                                const int itg = i0 + item[u], ci = itg / L.ngroups, gj = itg - ci * L.ngroups;
-                                rec[u] = src[(size_t)(ci * L.ncols + gj * L.grp_cells) * ccap + (e - (int)s_pre[item[u]])];
-                            }
+                            if (e < e_end) rec[u] = src[s_src0[item[u]] + (uint32_t)e];
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++) { const int e = e0 + 64 * u + lane; if (e < e_end) put(n + e, rec[u].x, rec[u].y); }
@@ -321,26 +321,29 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     bool cm = cf_geom && n <= 65535;               // count domain: the pyramid's 16-bit counters cannot overflow
 
     // every point's node from its geometric key: the one list node on the point's root-to-leaf chain.  marks = (depth, cell) -> list index.
-    auto relabel_from_keys = [&](const QtNodes C) {
-        uint16_t* const mark = reinterpret_cast<uint16_t*>(ccount);
-        static_assert(sizeof(ccount) >= QT_HPYR * 2 && QT_HPYR % 8 == 0, "marks");
+    uint16_t* const mark = reinterpret_cast<uint16_t*>(ccount);
+    static_assert(sizeof(ccount) >= QT_HPYR * 2 && QT_HPYR % 8 == 0, "marks");
+    int mark_off[7];
+#pragma unroll
+    for (int d = 0; d < 7; d++) mark_off[d] = hoff(min(d, DH));
+    auto build_marks = [&](const QtNodes C) {
         const int pyr = hoff(-1);
         for (int i = tid; i < (pyr + 7) / 8; i += QT_T) reinterpret_cast<uint4*>(mark)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         __syncthreads();
         for (int i = tid; i < S; i += QT_T) { const int ek = C.ekey[i]; mark[hoff(ek >> 13) + (ek & 0x1FFF)] = (uint16_t)i; }
         __syncthreads();
-        int o[7];
+    };
+    auto node_of_key = [&](int gk) {
+        int m[7];
 #pragma unroll
-        for (int d = 0; d < 7; d++) o[d] = hoff(min(d, DH));
-        auto node_of_key = [&](int gk) {
-            int m[7];
+        for (int d = 0; d < 7; d++) m[d] = mark[mark_off[d] + (gk >> (2 * (DH - min(d, DH))))];      // independent reads; exactly one of them is a node
+        int e = m[0];
 #pragma unroll
-            for (int d = 0; d < 7; d++) m[d] = mark[o[d] + (gk >> (2 * (DH - min(d, DH))))];      // independent reads; exactly one of them is a node
-            int e = m[0];
-#pragma unroll
-            for (int d = 1; d < 7; d++) if (m[d] != 0xFFFF) e = m[d];
-            return e;
-        };
+        for (int d = 1; d < 7; d++) if (m[d] != 0xFFFF) e = m[d];
+        return e;
+    };
+    auto relabel_from_keys = [&](const QtNodes C) {
+        build_marks(C);
         if (in_lds) {
             int gk[QT_PTS / QT_T];
 #pragma unroll
@@ -777,11 +780,14 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         if (S >= N || S == prevSize) break;
         if (!phase2 && (S + nToExpand * 3) > N) phase2 = true;
     }
-    if (cm) relabel_from_keys(view(cur));           // the distribution ended in the count domain: label the points now
-
+    // ---- keep the best point of every node (:381-400), emit in list order.  When the distribution ended in the count domain the points still
+    //      carry their geometric keys: the node is looked up on the fly (marks in the child-count array, the best-point slots in the
+    //      child-index array), one sweep instead of two.
+    const bool keyed = cm;                                           // uniform
+    if (keyed) build_marks(view(cur));
     QT_MARK(3);
-    // ---- keep the best point of every node (:381-400), emit in list order
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(ccount);      // QT_M * 8 bytes <= sizeof(ccount)
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(keyed ? reinterpret_cast<uint32_t*>(child_index) : ccount);      // QT_M * 8 bytes either way
+    static_assert(sizeof(child_index) >= QT_M * 8, "best-point slots");
     for (int i = tid; i < S; i += QT_T) best[i] = 0ull;
     __syncthreads();
     auto offer = [&](uint32_t xy, uint32_t sk, int node) {
@@ -790,18 +796,22 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         atomicMax(&best[node], key);
     };
     if (in_lds) {
-        uint32_t sk[QT_PTS / QT_T];
+        uint32_t sk[QT_PTS / QT_T]; int nd[QT_PTS / QT_T];
 #pragma unroll
-        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; sk[k] = p < n ? psk[p] : 0u; }      // global loads, all in flight
+        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; sk[k] = p < n ? psk[p] : 0u; nd[k] = p < n ? (int)s_pnode[p] : 0; }      // global loads, all in flight
+        if (keyed) {
 #pragma unroll
-        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) offer(s_pxy[p], sk[k], (int)s_pnode[p]); }
+            for (int k = 0; k < QT_PTS / QT_T; k++) nd[k] = node_of_key(nd[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) offer(s_pxy[p], sk[k], nd[k]); }
     } else {
         for (int p0 = tid; p0 < n; p0 += 8 * QT_T) {                  // points in global memory: eight records in flight per thread
             uint32_t xy[8], sk[8]; int nd[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; const bool on = p < n; xy[k] = on ? pxy[p] : 0u; sk[k] = on ? psk[p] : 0u; nd[k] = on ? (int)pnode[p] : 0; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; if (p < n) offer(xy[k], sk[k], nd[k]); }
+            for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; if (p < n) offer(xy[k], sk[k], keyed ? node_of_key(nd[k]) : nd[k]); }
         }
     }
     __syncthreads();
