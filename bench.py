@@ -70,6 +70,8 @@ def parse_args():
                     help="every timed step repeats its batch `inner_repeats` times so that the K timed steps cover at least this much GPU time "
                          "(0 = one pass per step); value counts every pass")
     ap.add_argument("--pcie-seconds", type=float, default=1.5, help="c2, N = 1: budget of the host-fed (PCIe-inclusive) secondary measurement (0 = skip)")
+    ap.add_argument("--c4-split", type=int, choices=[0, 1], default=1,
+                    help="c4: hs_orb_set_split(1) on both camera handles (level 0's FAST + quadtree on a second stream beside the pyramid); 0 = the library default")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: ranks rendezvous over gloo, exchange one tensor and rank 0 prints a JSON line (covers the --gpus spawn path on CPU)")
     return ap.parse_args()
@@ -494,6 +496,9 @@ def run_c4(args, rank, world, local_rank, dev, torch, dist, HS, N):
     exi = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=IFEAT, fScaleFactor=1.4), device=local_rank)
     ex.reserve(W, H, 2)
     exi.reserve(IW, IH, 1)
+    if args.c4_split:                # two cameras share the GPU: split both launch sequences so that their kernels interleave (hs_orb_set_split)
+        ex.set_split(1)
+        exi.set_split(1)
     cap, icap = ex.max_keypoints(), exi.max_keypoints()
     kb = N.KP_DTYPE.itemsize
     mk = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device=dev)
@@ -565,7 +570,8 @@ def run_c4(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out = base_line("dual-camera steps/sec: 1080p stereo extract+match + 4000x3000 extract + 50k-landmark SearchByProjection", value, "steps/s", args, world, elapsed)
     out["config"] = {"workload": "C4: per step one 1920x1080 stereo pair (2000 feat @1.2) + one 4000x3000 frame (3000 feat @1.4) + SearchByProjection of a "
                                  "50 000-landmark local map (th 5, nnratio 0.8) on the stereo frame's device-resident outputs",
-                     "keypoints_stereo_left": n0, "keypoints_imaging": int(inn.item()), "projection_matches": int(nm.item()), "landmarks": L}
+                     "keypoints_stereo_left": n0, "keypoints_imaging": int(inn.item()), "projection_matches": int(nm.item()), "landmarks": L,
+                     "split_launch_sequences": bool(args.c4_split)}
     out["stage_ms"] = {k: round(v, 4) for k, v in times.items()}
     dom = max(times, key=times.get)
     dom_bytes = {"stereo_frontend": 2 * pair_frame, "projection_50k": proj_bytes, "imaging_extract": img_frame}[dom]

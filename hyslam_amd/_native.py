@@ -71,7 +71,7 @@ EXPORTS = [
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_device", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait",
-    "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_synchronize",
+    "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_set_split", "hs_orb_synchronize",
     "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
@@ -135,6 +135,7 @@ def lib():
     L.hs_orb_last_error.restype = C.c_char_p
     L.hs_orb_get_levels.argtypes = [vp]
     L.hs_orb_get_device.argtypes = [vp]
+    L.hs_orb_set_split.argtypes = [vp, C.c_int]
     L.hs_orb_get_scale_factor.argtypes = [vp]
     L.hs_orb_get_scale_factor.restype = f32
     L.hs_orb_get_scale_tables.argtypes = [vp, vp, vp, vp, vp, vp]

@@ -20,6 +20,8 @@ struct hs_orb {
     uint16_t taps[7];
     HsFastKnobs fast_knobs{};          // HS_FAST_* environment knobs, read once in hs_orb_create
     uint32_t fast_epoch = 0;           // FAST launches on this workspace so far (selects the work-queue counter set)
+    int split_mode = -1;               // HS_EXTRACT_SPLIT (read once): 1 = always run level 0's FAST + quadtree beside the pyramid, 0 = never, -1 = for small batches
+    hipStream_t s_aux = nullptr; hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;      // the second launch sequence of the split and its fences
     bool qt_point_domain = false;      // HS_QT_POINT_DOMAIN=1 (read once): the quadtree's general point-domain passes only (parity tests of the fallback)
     bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
@@ -243,7 +245,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch, h->fast_knobs), 256)));
-        HIP_TRY(h, hipMemset(h->d_fast_ovf, 0, 2 * HS_FAST_QUEUE_DWORDS * 4));       // both work-queue counter sets start at zero
+        HIP_TRY(h, hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4));       // all four work-queue counter sets start at zero
     }
     h->w = w; h->h = hh; h->batch_cap = batch;      // configured only now
     return HS_OK;
@@ -313,23 +315,60 @@ int ensure_stereo_scratch(hs_orb* h, size_t entries)
 int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
 {
     const int L = h->p.nlevels;
-    mark(h, 0, s);
-    hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
-    mark(h, 1, s);
-    {   // launch N uses work-queue counter set N & 1 and relies on launch N - 1 having zeroed it: the epoch advances only when a launch was
-        // enqueued without error; after a failed launch both sets are zeroed again so that the next one starts from a known state
+    // Level 0 needs no pyramid.  For one or two LARGE frames the chain of launches is latency-bound (dependent pyramid launches, a FAST launch
+    // whose duration is its slowest work item, the level-0 quadtree workgroup — 0.11 ms for a 4000 x 3000 frame): level 0's FAST + quadtree run
+    // on a second stream BESIDE the pyramid and the other levels' FAST + quadtree, joined before the describe stage.  Same kernels, same
+    // results.  Measured: the 4000 x 3000 "Imaging" extraction 0.245 -> 0.16 ms (config C4: 2 350 -> 3 550 steps/s); a 1080p pair gets SLOWER
+    // (0.132 -> 0.160 ms: the fork / join between the streams costs more than the overlap saves), 16 pairs too (0.468 -> 0.519 ms), hence the
+    // size rule.  Not with stage events (they would serialise the two sequences).
+    const int items0 = L > 1 ? h->lv[1].item_begin : h->fast_items;            // work items of level 0 come first in the item list
+    const bool split = !h->prof && L > 1 && items0 > 0 && items0 < h->fast_items && (h->split_mode == 1 || (h->split_mode < 0 && batch <= 2 && (size_t)h->w * (size_t)h->h * (size_t)batch >= 6000000));
+    auto fast = [&](int item_first, int item_count, int spill_slot, hipStream_t st) -> int {
+        // launch N uses work-queue counter set N & 3 and relies on launch N - 2 having zeroed it: the epoch advances only when a launch was
+        // enqueued without error; after a failed launch all sets are zeroed again so that the next one starts from a known state
         const bool launched = hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
-                                             h->d_cand, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs, s);
+                                             h->d_cand, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs,
+                                             item_first, item_count, spill_slot, st);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
-            (void)hipMemsetAsync(h->d_fast_ovf, 0, 2 * HS_FAST_QUEUE_DWORDS * 4, s);
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4);
             return fail(h, HS_ERR_HIP, std::string("FAST launch: ") + hipGetErrorString(e));
         }
         if (launched) h->fast_epoch++;
+        return HS_OK;
+    };
+    auto quadtree = [&](int level_first, int level_count, hipStream_t st) {
+        hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
+                           h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0,
+                           level_first, level_count, st);
+    };
+    if (split) {
+        if (!h->s_aux) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sfork, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sjoin, hipEventDisableTiming));
+        }
+        HIP_TRY(h, hipEventRecord(h->ev_sfork, s));                           // everything enqueued on s so far (the frames' upload, the previous call) comes first
+        HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_sfork, 0));
+        int rc = fast(0, items0, 1, h->s_aux);
+        if (rc != HS_OK) return rc;
+        quadtree(0, 1, h->s_aux);
+        HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
+        hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+        rc = fast(items0, h->fast_items - items0, 0, s);
+        if (rc != HS_OK) return rc;
+        quadtree(1, L - 1, s);
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
+    } else {
+        mark(h, 0, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+        mark(h, 1, s);
+        const int rc = fast(0, h->fast_items, 0, s);
+        if (rc != HS_OK) return rc;
+        mark(h, 2, s);
+        quadtree(0, L, s);
     }
-    mark(h, 2, s);
-    hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
-                       h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0, s);
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->d_sel_perm, h->sel_img_stride, h->max_kp,
                        h->d_taps, out, s, h->fast_taps);
@@ -426,6 +465,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
+    { const char* e = getenv("HS_EXTRACT_SPLIT"); h->split_mode = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
     static const uint16_t def[7] = { 18, 34, 49, 55, 49, 34, 18 };
     for (int k = 0; k < 7; k++) h->taps[k] = zero ? def[k] : p->blur_taps[k];
@@ -465,6 +505,9 @@ void hs_orb_destroy(hs_orb* h)
     if (h->lane2) { hs_orb_destroy(h->lane2); h->lane2 = nullptr; }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->s_aux) { hipStreamSynchronize(h->s_aux); hipStreamDestroy(h->s_aux); }
+    if (h->ev_sfork) hipEventDestroy(h->ev_sfork);
+    if (h->ev_sjoin) hipEventDestroy(h->ev_sjoin);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_geometry(h);
     hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
@@ -1345,6 +1388,15 @@ int hs_orb_set_lanes(hs_orb* h, int lanes)
         if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         if (!h->ev_join) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
+    return HS_OK;
+}
+
+int hs_orb_set_split(hs_orb* h, int mode)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (mode < -1 || mode > 1) return fail(h, HS_ERR_INVALID, "split mode must be -1 (auto), 0 or 1");
+    h->split_mode = mode;
+    if (h->lane2) h->lane2->split_mode = mode;
     return HS_OK;
 }
 

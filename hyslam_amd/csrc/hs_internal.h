@@ -129,18 +129,19 @@ int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kerne
 int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
 int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
-#define HS_FAST_QUEUE_DWORDS 256   // head of the FAST overflow buffer: two alternating sets of 8 work-queue counters on 128-byte lines of their own
+#define HS_FAST_QUEUE_DWORDS 256   // head of the FAST overflow buffer: FOUR rotating sets of 8 work-queue counters on 128-byte lines of their own
 struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand /*{y<<16|x, score<<24|cell} per slot*/, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
-                    const HsFastKnobs& knobs, hipStream_t s);
+                    const HsFastKnobs& knobs, int item_first, int item_count /*the launch covers items [first, first + count) of every image*/,
+                    int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, hipStream_t s);
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count, hipStream_t s);
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
                         const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps);

@@ -114,7 +114,7 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
 {
     RowGeom g;
     g.img = w / items_per_img;
-    const HsFastItem it = items[w - g.img * items_per_img];     // one s_load_dwordx16
+    const HsFastItem it = items[w - g.img * items_per_img];     // one s_load_dwordx16 (`items` already points at the launch's first item)
     g.ncell = it.ncell; g.c0 = it.c0; g.gcell0 = it.gcell0; g.slot0 = it.slot0; g.ccap = it.ccap;
     g.inv_w = it.inv_w; g.inv_w1 = it.inv_w1;
     g.xoff = it.xoff; g.yoff = it.yoff;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
-                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch)
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -194,12 +194,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
     uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
     uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
-    uint32_t* const queue = overflow + (size_t)(epoch & 1) * HS_FAST_QUEUE_DWORDS;   // 8 work counters, 128 bytes apart
-    if (blockIdx.x == 0 && threadIdx.x < 8) overflow[(size_t)((epoch + 1) & 1) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
-    uint32_t* const ovf = overflow + 2 * HS_FAST_QUEUE_DWORDS + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
+    uint32_t* const queue = overflow + (size_t)(epoch & 3) * HS_FAST_QUEUE_DWORDS;   // 8 work counters, 128 bytes apart
+    if (blockIdx.x == 0 && threadIdx.x < 8) overflow[(size_t)((epoch + 2) & 3) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
+    uint32_t* const ovf = overflow + 4 * HS_FAST_QUEUE_DWORDS + spill_base + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
     const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
     const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
 
+    items += item_first;                                         // this launch covers items [item_first, item_first + items_per_img) of every image
     const int tid = threadIdx.x;
     const int col = tid & (COLS - 1), sub = tid >> LC;
     const int ld_row = tid / LPR, ld_c16 = tid % LPR;
@@ -216,8 +217,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     // wave cycles waiting).  The grab for the item after next is issued right after the next tile's prefetch and consumed an item later,
     // so its latency is never exposed; 8 counters on lines of their own see ~11 grabs/us each.  When a queue runs dry its waves steal
     // from the other queues, and leave when all eight are empty (every wave reaches that exit: the counters only grow).
-    // Two counter sets alternate between launches: a launch uses set `epoch & 1` and its first workgroup zeroes the OTHER set for the launch
-    // after it (launches of a handle are ordered on its stream; both sets start at zero) — no memset launch in the chain.
+    // Four counter sets rotate between launches: a launch uses set `epoch & 3` and its first workgroup zeroes set `(epoch + 2) & 3` for the
+    // launch after next — no memset launch in the chain.  Two consecutive launches of a handle may run CONCURRENTLY (level 0 beside the
+    // pyramid, the other levels after it: hs_api.hip), which is why the set a launch zeroes is not the next launch's.
     const int per_x = (total_work + 7) >> 3, wpx = gridDim.x >> 3;
     int q = (int)(blockIdx.x & 7);                               // current queue (wave-uniform)
     auto q_size = [&](int qq) { return min(max(total_work - qq * per_x, 0), per_x); };
@@ -652,12 +654,12 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
-    return (size_t)2 * HS_FAST_QUEUE_DWORDS * 4 + (size_t)fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;
+    return (size_t)4 * HS_FAST_QUEUE_DWORDS * 4 + (size_t)2 * fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;      // two launches may be in flight
 }
 
 static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int spill_slot, int items_all, hipStream_t s)
 {
     (void)max_wcell;
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
@@ -667,8 +669,9 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
+    const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
@@ -679,9 +682,10 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 // so the caller advances its epoch only for launches that happened
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int item_count, int spill_slot, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
-    if (total_cells <= 0) return false;
-    return launch_fast_rows(d_items, img0, batch, total_cells, items_per_img, fast_th, cand, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs, s);
+    if (total_cells <= 0 || item_count <= 0) return false;
+    return launch_fast_rows(d_items, img0, batch, total_cells, item_count, fast_th, cand, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs,
+                            item_first, spill_slot, items_per_img, s);
 }

@@ -112,7 +112,7 @@ __device__ __forceinline__ int child_of(const QtNodes N, int nd, int x, int y)
 #ifdef HS_QT_PROFILE
 __device__ unsigned long long g_qt_prof[128];
 extern "C" void hs_debug_qt_profile(unsigned long long* out128) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_qt_prof), sizeof(unsigned long long) * 128); }
-#define QT_MARK(tag) do { if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && qt_k < 126) { g_qt_prof[qt_k++] = __builtin_amdgcn_s_memtime(); g_qt_prof[qt_k++] = (tag); } } while (0)
+#define QT_MARK(tag) do { if (tid == 0 && level_first + blockIdx.x == 0 && blockIdx.y == 0 && qt_k < 126) { g_qt_prof[qt_k++] = __builtin_amdgcn_s_memtime(); g_qt_prof[qt_k++] = (tag); } } while (0)
 #else
 #define QT_MARK(tag)
 #endif
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride,
-                                                   uint16_t* __restrict__ sel_perm, int force_point_domain)
+                                                   uint16_t* __restrict__ sel_perm, int force_point_domain, int level_first)
 {
     __shared__ QtRects s_rect[2];                  // point domain: node rectangles; count domain: the histogram pyramid (u16)
     __shared__ uint32_t s_cnt[2][QT_M];            // points per node
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     int qt_k = 0;
 #endif
     QT_MARK(0);
-    const int level = blockIdx.x, img = blockIdx.y;
+    const int level = level_first + blockIdx.x, img = blockIdx.y;
     const HsLevel& L = lv[level];
     const int N = L.quota;
     uint32_t* pxy = pts_xy_all + (size_t)img * cand_img_stride + L.cand_off;
@@ -871,16 +871,17 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     }
     QT_MARK(4);
 #ifdef HS_QT_PROFILE
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_qt_prof[127] = qt_k;
+    if (tid == 0 && level_first + blockIdx.x == 0 && blockIdx.y == 0) g_qt_prof[127] = qt_k;
 #endif
 }
 
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, hipStream_t s)
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, int level_first, int level_count, hipStream_t s)
 {
-    dim3 grid(nlevels, batch, 1);
+    if (level_count <= 0) return;
+    dim3 grid(level_count, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first);
 }

@@ -207,6 +207,10 @@ class ORBExtractor:
         """1 or 2 internal launch sequences for the batched device entry points (hs_orb_set_lanes)."""
         N.check(self._h, self._lib.hs_orb_set_lanes(self._h, int(lanes)))
 
+    def set_split(self, mode):
+        """-1 auto, 0 never, 1 always: level 0's FAST + quadtree on a second stream beside the pyramid (hs_orb_set_split)"""
+        N.check(self._h, self._lib.hs_orb_set_split(self._h, int(mode)))
+
     def synchronize(self, stream=0):
         N.check(self._h, self._lib.hs_orb_synchronize(self._h, stream or None))
 

@@ -148,6 +148,13 @@ int  hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uin
  * caller's stream reaches the point after the call.  Default 1. */
 int  hs_orb_set_lanes(hs_orb* h, int lanes);
 
+/* The launch sequence of an extraction can be SPLIT: level 0 needs no pyramid, so its FAST + quadtree can run on a second stream of the handle
+ * beside the pyramid and the other levels' FAST + quadtree (joined before the describe stage; same kernels, same results).  mode -1 (default): split
+ * one or two large frames (>= 6 Mpx per call: a 4000 x 3000 "Imaging" frame: 0.24 -> 0.22 ms); 0: never; 1: always.  For an isolated 1080p pair the
+ * fork / join between the streams costs more than the overlap saves (0.132 -> 0.160 ms), but when several handles share the GPU (hySLAM's SLAM stereo
+ * camera + Imaging camera, BASELINE config 4) splitting BOTH lets their kernels interleave: 2 400 -> 3 500 steps/s.  Ignored while stage events are on. */
+int  hs_orb_set_split(hs_orb* h, int mode);
+
 /* block until everything enqueued on the handle's own stream (or `stream`) has finished */
 int  hs_orb_synchronize(hs_orb* h, void* stream);
 
@@ -357,7 +364,8 @@ int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_s
  * (ncclCommInitRank).  One process per GPU.  hs_comm_allgather_records enqueues ncclAllGather of `record_bytes` bytes per rank on `stream`
  * (NULL = the handle's stream): d_gathered [world][record_bytes]; in place when d_record == d_gathered + rank * record_bytes.  With the
  * extraction before it and the matcher after it on the same stream a config-5 step needs no event and no host synchronisation.
- * librccl is loaded on first use (dlopen): HS_ERR_NO_DEVICE when it or a GPU is missing.  Asynchronous. */
+ * librccl is loaded on first use (dlopen): HS_ERR_NO_DEVICE when it or a GPU is missing.  Asynchronous.
+ * Destroy a communicator BEFORE the handle it was created on. */
 #define HS_COMM_ID_BYTES 128
 typedef struct hs_comm hs_comm;
 int  hs_comm_get_unique_id(uint8_t* id /* [HS_COMM_ID_BYTES] */);

@@ -192,11 +192,12 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
-@pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
+@pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_EXTRACT_SPLIT": "1"}, {"HS_EXTRACT_SPLIT": "0"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
-    """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, and NMS driven from the score
-    tile instead of the corner list: same bits as the oracle"""
+    """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, NMS driven from the score
+    tile instead of the corner list, the quadtree's point-domain passes, and the split launch sequence (level 0's FAST + quadtree on a second
+    stream beside the pyramid) forced on / off: same bits as the oracle"""
     e = dict(os.environ)
     e.update(env)
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
