@@ -51,22 +51,49 @@ __device__ __forceinline__ int wave_append(bool flag, int& base)
     return slot;
 }
 
-// Corner score of a pixel that passed the segment test with polarity `dark` (d[k] = v - ring[k] for dark, ring[k] - v for bright).
+// Corner score of a pixel that passed the segment test with polarity `bright`.
 // cv::FAST's cornerScore<16> is max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1; for a corner of one polarity the other
-// polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with d of its own polarity.
-__device__ __forceinline__ int fast_corner_score(const int (&d)[16])
+// polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with d[k] = v - ring[k]
+// (dark) or ring[k] - v (bright).  Two ring pixels per 32-bit register and packed 16-bit min / max:
+//   R_j  = (ring[2j], ring[2j+1])            one byte permute of two byte loads
+//   A_j  = (d[2j], d[2j+1])                  one v_pk_mad_i16 with the per-lane sign: R * (-s) + s*v
+//   B_j  = (d[2j+1], d[2j+2])                one byte permute of (A_j, A_j+1)
+//   L2_j = min(A_j, B_j)                     = (lo2[2j], lo2[2j+1]),  lo2[k] = min(d[k], d[k+1])
+//   L4_j = min(L2_j, L2_j+1), L8_j = min(L4_j, L4_j+2)                lo8[k] = min(d[k..k+7])
+//   arc9 = min(L8_j, A_j+4)                  = the 9-arcs starting at 2j and 2j+1;  score = max over j and halves - 1
+// 68 VALU instructions per corner instead of 111 with one value per register.  Measured and dropped: ds_read_u8_d16 / _d16_hi would
+// pack the pairs for free, but with SRAM-ECC a d16 load zeroes the other half of the register; seven UNALIGNED wide reads (4 bytes from
+// column -1 of rows +-3, 8 bytes from column -2 / -3 of the other rows) put every ring pixel at a fixed byte of a known register but
+// double the kernel's LDS busy time (0.33 -> 0.69 of the busy cycles): 0.203 -> 0.236 ms.
+typedef short fr_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fr_u(fr_s2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ fr_s2 fr_s(uint32_t x) { return __builtin_bit_cast(fr_s2, x); }
+// low 16-bit field = byte 0 of `lo`, high field = byte 0 of `hi`
+__device__ __forceinline__ uint32_t fr_pair(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x0C040C00u); }
+__device__ __forceinline__ int fast_corner_score_pk(const uint32_t (&R)[8], int v, bool bright)
 {
-    int lo2[16], lo4[16], lo8[16];
+    const uint32_t ns = bright ? 0x00010001u : 0xFFFFFFFFu;
+    const int sv1 = bright ? -v : v;
+    const uint32_t sv = __builtin_amdgcn_perm((uint32_t)sv1, (uint32_t)sv1, 0x05040504u);
+    fr_s2 A[8], B[8], L2[8], L4[8], L8[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) lo2[k] = min(d[k], d[(k + 1) & 15]);
+    for (int j = 0; j < 8; j++) {
+        uint32_t d;
+        asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(R[j]), "v"(ns), "v"(sv));
+        A[j] = fr_s(d);
+    }
 #pragma unroll
-    for (int k = 0; k < 16; k++) lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+    for (int j = 0; j < 8; j++) B[j] = fr_s(__builtin_amdgcn_alignbit(fr_u(A[(j + 1) & 7]), fr_u(A[j]), 16));
 #pragma unroll
-    for (int k = 0; k < 16; k++) lo8[k] = min(lo4[k], lo4[(k + 4) & 15]);
-    int a0 = min(lo8[0], d[8]);
+    for (int j = 0; j < 8; j++) L2[j] = __builtin_elementwise_min(A[j], B[j]);
 #pragma unroll
-    for (int k = 1; k < 16; k++) a0 = max(a0, min(lo8[k], d[(k + 8) & 15]));      // arcs of 9: d[k..k+8]
-    return a0 - 1;
+    for (int j = 0; j < 8; j++) L4[j] = __builtin_elementwise_min(L2[j], L2[(j + 1) & 7]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) L8[j] = __builtin_elementwise_min(L4[j], L4[(j + 2) & 7]);
+    fr_s2 mx = __builtin_elementwise_min(L8[0], A[4]);
+#pragma unroll
+    for (int j = 1; j < 8; j++) mx = __builtin_elementwise_max(mx, __builtin_elementwise_min(L8[j], A[(j + 4) & 7]));
+    return max((int)mx.x, (int)mx.y) - 1;
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -204,6 +231,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     const int tid = threadIdx.x;
     const int col = tid & (COLS - 1), sub = tid >> LC;
     const int ld_row = tid / LPR, ld_c16 = tid % LPR;
+    // byte transposition of the scan masks (see scan A): lane L's byte j comes from lane (L - 16 j) & 63
+    const int bp1 = ((tid - 16) & 63) << 2, bp2 = ((tid - 32) & 63) << 2, bp3 = ((tid - 48) & 63) << 2;
     const int t = min(max(fast_th, 0), 255);
     const uint32_t kbias = (0x80u - (uint32_t)((t + 1) >> 2)) * 0x01010101u;     // see scan A
     constexpr int RO[16] = { 3 * PITCH + 0, 3 * PITCH + 1, 2 * PITCH + 2, 1 * PITCH + 3, 0 * PITCH + 3, -1 * PITCH + 3, -2 * PITCH + 2, -3 * PITCH + 1,
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int i = i0 + tid;
                 const bool act = i < npx;
                 const int code = plist[act ? i : 0];
-                const int eb = code & 31, el = (code >> 5) & 63;                 // bit of the scan mask (8 * pixel + row), lane that found it
+                const int eb = code & 31, el = ((code >> 5) - ((code & 24) << 1)) & 63;   // bit of the scan mask (8 * pixel + row); lane that found it (its byte j sits 16 j lanes up)
                 const int py = BR * (RS * (code >> 11) + (el >> LC)) + (eb & 7);
                 const int px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
                 const int pos = (py << 8) | px;
@@ -366,11 +395,11 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int py = (pos >> 8) & 127, px = pos & 255;
                 const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
                 const int v = ctr[0];
-                int d[16];
+                uint32_t R[8];
 #pragma unroll
-                for (int k = 0; k < 16; k++) { int e = v - (int)ctr[RO[k]]; d[k] = bright ? -e : e; }
+                for (int j = 0; j < 8; j++) R[j] = fr_pair(ctr[RO[2 * j]], ctr[RO[2 * j + 1]]);
                 const int gc = (px * inv_w) >> 16;               // cell of the item; its columns start at 1 + gc*(wcell+1)
-                const uint32_t sc_pos = (uint32_t)(((py + 1) << 8) | (1 + px + gc)), sc_val = (uint32_t)fast_corner_score(d) & 0xFFu;
+                const uint32_t sc_pos = (uint32_t)(((py + 1) << 8) | (1 + px + gc)), sc_val = (uint32_t)fast_corner_score_pk(R, v, bright) & 0xFFu;
                 plist[i] = (uint16_t)sc_pos;                     // score tile coordinates: what nms_and_emit reads
                 pscore[i] = (uint8_t)sc_val;
             }
@@ -485,6 +514,16 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     }
                     const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior
                     M &= vmask8 & (((1u << nrow) - 1u) * 0x01010101u);
+                }
+                // The maybe-pixels come in clusters (both sides of a slanted edge): on the bench scene a block has its ~120 hits in ~14 of
+                // its 64 lanes, and the bit loop of emit_mask runs as long as the busiest lane has hits (17.7 rounds on average).  Each lane
+                // therefore keeps byte 0 (its first pixel column) and takes byte j from the lane 16 j to its left: the four columns of a
+                // lane's word are 64 px apart and a cluster's columns land in different lanes (8.4 rounds).  corners_and_scores undoes it
+                // when it decodes a code.
+                {
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)M), t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp2, (int)M),
+                                   t3 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp3, (int)M);
+                    M = (M & 0xFFu) | (t1 & 0xFF00u) | (t2 & 0xFF0000u) | (t3 & 0xFF000000u);
                 }
                 if (FR_STOP <= 1) { if (M == 0x12345u) plist[tid] = 1; continue; }      // keeps M live
                 emit_mask(M, y0, false, b);

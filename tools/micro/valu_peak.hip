@@ -49,6 +49,17 @@ __global__ __launch_bounds__(64) void k_issue(uint32_t* out, unsigned long long*
             if (OP == 27) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(c));
             if (OP == 28) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(c));
             if (OP == 29) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 30) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(x) : "v"(c));
+            if (OP == 31) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(c) : "vcc");
+            if (OP == 32) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(r[(k + 1) & 15]), "v"(c) : "vcc");
+            if (OP == 33) asm volatile("v_pk_mad_i16 %0, %0, %1, %1" : "+v"(x) : "v"(c));
+            if (OP == 34) asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1" : : "v"(x), "v"(c) : "s20", "s21");
+            if (OP == 35) asm volatile("s_and_b64 s[20:21], s[20:21], s[22:23]" : : : "s20", "s21", "scc");
+            if (OP == 36) asm volatile("v_perm_b32 %0, %0, %1, %1\n s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[24:25], s[24:25], s[22:23]" : "+v"(x) : "v"(c) : "s20", "s21", "s24", "s25", "scc");
+            if (OP == 37) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x) : "v"(c));
+            if (OP == 38) asm volatile("v_sub_u32 %0, %0, %1\n v_alignbit_b32 %2, %2, %0, 31" : "+v"(x), "+v"(r[(k + 8) & 15]) : "v"(c));
+            if (OP == 39) asm volatile("v_readlane_b32 s20, %0, 5" : : "v"(x) : "s20");
+            if (OP == 40) asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %1\n s_and_b64 s[24:25], s[24:25], s[20:21]\n s_or_b64 s[26:27], s[26:27], s[24:25]" : : "v"(x), "v"(c) : "s20", "s21", "s24", "s25", "s26", "s27", "scc");
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -113,5 +124,16 @@ int main()
     run<27>("v_pk_mul_lo_u16", d_out, d_cyc);
     run<28>("v_mad_u32_u24", d_out, d_cyc);
     run<29>("v_mul_u32_u24", d_out, d_cyc);
+    run<30>("v_sub_u32_sdwa byte", d_out, d_cyc);
+    run<31>("v_cmp_lt_u32 vcc", d_out, d_cyc);
+    run<32>("v_cmp+v_addc (x2)", d_out, d_cyc);
+    run<33>("v_pk_mad_i16", d_out, d_cyc);
+    run<34>("v_cmp_lt_u32_e64 sgpr", d_out, d_cyc);
+    run<35>("s_and_b64 (SALU)", d_out, d_cyc);
+    run<36>("v_perm + 2 SALU (x3)", d_out, d_cyc);
+    run<37>("v_pk_min_i16", d_out, d_cyc);
+    run<38>("v_sub+v_alignbit (x2)", d_out, d_cyc);
+    run<39>("v_readlane_b32", d_out, d_cyc);
+    run<40>("v_cmp_e64 + 2 SALU (x3)", d_out, d_cyc);
     return 0;
 }
