@@ -231,8 +231,6 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     const int tid = threadIdx.x;
     const int col = tid & (COLS - 1), sub = tid >> LC;
     const int ld_row = tid / LPR, ld_c16 = tid % LPR;
-    // byte transposition of the scan masks (see scan A): lane L's byte j comes from lane (L - 16 j) & 63
-    const int bp1 = ((tid - 16) & 63) << 2, bp2 = ((tid - 32) & 63) << 2, bp3 = ((tid - 48) & 63) << 2;
     const int t = min(max(fast_th, 0), 255);
     const uint32_t kbias = (0x80u - (uint32_t)((t + 1) >> 2)) * 0x01010101u;     // see scan A
     constexpr int RO[16] = { 3 * PITCH + 0, 3 * PITCH + 1, 2 * PITCH + 2, 1 * PITCH + 3, 0 * PITCH + 3, -1 * PITCH + 3, -2 * PITCH + 2, -3 * PITCH + 1,
@@ -356,34 +354,58 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             FR_FENCE();
             FR_T(tc0);
             int n_corner = n_done;
-            for (int i0 = n_done; i0 < npx; i0 += 64) {
+            int nend = npx;                                  // list end including the re-queued pixels (below)
+            for (int i0 = n_done; i0 < nend; i0 += 64) {
                 const int i = i0 + tid;
-                const bool act = i < npx;
+                const bool act = i < nend;
                 const int code = plist[act ? i : 0];
-                const int eb = code & 31, el = ((code >> 5) - ((code & 24) << 1)) & 63;   // bit of the scan mask (8 * pixel + row); lane that found it (its byte j sits 16 j lanes up)
-                const int py = BR * (RS * (code >> 11) + (el >> LC)) + (eb & 7);
+                const bool redo_dark = code & 0x8000;       // re-queued: passed both compass tests and is no bright corner
+                const int eb = code & 31, ew = (code >> 5) & 63;                 // bit of the scan mask (8 * pixel + row), lane that held the word
+                const int el = (ew & 48) | ((ew - ((code & 24) >> 1)) & 15);     // lane that found it: byte j sits 4 j lanes up in its row of 16
+                const int py = BR * (RS * ((code >> 11) & 15) + (el >> LC)) + (eb & 7);
                 const int px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
                 const int pos = (py << 8) | px;
                 const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
                 const int v = ctr[0];
                 const int lo = v - t, hi = v + t;
-                // one subtract + one v_alignbit per ring pixel and polarity: the sign bit of (r - lo) / (hi - r) is shifted into the mask
-                // (bit order comes out reversed, which a cyclic run test does not care about)
-                uint32_t mdark = 0, mbright = 0;
+                int r[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int r = ctr[RO[k]];
-                    mdark = __builtin_amdgcn_alignbit(mdark, (uint32_t)(r - lo), 31);
-                    mbright = __builtin_amdgcn_alignbit(mbright, (uint32_t)(hi - r), 31);
+                for (int k = 0; k < 16; k++) r[k] = ctr[RO[k]];
+                // ONE polarity per pixel.  A 9-arc contains two adjacent compass points (ring 0, 4, 8, 12), so a dark corner passes the exact
+                // compass test "(r0 or r8 darker) and (r4 or r12 darker)" and a bright corner its mirror image; practically no pixel passes
+                // both (0.00 % of the bench frames), so the 16 ring pixels go through the segment test of the polarity that can still
+                // succeed: one multiply-add (+-r -+ bound) and one v_alignbit per ring pixel — the sign bit of the difference is shifted into
+                // the mask (bit order comes out reversed, which a cyclic run test does not care about) — instead of two of each.
+                const bool dark_ok = max(min(r[0], r[8]), min(r[4], r[12])) < lo, bright_ok = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
+                auto run9 = [&](bool bright) -> bool {
+                    const int a = bright ? -1 : 1, b = bright ? hi : -lo;        // dark: r - lo < 0;  bright: hi - r < 0
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        uint32_t d;                                            // as asm: the compiler turns r * a into a select of r and -r (4 instructions per pixel)
+                        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(r[k]), "v"(a), "v"(b));
+                        m = __builtin_amdgcn_alignbit(m, d, 31);
+                    }
+                    m |= m << 16;
+                    uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
+                    return (x & 0xFFFFu) != 0;
+                };
+                bool bright = bright_ok && !redo_dark;
+                bool corner = run9(bright) && act && (dark_ok || bright_ok);
+                // Pixels that pass BOTH compass tests (6-8 % of the candidates on the reduced levels, 0.1 % on level 0) and are no bright
+                // corner need the dark test as well: they go back to the END of the list with bit 15 set and fill the lanes of the last,
+                // partly empty iteration (running the second test in place would double the cost of nearly every iteration).  The last
+                // iteration itself (whose lanes already cover the list end) and a full list run the second test in place.
+                const bool redo = act && dark_ok && bright_ok && !corner && !redo_dark;
+                if (__any(redo)) {
+                    if (i0 + 64 < nend && nend + 64 <= lds.pcap) {
+                        const int slot = wave_append(redo, nend);
+                        if (redo) plist[slot] = (uint16_t)(code | 0x8000);
+                    } else if (redo && run9(false)) { corner = true; bright = false; }
                 }
-                uint32_t m = mdark | (mdark << 16);
-                uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
-                uint32_t m2 = mbright | (mbright << 16);
-                uint32_t y = m2 & (m2 >> 1); y &= y >> 2; y &= y >> 4; y &= m2 >> 8;
-                const bool corner = act && ((x | y) & 0xFFFFu) != 0;
                 FR_FENCE();                                // this iteration's reads precede the in-place compaction writes
                 const int slot = wave_append(corner, n_corner);
-                if (corner) plist[slot] = (uint16_t)(pos | ((y & 0xFFFFu) ? 0x8000 : 0));
+                if (corner) plist[slot] = (uint16_t)(pos | (bright ? 0x8000 : 0));
             }
             FR_FENCE();
             FR_T(tc1);
@@ -517,12 +539,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 }
                 // The maybe-pixels come in clusters (both sides of a slanted edge): on the bench scene a block has its ~120 hits in ~14 of
                 // its 64 lanes, and the bit loop of emit_mask runs as long as the busiest lane has hits (17.7 rounds on average).  Each lane
-                // therefore keeps byte 0 (its first pixel column) and takes byte j from the lane 16 j to its left: the four columns of a
-                // lane's word are 64 px apart and a cluster's columns land in different lanes (8.4 rounds).  corners_and_scores undoes it
-                // when it decodes a code.
+                // therefore keeps byte 0 (its first pixel column) and takes byte j from the lane 4 j to its left in its row of 16 lanes (DPP
+                // row rotate): the four columns of a lane's word are 16 px apart and a cluster's columns land in different lanes (9.3
+                // rounds; 8.4 with the lanes 16 j apart, but then neighbouring list entries come from areas 64 px apart and the ring reads
+                // of the segment test collide in the LDS banks).  corners_and_scores undoes it when it decodes a code.
                 {
-                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)M), t2 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp2, (int)M),
-                                   t3 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp3, (int)M);
+                    const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)M, 0x124, 0xF, 0xF, false), t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)M, 0x128, 0xF, 0xF, false),
+                                   t3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)M, 0x12C, 0xF, 0xF, false);      // row_ror:4 / 8 / 12
                     M = (M & 0xFFu) | (t1 & 0xFF00u) | (t2 & 0xFF0000u) | (t3 & 0xFF000000u);
                 }
                 if (FR_STOP <= 1) { if (M == 0x12345u) plist[tid] = 1; continue; }      // keeps M live
