@@ -364,34 +364,25 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int el = (ew & 48) | ((ew - ((code & 24) >> 1)) & 15);     // lane that found it: byte j sits 4 j lanes up in its row of 16
                 const int py = BR * (RS * ((code >> 11) & 15) + (el >> LC)) + (eb & 7);
                 const int px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
-                const int pos = (py << 8) | px;
                 const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
                 const int v = ctr[0];
                 const int lo = v - t, hi = v + t;
                 int r[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) r[k] = ctr[RO[k]];
-                // ONE polarity per pixel.  A 9-arc contains two adjacent compass points (ring 0, 4, 8, 12), so a dark corner passes the exact
-                // compass test "(r0 or r8 darker) and (r4 or r12 darker)" and a bright corner its mirror image; practically no pixel passes
-                // both (0.00 % of the bench frames), so the 16 ring pixels go through the segment test of the polarity that can still
-                // succeed: one multiply-add (+-r -+ bound) and one v_alignbit per ring pixel — the sign bit of the difference is shifted into
-                // the mask (bit order comes out reversed, which a cyclic run test does not care about) — instead of two of each.
+                // ONE polarity per pixel, and the corner SCORE as the segment test.  A 9-arc contains two adjacent compass points (ring 0, 4,
+                // 8, 12), so a dark corner passes the exact compass test "(r0 or r8 darker) and (r4 or r12 darker)" and a bright corner its
+                // mirror image; the pixel goes through the packed score network of the polarity that can still succeed: it is a corner of
+                // that polarity exactly when max_arc min(d) > t, i.e. score >= t (cornerScore's own definition) — 68 instructions that yield the
+                // decision AND the score, instead of a segment test of both polarities (82) followed by a second pass over the corners
+                // (decode, 17 ring reads and the score network again for ~40 % of the pixels).
                 const bool dark_ok = max(min(r[0], r[8]), min(r[4], r[12])) < lo, bright_ok = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
-                auto run9 = [&](bool bright) -> bool {
-                    const int a = bright ? -1 : 1, b = bright ? hi : -lo;        // dark: r - lo < 0;  bright: hi - r < 0
-                    uint32_t m = 0;
+                uint32_t R[8];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        uint32_t d;                                            // as asm: the compiler turns r * a into a select of r and -r (4 instructions per pixel)
-                        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(r[k]), "v"(a), "v"(b));
-                        m = __builtin_amdgcn_alignbit(m, d, 31);
-                    }
-                    m |= m << 16;
-                    uint32_t x = m & (m >> 1); x &= x >> 2; x &= x >> 4; x &= m >> 8;
-                    return (x & 0xFFFFu) != 0;
-                };
-                bool bright = bright_ok && !redo_dark;
-                bool corner = run9(bright) && act && (dark_ok || bright_ok);
+                for (int j = 0; j < 8; j++) R[j] = fr_pair((uint32_t)r[2 * j], (uint32_t)r[2 * j + 1]);
+                const bool bright = bright_ok && !redo_dark;
+                int sc = fast_corner_score_pk(R, v, bright);
+                bool corner = sc >= t && act && (dark_ok || bright_ok);
                 // Pixels that pass BOTH compass tests (6-8 % of the candidates on the reduced levels, 0.1 % on level 0) and are no bright
                 // corner need the dark test as well: they go back to the END of the list with bit 15 set and fill the lanes of the last,
                 // partly empty iteration (running the second test in place would double the cost of nearly every iteration).  The last
@@ -401,34 +392,25 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     if (i0 + 64 < nend && nend + 64 <= lds.pcap) {
                         const int slot = wave_append(redo, nend);
                         if (redo) plist[slot] = (uint16_t)(code | 0x8000);
-                    } else if (redo && run9(false)) { corner = true; bright = false; }
+                    } else {
+                        const int sc2 = fast_corner_score_pk(R, v, false);
+                        if (redo && sc2 >= t) { corner = true; sc = sc2; }
+                    }
                 }
                 FR_FENCE();                                // this iteration's reads precede the in-place compaction writes
                 const int slot = wave_append(corner, n_corner);
-                if (corner) plist[slot] = (uint16_t)(pos | (bright ? 0x8000 : 0));
+                if (corner) {
+                    const int gc = (px * inv_w) >> 16;           // cell of the item; its columns start at 1 + gc*(wcell+1)
+                    plist[slot] = (uint16_t)(((py + 1) << 8) | (1 + px + gc));     // score tile coordinates: what nms_and_emit reads
+                    pscore[slot] = (uint8_t)sc;
+                }
             }
             FR_FENCE();
             FR_T(tc1);
             FR_ACC(4, tc0, tc1);
-            if (FR_STOP <= 3) { npx = n_done = 0; return; }
-            for (int i = n_done + tid; i < n_corner; i += 64) {
-                const int pos = plist[i];
-                const bool bright = pos & 0x8000;
-                const int py = (pos >> 8) & 127, px = pos & 255;
-                const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
-                const int v = ctr[0];
-                uint32_t R[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) R[j] = fr_pair(ctr[RO[2 * j]], ctr[RO[2 * j + 1]]);
-                const int gc = (px * inv_w) >> 16;               // cell of the item; its columns start at 1 + gc*(wcell+1)
-                const uint32_t sc_pos = (uint32_t)(((py + 1) << 8) | (1 + px + gc)), sc_val = (uint32_t)fast_corner_score_pk(R, v, bright) & 0xFFu;
-                plist[i] = (uint16_t)sc_pos;                     // score tile coordinates: what nms_and_emit reads
-                pscore[i] = (uint8_t)sc_val;
-            }
+            if (FR_STOP <= 4 && FR_STOP >= 3) { npx = n_done = 0; return; }
             npx = n_done = n_corner;
             FR_FENCE();
-            FR_T(tc2);
-            FR_ACC(5, tc1, tc2);
         };
         // the list is full of scored corners (saturated image): spill them (row, column, score) to this wave's global area
         auto spill_corners = [&]() {
@@ -490,7 +472,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 for (int r = 0; r < BR; r++) {
                     uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x01010101u << r));
                     const int incl_r = wave_scan_incl((int)__popc(Mr));
-                    const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 4*COLS <= pcap
+                    const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 256 <= pcap
                     if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else make_room(total_r); }
                     int pos = npx + incl_r - (int)__popc(Mr);
                     while (Mr) {
@@ -692,8 +674,10 @@ static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs)
     const int floor_bytes = std::max(fixed + 3 * 1024, (c.tr + 8) * pitch);   // >= 1024 list entries; the over-read of the last scan block stays inside
     const int granules = (floor_bytes + GRAN - 1) / GRAN;
     L.pcap = ((granules * GRAN - fixed) / 3) & ~15;           // 2 bytes position + 1 byte score per entry; >= 4*cols (one tile row of pixels)
-    if (knobs.pcap > 0) L.pcap = std::max(4 * cols, knobs.pcap & ~15);
-    if (knobs.small_lists) L.pcap = 4 * cols;
+    // floor: one row step of a scan block (64 lanes x 4 pixels, whatever the tile width) must fit an empty list — the scored corners leave
+    // their scores in `pscore` while the rest of the list is still being read, so the list may never run past its end
+    if (knobs.pcap > 0) L.pcap = std::max(256, knobs.pcap & ~15);
+    if (knobs.small_lists) L.pcap = 256;
     int o = c.tr * pitch;
     L.off_plist = o; o += L.pcap * 2;
     L.off_pscore = o; o += L.pcap;
