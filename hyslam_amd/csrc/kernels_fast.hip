@@ -51,49 +51,30 @@ __device__ __forceinline__ int wave_append(bool flag, int& base)
     return slot;
 }
 
-// Corner score of a pixel that passed the segment test with polarity `bright`.
-// cv::FAST's cornerScore<16> is max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1; for a corner of one polarity the other
-// polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with d[k] = v - ring[k]
-// (dark) or ring[k] - v (bright).  Two ring pixels per 32-bit register and packed 16-bit min / max:
-//   R_j  = (ring[2j], ring[2j+1])            one byte permute of two byte loads
-//   A_j  = (d[2j], d[2j+1])                  one v_pk_mad_i16 with the per-lane sign: R * (-s) + s*v
-//   B_j  = (d[2j+1], d[2j+2])                one byte permute of (A_j, A_j+1)
-//   L2_j = min(A_j, B_j)                     = (lo2[2j], lo2[2j+1]),  lo2[k] = min(d[k], d[k+1])
-//   L4_j = min(L2_j, L2_j+1), L8_j = min(L4_j, L4_j+2)                lo8[k] = min(d[k..k+7])
-//   arc9 = min(L8_j, A_j+4)                  = the 9-arcs starting at 2j and 2j+1;  score = max over j and halves - 1
-// 68 VALU instructions per corner instead of 111 with one value per register.  Measured and dropped: ds_read_u8_d16 / _d16_hi would
-// pack the pairs for free, but with SRAM-ECC a d16 load zeroes the other half of the register; seven UNALIGNED wide reads (4 bytes from
-// column -1 of rows +-3, 8 bytes from column -2 / -3 of the other rows) put every ring pixel at a fixed byte of a known register but
-// double the kernel's LDS busy time (0.33 -> 0.69 of the busy cycles): 0.203 -> 0.236 ms.
-typedef short fr_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t fr_u(fr_s2 x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ fr_s2 fr_s(uint32_t x) { return __builtin_bit_cast(fr_s2, x); }
-// low 16-bit field = byte 0 of `lo`, high field = byte 0 of `hi`
-__device__ __forceinline__ uint32_t fr_pair(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x0C040C00u); }
-__device__ __forceinline__ int fast_corner_score_pk(const uint32_t (&R)[8], int v, bool bright)
+// Corner score of one polarity: cv::FAST's cornerScore<16> is max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1; for a corner of one
+// polarity the other polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with
+// d[k] = v - ring[k] (dark) or ring[k] - v (bright), and the pixel IS a corner of that polarity exactly when max_arc min(d) > t.
+// Three-input min / max: lo3[k] = min(d[k..k+2]), arc9[k] = min(lo3[k], lo3[k+3], lo3[k+6]), a max3 tree over the 16 arcs — 16 + 16 + 8
+// instructions after the 16 multiply-adds that make d with the per-lane sign (56 in all; the packed 16-bit network this replaces took 66
+// with its byte permutes, the two-input network of round 2 111).
+__device__ __forceinline__ int fast_corner_score3(const int (&r)[16], int v, bool bright)
 {
-    const uint32_t ns = bright ? 0x00010001u : 0xFFFFFFFFu;
-    const int sv1 = bright ? -v : v;
-    const uint32_t sv = __builtin_amdgcn_perm((uint32_t)sv1, (uint32_t)sv1, 0x05040504u);
-    fr_s2 A[8], B[8], L2[8], L4[8], L8[8];
+    const int a = bright ? 1 : -1, b = bright ? -v : v;          // d = a * ring + b
+    int d[16], lo3[16], arc[16];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint32_t d;
-        asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(R[j]), "v"(ns), "v"(sv));
-        A[j] = fr_s(d);
-    }
+    for (int k = 0; k < 16; k++) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d[k]) : "v"(r[k]), "v"(a), "v"(b));   // as asm: the compiler turns r * a into a select of r and -r
+    // (as asm as well: left to itself the compiler shares min(d[k+1], d[k+2]) between neighbours and ends up with 32 two-input minima)
+    auto min3 = [](int x, int y, int z) { int o; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
+    auto max3 = [](int x, int y, int z) { int o; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
 #pragma unroll
-    for (int j = 0; j < 8; j++) B[j] = fr_s(__builtin_amdgcn_alignbit(fr_u(A[(j + 1) & 7]), fr_u(A[j]), 16));
+    for (int k = 0; k < 16; k++) lo3[k] = min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) L2[j] = __builtin_elementwise_min(A[j], B[j]);
+    for (int k = 0; k < 16; k++) arc[k] = min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    int m[6];
 #pragma unroll
-    for (int j = 0; j < 8; j++) L4[j] = __builtin_elementwise_min(L2[j], L2[(j + 1) & 7]);
-#pragma unroll
-    for (int j = 0; j < 8; j++) L8[j] = __builtin_elementwise_min(L4[j], L4[(j + 2) & 7]);
-    fr_s2 mx = __builtin_elementwise_min(L8[0], A[4]);
-#pragma unroll
-    for (int j = 1; j < 8; j++) mx = __builtin_elementwise_max(mx, __builtin_elementwise_min(L8[j], A[(j + 4) & 7]));
-    return max((int)mx.x, (int)mx.y) - 1;
+    for (int k = 0; k < 5; k++) m[k] = max3(arc[3 * k], arc[3 * k + 1], arc[3 * k + 2]);
+    m[5] = arc[15];
+    return max(max3(m[0], m[1], m[2]), max3(m[3], m[4], m[5])) - 1;
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -372,16 +353,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 for (int k = 0; k < 16; k++) r[k] = ctr[RO[k]];
                 // ONE polarity per pixel, and the corner SCORE as the segment test.  A 9-arc contains two adjacent compass points (ring 0, 4,
                 // 8, 12), so a dark corner passes the exact compass test "(r0 or r8 darker) and (r4 or r12 darker)" and a bright corner its
-                // mirror image; the pixel goes through the packed score network of the polarity that can still succeed: it is a corner of
-                // that polarity exactly when max_arc min(d) > t, i.e. score >= t (cornerScore's own definition) — 68 instructions that yield the
+                // mirror image; the pixel goes through the score network of the polarity that can still succeed: it is a corner of that
+                // polarity exactly when max_arc min(d) > t, i.e. score >= t (cornerScore's own definition) — 56 instructions that yield the
                 // decision AND the score, instead of a segment test of both polarities (82) followed by a second pass over the corners
-                // (decode, 17 ring reads and the score network again for ~40 % of the pixels).
+                // (decode, 17 ring reads and a score network for ~40 % of the pixels).
                 const bool dark_ok = max(min(r[0], r[8]), min(r[4], r[12])) < lo, bright_ok = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
-                uint32_t R[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) R[j] = fr_pair((uint32_t)r[2 * j], (uint32_t)r[2 * j + 1]);
                 const bool bright = bright_ok && !redo_dark;
-                int sc = fast_corner_score_pk(R, v, bright);
+                int sc = fast_corner_score3(r, v, bright);
                 bool corner = sc >= t && act && (dark_ok || bright_ok);
                 // Pixels that pass BOTH compass tests (6-8 % of the candidates on the reduced levels, 0.1 % on level 0) and are no bright
                 // corner need the dark test as well: they go back to the END of the list with bit 15 set and fill the lanes of the last,
@@ -393,7 +371,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                         const int slot = wave_append(redo, nend);
                         if (redo) plist[slot] = (uint16_t)(code | 0x8000);
                     } else {
-                        const int sc2 = fast_corner_score_pk(R, v, false);
+                        const int sc2 = fast_corner_score3(r, v, false);
                         if (redo && sc2 >= t) { corner = true; sc = sc2; }
                     }
                 }
