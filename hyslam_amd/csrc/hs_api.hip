@@ -42,6 +42,8 @@ struct hs_orb {
     uint32_t* d_fast_ovf = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
+    uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
+    std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
     uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
     int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
     uint32_t* d_sel = nullptr;
@@ -106,6 +108,7 @@ void free_geometry(hs_orb* h)
 {
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
+    hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear();
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
     hipFree(h->d_cand); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
@@ -237,6 +240,17 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         for (int l = 1; l < L; l++) { xt[l] = tables.data() + tab_off[4 * l]; yo[l] = tables.data() + tab_off[4 * l + 2]; }
         hs_pyramid_plan_fusion(h->lv.data(), L, xt.data(), yo.data());
         if (h->no_fuse) for (int l = 0; l < L; l++) h->lv[l].fuse_tbx = 0;
+        std::vector<const int16_t*> ib(L, nullptr);
+        for (int l = 1; l < L; l++) ib[l] = tables.data() + tab_off[4 * l + 3];
+        std::vector<uint64_t> blob;
+        hs_pyramid_build_tables(h->lv.data(), L, xt.data(), yo.data(), ib.data(), blob, h->pyr_fuse);
+        HIP_TRY(h, hipMalloc(&h->d_pyr_tabs, std::max<size_t>(blob.size() * 8, 256)));
+        if (!blob.empty()) HIP_TRY(h, hipMemcpy(h->d_pyr_tabs, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+        for (HsPyrFuse& F : h->pyr_fuse) {                    // blob offsets -> device pointers
+            if (!F.valid) continue;
+            F.rowA = reinterpret_cast<const HsPyrRow*>(h->d_pyr_tabs + (uintptr_t)F.rowA); F.rowB = reinterpret_cast<const HsPyrRow*>(h->d_pyr_tabs + (uintptr_t)F.rowB);
+            F.xt = reinterpret_cast<const HsPyrXTile*>(h->d_pyr_tabs + (uintptr_t)F.xt); F.yt = reinterpret_cast<const HsPyrYTile*>(h->d_pyr_tabs + (uintptr_t)F.yt);
+        }
     }
     HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
     {
@@ -355,14 +369,14 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         if (rc != HS_OK) return rc;
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
-        hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), L, img0, batch, s);
         rc = fast(items0, h->fast_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
     } else {
         mark(h, 0, s);
-        hs_launch_pyramid(h->d_lv, h->lv.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), L, img0, batch, s);
         mark(h, 1, s);
         const int rc = fast(0, h->fast_items, 0, s);
         if (rc != HS_OK) return rc;

@@ -2,6 +2,7 @@
 // gfx950 (MI355X) only: wave64, 160 KiB LDS/CU.  Compiled with -ffp-contract=off: several results
 // (resize tables, fastAtan2, rBRIEF rotation) are defined by separately rounded fp32 operations.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -121,8 +122,31 @@ struct HsOut {                     // extractor outputs, split the same way
     int32_t cap;
 };
 
+// Two-levels-per-launch pyramid kernel (kernels_pyramid.hip): everything a workgroup used to derive from the level and resize tables with a
+// chain of dependent scalar loads is precomputed on the host — the tile geometry factorises into one record per tile column and one per tile
+// row, the vertical pass gets one 8-byte record per destination row (clamped source rows + weights), and the level descriptions travel as a
+// kernel argument instead of through the HsLevel array.
+struct HsXTab { int16_t sx, a0, a1, pad; };                       // x table of cv::resize: first source column and the two 11-bit weights
+struct HsPyrXTile { int32_t ax0, own_x1, col0, nvec, _r[4]; };    // first column / end of the owned columns of the level-A region; first source column (16-aligned), 16-byte vectors per source row
+struct HsPyrYTile { int32_t ay0, own_y1, ay_last, sy_first, n_sr, _r[3]; };   // level-A rows [ay0, ay_last], owned up to own_y1; source rows from sy_first, n_sr of them
+struct HsPyrRow { int16_t r0, r1; uint16_t b0, b1; };            // destination row: its two source rows (clamped, absolute) and vertical weights
+static_assert(sizeof(HsPyrXTile) == 32 && sizeof(HsPyrYTile) == 32 && sizeof(HsPyrRow) == 8, "scalar-load records");
+struct HsPyrFuse {
+    const uint8_t* sbase;          // source level S = A - 1 (nullptr: level 0 = the caller's frames, HsImg0)
+    uint64_t s_img_stride; int32_t spitch; int32_t _r0;
+    uint8_t* abase; uint64_t a_img_stride; int32_t apitch, aw, ah, _r1;
+    uint8_t* bbase; uint64_t b_img_stride; int32_t bpitch, bw, bh, _r2;
+    const HsXTab* xtA; const HsXTab* xtB;
+    const HsPyrRow* rowA; const HsPyrRow* rowB;                    // [A.h], [B.h]
+    const HsPyrXTile* xt; const HsPyrYTile* yt;                    // [grid.x], [grid.y]
+    int32_t tbx, sr, lds_pitch, valid;                             // tile width of level B, LDS rows / pitch of the source rectangle; valid = this pair is fused
+};
+
 // kernels_*.hip launchers (all asynchronous on `s`)
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+// host side of HsPyrFuse for every fused pair: records appended to `blob` (device pointers are blob offsets until hs_api.hip relocates them)
+void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
+                             std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse);
 // decides, from the host copies of the resize tables, whether levels (l, l+1) can be produced by the fused kernel and with which tile geometry
 void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/);
 int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kernel launches of one hs_launch_pyramid call

@@ -480,18 +480,25 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     // replaces (measured: 3.7 % of the pixels pass instead of 3.6 %); the segment test on the full bytes follows as before.
                     // ~26 plain 32-bit ALU operations per row of 4 pixels instead of ~34 packed-16-bit ones, which also issue slower.
                     const uint32_t* tp = tile32 + (y0 - 3) * PD + col;
-                    uint32_t Q[BR + 6];
+                    uint32_t Q[BR + 6], G[BR + 6];
 #pragma unroll
-                    for (int k = 0; k < BR + 6; k++) Q[k] = (tp[k * PD] >> 2) & 0x3F3F3F3Fu;
+                    for (int k = 0; k < BR + 6; k++) { Q[k] = (tp[k * PD] >> 2) & 0x3F3F3F3Fu; G[k] = Q[k] + kbias; }
+                    // "x darker than C": bit 7 of (q_C + bias) - q_x; "x brighter": bit 7 of q_x + (bias - q_C).  Vertically the four differences
+                    // of a pixel are shared with the pixels three rows above and below it: with D1[y] = G[y] - Q[y+3] and D2[y] = G[y+3] - Q[y],
+                    // row c sees "top or bottom darker" = D2[c-3] | D1[c] and "top or bottom brighter" = D1[c-3] | D2[c] — two subtractions per
+                    // tile row instead of four per centre row (the same 32-bit values as the direct form, so the masks are the same bits).
+                    uint32_t D1[BR + 3], D2[BR + 3];
+#pragma unroll
+                    for (int y = 0; y < BR + 3; y++) { D1[y] = G[y] - Q[y + 3]; D2[y] = G[y + 3] - Q[y]; }
 #pragma unroll
                     for (int r = 0; r < BR; r++) {
                         const uint32_t qC = Q[r + 3];
-                        const uint32_t gC = qC + kbias, nC = kbias - qC;                     // "x darker than C": bit 7 of gC - q_x; "x brighter": bit 7 of q_x + nC
+                        const uint32_t gC = G[r + 3], nC = kbias - qC;
                         const uint32_t qCm = lane_from_below(qC), qCp = lane_from_above(qC);
                         const uint32_t qL = __builtin_amdgcn_alignbyte(qC, qCm, 1);          // the pixels 3 columns to the left / right of this lane's four
                         const uint32_t qR = __builtin_amdgcn_alignbyte(qCp, qC, 3);
-                        const uint32_t dark = ((gC - Q[r]) | (gC - Q[r + 6])) & ((gC - qL) | (gC - qR));       // (top or bottom darker) and (left or right darker)
-                        const uint32_t bright = ((Q[r] + nC) | (Q[r + 6] + nC)) & ((qL + nC) | (qR + nC));
+                        const uint32_t dark = (D2[r] | D1[r + 3]) & ((gC - qL) | (gC - qR));           // (top or bottom darker) and (left or right darker)
+                        const uint32_t bright = (D1[r] | D2[r + 3]) & ((qL + nC) | (qR + nC));
                         M = (M >> 1) | ((dark | bright) & 0x80808080u);                      // row r ends up at bit r of its pixel's byte
                     }
                     const int nrow = min(max(yend - y0, 0), BR);                     // rows of this block inside the interior

@@ -14,8 +14,7 @@
 // 8-byte record {sx, a0, a1, -} per output.
 #include "hs_internal.h"
 #include <algorithm>
-
-struct HsXTab { int16_t sx, a0, a1, pad; };
+#include <cstring>
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict__ lv, int level, HsImg0 img0)
@@ -217,54 +216,45 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
 // every B tile, so every pixel of A is written exactly once; the 1-2 px halo a tile needs from its neighbours' parts is recomputed, with
 // identical bits), and then makes its tile of B from the LDS copy.  The chain of launches shrinks from L-1 to ceil((L-1)/2), level A is
 // never re-read from memory, and the source rectangle is shared by both levels.  Same arithmetic as k_resize_level_lds.
+// Round 3: TABLE-DRIVEN.  The kernel used to derive its geometry from the HsLevel array and the resize tables with a chain of ~8 dependent
+// scalar loads before its first vector load, and every row of a vertical pass cost ~38 scalar instructions (64-bit table addresses, clamps, a
+// re-load of the pitch, a 64-bit multiply for the store address): 548 scalar against 518 vector instructions per wave.  Now the level
+// descriptions are a kernel argument, the tile geometry is two 32-byte records (HsPyrXTile / HsPyrYTile), a destination row is one 8-byte
+// record (HsPyrRow: clamped source rows + weights, fetched one row ahead) and stores use a scalar row base + a 32-bit lane offset.
+typedef uint32_t hs_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t hs_u32x2 __attribute__((ext_vector_type(2)));
 #define FZ_ROWS 16
 #define FZ_APITCH 272             // LDS pitch of the level-A region: 256 columns + the 3-dword window over-read of the last lane
-__global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __restrict__ lv, int levelA, HsImg0 img0)
+template <typename T> __device__ __forceinline__ void hs_gstore_off(uint8_t* uniform_base, uint32_t lane_off, T v)
+{
+    *(HS_GLOBAL T*)((HS_GLOBAL uint8_t*)(uintptr_t)uniform_base + lane_off) = v;
+}
+__global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 img0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const HsLevel& A = lv[levelA];
-    const HsLevel& B = lv[levelA + 1];
-    const int TBX = A.fuse_tbx, SR = A.fuse_sr, lds_pitch = A.fuse_pitch;
+    const int TBX = F.tbx, lds_pitch = F.lds_pitch;
     uint8_t* const s_src = smem;                                                         // [SR][lds_pitch] source rectangle, later the level-A region
     uint8_t* const s_a = smem;                                                           // [AR][FZ_APITCH]
-    uint16_t* const s_h = reinterpret_cast<uint16_t*>(smem + (size_t)lds_pitch * SR);    // [SR][256] (H >> 4) for level A, later [AR][256] for level B
+    uint16_t* const s_h = reinterpret_cast<uint16_t*>(smem + (size_t)lds_pitch * F.sr);  // [SR][256] (H >> 4) for level A, later [AR][256] for level B
     const int img = blockIdx.z;
     const int tx = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint8_t* sbase; size_t spitch;
-    if (levelA == 1) { sbase = hs_img0_ptr(img0, img); spitch = img0.row_stride; }
-    else { const HsLevel& S = lv[levelA - 1]; sbase = S.base + (size_t)img * S.img_stride; spitch = S.pitch; }
-    const int sw = lv[levelA - 1].w, sh = lv[levelA - 1].h;
-    const HsXTab* xtA = reinterpret_cast<const HsXTab*>(A.xofs);
-    const HsXTab* xtB = reinterpret_cast<const HsXTab*>(B.xofs);
-    auto sxB = [&](int x) { return (int)(int16_t)hs_cload<uint32_t>(&xtB[x]); };        // .sx = low half of the record's first dword
-    auto sxA = [&](int x) { return (int)(int16_t)hs_cload<uint32_t>(&xtA[x]); };
-
-    // ---- geometry (wave-uniform)
+    const HsPyrXTile X = __builtin_bit_cast(HsPyrXTile, hs_cload<hs_u32x8>(&F.xt[blockIdx.x]));
+    const HsPyrYTile Y = __builtin_bit_cast(HsPyrYTile, hs_cload<hs_u32x8>(&F.yt[blockIdx.y]));
+    const uint8_t* sbase; uint32_t spitch;
+    if (F.sbase == nullptr) { sbase = hs_img0_ptr(img0, img); spitch = (uint32_t)img0.row_stride; }
+    else { sbase = F.sbase + (size_t)img * F.s_img_stride; spitch = (uint32_t)F.spitch; }
     const int bx0 = blockIdx.x * TBX, by0 = blockIdx.y * FZ_ROWS;
-    const int by_last = min(by0 + FZ_ROWS, B.h) - 1;
-    const bool last_x = bx0 + TBX >= B.w, last_y = by0 + FZ_ROWS >= B.h;
-    const int ax0 = blockIdx.x == 0 ? 0 : (sxB(bx0) & ~3);                                // first column of the level-A region = first owned column
-    const int own_x1 = last_x ? ((A.w + 3) & ~3) : (sxB(bx0 + TBX) & ~3);
-    const int ay0 = blockIdx.y == 0 ? 0 : min(max(hs_cload_i16(B.yofs, by0), 0), A.h - 1);
-    const int own_y1 = last_y ? A.h : min(max(hs_cload_i16(B.yofs, by0 + FZ_ROWS), 0), A.h - 1);
-    const int ay_last = max(min(max(hs_cload_i16(B.yofs, by_last) + 1, 0), A.h - 1), own_y1 - 1);
-    const int nAr = ay_last - ay0 + 1;                                                    // <= AR (host-verified)
-    const int ax_lastcol = min(ax0 + 255, A.w - 1);
-    const int col0 = sxA(ax0) & ~15;
-    const int col_last = min(sxA(ax_lastcol) + 1, sw - 1);
-    const int sy_first = min(max(hs_cload_i16(A.yofs, ay0), 0), sh - 1);
-    const int sy_last = min(max(hs_cload_i16(A.yofs, ay_last) + 1, 0), sh - 1);
-    const int nvec = ((col_last - col0) >> 4) + 1, nSr = sy_last - sy_first + 1;          // nvec*16 <= lds_pitch - 16, nSr <= SR (host-verified)
+    const int ax0 = X.ax0, ay0 = Y.ay0, nAr = Y.ay_last - Y.ay0 + 1, nSr = Y.n_sr, nvec = X.nvec;
 
-    // ---- 1: the source rectangle
+    // ---- 1: the source rectangle (a wave takes whole source rows, floor(64 / nvec) at a time)
     {
-        const int lane = threadIdx.x & 63;
+        const uint8_t* const src0 = hs_uniform_ptr(sbase + (size_t)Y.sy_first * spitch + X.col0);
         const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
-        const int rl = (lane >= nvec) + (lane >= 2 * nvec) + (lane >= 3 * nvec), q = lane - rl * nvec;
-        if (lane < rpw * nvec) {
+        const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
+        if (tx < rpw * nvec) {
             for (int r = wave * rpw + rl; r < nSr; r += 4 * rpw) {
-                const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
+                const hs_u32x4 v = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
                 *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
             }
         }
@@ -299,50 +289,105 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(const HsLevel* __rest
         const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
         return pyr_vquad(H0, H1, b0, b1);
     };
-    const ColData cA = col_data(xtA, ax0 + 4 * tx, A.w - 1, col0);
+    const ColData cA = col_data(F.xtA, ax0 + 4 * tx, F.aw - 1, X.col0);
     __syncthreads();
     // ---- 2: horizontal sums of the source rows for the level-A columns
     h_pass(s_src, lds_pitch, nSr, cA);
     __syncthreads();
     // ---- 3: level-A region -> LDS (it overlays the source rectangle, which is dead now) and, for the owned part, HBM
     {
-        uint8_t* const aimg = A.base + (size_t)img * A.img_stride;
-        const int acol = ax0 + 4 * tx;
-        const bool own_col = acol < own_x1;
-        // the row parameters are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic
-        int sy_n = hs_cload_i16(A.yofs, min(ay0 + wave, ay_last));
-        uint32_t b01_n = hs_cload<uint32_t>(A.ibeta + 2 * min(ay0 + wave, ay_last));
-        for (int ay = ay0 + wave; ay <= ay_last; ay += 4) {
-            const int sy = sy_n;
-            const uint32_t b01 = b01_n;
-            sy_n = hs_cload_i16(A.yofs, min(ay + 4, ay_last));
-            b01_n = hs_cload<uint32_t>(A.ibeta + 2 * min(ay + 4, ay_last));
-            const int r0 = min(max(sy, 0), sh - 1) - sy_first, r1 = min(max(sy + 1, 0), sh - 1) - sy_first;
-            const uint32_t px = v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16);
+        uint8_t* const aimg = F.abase + (size_t)img * F.a_img_stride;
+        const uint32_t acol = (uint32_t)(ax0 + 4 * tx);
+        const bool own_col = (int)acol < X.own_x1;
+        // the row records are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic
+        HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay0 + wave, Y.ay_last)]));
+        for (int ay = ay0 + wave; ay <= Y.ay_last; ay += 4) {
+            const HsPyrRow rec = nxt;
+            nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay + 4, Y.ay_last)]));
+            const uint32_t px = v_combine(rec.r0 - Y.sy_first, rec.r1 - Y.sy_first, rec.b0, rec.b1);
             *reinterpret_cast<uint32_t*>(&s_a[(ay - ay0) * FZ_APITCH + 4 * tx]) = px;
-            if (own_col && ay < own_y1) hs_gstore<uint32_t>(aimg + (size_t)ay * A.pitch + acol, px);
+            if (own_col && ay < Y.own_y1) hs_gstore_off<uint32_t>(aimg + (size_t)ay * (uint32_t)F.apitch, acol, px);
         }
     }
-    const ColData cB = col_data(xtB, bx0 + 4 * tx, B.w - 1, ax0);
+    const ColData cB = col_data(F.xtB, bx0 + 4 * tx, F.bw - 1, ax0);
     __syncthreads();
     // ---- 4: horizontal sums of the level-A rows for the tile's level-B columns (the sums overlay the level-A sums)
     if (4 * tx < TBX) h_pass(s_a, FZ_APITCH, nAr, cB);
     __syncthreads();
     // ---- 5: the level-B tile
-    if (4 * tx < TBX && bx0 + 4 * tx < B.w) {
-        uint8_t* const bimg = B.base + (size_t)img * B.img_stride;
-        int sy4[FZ_ROWS / 4]; uint32_t b4[FZ_ROWS / 4];                // the four rows' parameters (scalar loads) before the first use
+    if (4 * tx < TBX && bx0 + 4 * tx < F.bw) {
+        uint8_t* const bimg = F.bbase + (size_t)img * F.b_img_stride;
+        HsPyrRow rec4[FZ_ROWS / 4];                                    // the four rows' records (scalar loads) before the first use
 #pragma unroll
-        for (int rr = 0; rr < FZ_ROWS / 4; rr++) { const int by = min(by0 + wave + 4 * rr, B.h - 1); sy4[rr] = hs_cload_i16(B.yofs, by); b4[rr] = hs_cload<uint32_t>(B.ibeta + 2 * by); }
+        for (int rr = 0; rr < FZ_ROWS / 4; rr++) rec4[rr] = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowB[min(by0 + wave + 4 * rr, F.bh - 1)]));
 #pragma unroll
         for (int rr = 0; rr < FZ_ROWS / 4; rr++) {
             const int by = by0 + wave + 4 * rr;
-            if (by >= B.h) break;
-            const int sy = sy4[rr];
-            const uint32_t b01 = b4[rr];
-            const int r0 = min(max(sy, 0), A.h - 1) - ay0, r1 = min(max(sy + 1, 0), A.h - 1) - ay0;
-            hs_gstore<uint32_t>(bimg + (size_t)by * B.pitch + bx0 + 4 * tx, v_combine(r0, r1, b01 & 0xFFFFu, b01 >> 16));
+            if (by >= F.bh) break;
+            hs_gstore_off<uint32_t>(bimg + (size_t)by * (uint32_t)F.bpitch, (uint32_t)(bx0 + 4 * tx), v_combine(rec4[rr].r0 - ay0, rec4[rr].r1 - ay0, rec4[rr].b0, rec4[rr].b1));
         }
+    }
+}
+
+// Host side of the table-driven kernel: for every fused pair the tile records (the geometry the kernel used to compute itself, same
+// expressions) and for both levels of the pair the row records; everything is appended to `blob`, pointers into it are byte offsets.
+void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
+                             std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse)
+{
+    fuse.assign(nlevels, HsPyrFuse{});
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    std::vector<size_t> row_off(nlevels, 0);
+    auto rows_of = [&](int l) {                                  // row records of level l (source = level l-1), built once
+        if (row_off[l]) return row_off[l];
+        const int sh = h_lv[l - 1].h;
+        const size_t o = blob.size();
+        blob.resize(o + (size_t)h_lv[l].h);
+        for (int dy = 0; dy < h_lv[l].h; dy++) {
+            HsPyrRow r;
+            r.r0 = (int16_t)clampi(yofs[l][dy], 0, sh - 1); r.r1 = (int16_t)clampi(yofs[l][dy] + 1, 0, sh - 1);
+            r.b0 = (uint16_t)ibeta[l][2 * dy]; r.b1 = (uint16_t)ibeta[l][2 * dy + 1];
+            memcpy(&blob[o + dy], &r, 8);
+        }
+        return row_off[l] = o;                                   // o > 0: the blob starts with a pad word
+    };
+    if (blob.empty()) blob.push_back(0);
+    for (int l = 1; l + 1 < nlevels; l++) {
+        const HsLevel& A = h_lv[l];
+        if (A.fuse_tbx <= 0) continue;
+        const HsLevel& B = h_lv[l + 1]; const HsLevel& S = h_lv[l - 1];
+        const int16_t* xA = xtab[l]; const int16_t* xB = xtab[l + 1]; const int16_t* yA = yofs[l]; const int16_t* yB = yofs[l + 1];
+        const int tbx = A.fuse_tbx, nbx = (B.w + tbx - 1) / tbx, nby = (B.h + FZ_ROWS - 1) / FZ_ROWS;
+        HsPyrFuse& F = fuse[l];
+        F.sbase = l == 1 ? nullptr : S.base; F.s_img_stride = S.img_stride; F.spitch = S.pitch;
+        F.abase = A.base; F.a_img_stride = A.img_stride; F.apitch = A.pitch; F.aw = A.w; F.ah = A.h;
+        F.bbase = B.base; F.b_img_stride = B.img_stride; F.bpitch = B.pitch; F.bw = B.w; F.bh = B.h;
+        F.xtA = reinterpret_cast<const HsXTab*>(A.xofs); F.xtB = reinterpret_cast<const HsXTab*>(B.xofs);
+        F.rowA = reinterpret_cast<const HsPyrRow*>(rows_of(l) * 8); F.rowB = reinterpret_cast<const HsPyrRow*>(rows_of(l + 1) * 8);
+        F.tbx = tbx; F.sr = A.fuse_sr; F.lds_pitch = A.fuse_pitch; F.valid = 1;
+        const size_t ox = blob.size(); blob.resize(ox + 4 * (size_t)nbx);
+        for (int bx = 0; bx < nbx; bx++) {
+            const int bx0 = bx * tbx; const bool last_x = bx0 + tbx >= B.w;
+            HsPyrXTile t{};
+            t.ax0 = bx == 0 ? 0 : (xB[4 * bx0] & ~3);
+            t.own_x1 = last_x ? ((A.w + 3) & ~3) : (xB[4 * (bx0 + tbx)] & ~3);
+            const int ax_lastcol = std::min(t.ax0 + 255, A.w - 1);
+            t.col0 = xA[4 * t.ax0] & ~15;
+            const int col_last = std::min(xA[4 * ax_lastcol] + 1, S.w - 1);
+            t.nvec = ((col_last - t.col0) >> 4) + 1;
+            memcpy(&blob[ox + 4 * (size_t)bx], &t, 32);
+        }
+        const size_t oy = blob.size(); blob.resize(oy + 4 * (size_t)nby);
+        for (int by = 0; by < nby; by++) {
+            const int by0 = by * FZ_ROWS, by_last = std::min(by0 + FZ_ROWS, B.h) - 1; const bool last_y = by0 + FZ_ROWS >= B.h;
+            HsPyrYTile t{};
+            t.ay0 = by == 0 ? 0 : clampi(yB[by0], 0, A.h - 1);
+            t.own_y1 = last_y ? A.h : clampi(yB[by0 + FZ_ROWS], 0, A.h - 1);
+            t.ay_last = std::max(clampi(yB[by_last] + 1, 0, A.h - 1), t.own_y1 - 1);
+            t.sy_first = clampi(yA[t.ay0], 0, S.h - 1);
+            t.n_sr = clampi(yA[t.ay_last] + 1, 0, S.h - 1) - t.sy_first + 1;
+            memcpy(&blob[oy + 4 * (size_t)by], &t, 32);
+        }
+        F.xt = reinterpret_cast<const HsPyrXTile*>(ox * 8); F.yt = reinterpret_cast<const HsPyrYTile*>(oy * 8);
     }
 }
 
@@ -392,11 +437,11 @@ void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xt
     }
 }
 
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, HsImg0 img0, int batch, hipStream_t s)
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, int nlevels, HsImg0 img0, int batch, hipStream_t s)
 {
     for (int l = 1; l < nlevels; l++) {
         const HsLevel& D = h_lv[l];
-        if (D.fuse_tbx > 0 && l + 1 < nlevels) {
+        if (D.fuse_tbx > 0 && l + 1 < nlevels && fuse && fuse[l].valid) {
             // 16-byte source vectors: always fine for our own levels (pitch % 64 == 0), checked for the caller's frames
             bool vec16 = true;
             if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((h_lv[0].w + 15) & ~15) <= (int)img0.row_stride;
@@ -404,7 +449,7 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, int nlevels, Hs
                 const HsLevel& B = h_lv[l + 1];
                 const size_t lds = (size_t)D.fuse_pitch * D.fuse_sr + (size_t)std::max(D.fuse_sr, D.fuse_ar) * 256 * 2;
                 dim3 grid((B.w + D.fuse_tbx - 1) / D.fuse_tbx, (B.h + FZ_ROWS - 1) / FZ_ROWS, batch);
-                hipLaunchKernelGGL(k_resize_two_levels, grid, dim3(256), lds, s, d_lv, l, img0);
+                hipLaunchKernelGGL(k_resize_two_levels, grid, dim3(256), lds, s, fuse[l], img0);
                 l++;                                           // level l+1 is done too
                 continue;
             }
