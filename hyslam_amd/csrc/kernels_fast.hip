@@ -15,14 +15,18 @@
 // ~1 instruction/cycle/CU) became 0.24 ms.
 //   stage   the item's tile (interior + 3 px apron, <= 256 x 70 px) is fetched with 16-byte loads into registers while the PREVIOUS
 //           item is processed, then written to LDS; the only HBM traffic of the kernel is this one read of each level
-//   scan A  quick reject on the four compass points, 4 pixel columns x 8 rows per lane and block: 14 tile rows in registers, the
-//           horizontal ring pixels from the neighbouring lanes (DPP wave shifts), all compares as v_pk_*_u16 on two pixels at a time;
-//           the "maybe" pixels of a block go to an LDS list as codes (wave prefix sum of popcounts, one short bit loop per lane)
-//   corners maybe pixels (decoded on dense lanes): 16-bit darker/brighter ring masks, 9 contiguous cyclic bits; corners are compacted
-//           in place and scored; position and score stay in the list
+//   scan A  quick reject on the four compass points, 4 pixel columns x 8 rows per lane and block: 14 tile rows in registers, reduced to 6
+//           bits so that four pixels fit one plain 32-bit ALU operation; the horizontal ring pixels come from the neighbouring lanes (DPP
+//           wave shifts), the vertical differences are shared between the pixels three rows apart; the masks of a block are byte-
+//           transposed across lanes (a cluster of hits would otherwise keep one lane busy for 18 rounds) and their bits go to an LDS
+//           list as codes (wave prefix sum of popcounts, one short bit loop per lane)
+//   corners maybe pixels (decoded on dense lanes): the exact compass test picks the ONE polarity a pixel can still be a corner of, and
+//           the corner-score network of that polarity (three-input min / max over the 16 arcs of 9) is the segment test: score >= t
+//           decides, the score is kept.  Corners are compacted in place (score tile coordinates + score); the few pixels that pass both
+//           compass tests without being a bright corner are re-queued at the list end for the dark test
 //   tile    once every corner is scored the pixel tile is dead: its LDS is zeroed and becomes the dense score tile, in which every
 //           cell owns its columns plus one zero separator column, so the 3x3 NMS needs no cell-boundary logic
-//   NMS     over the corner list; survivors take a slot of their cell with an LDS atomic.
+//   NMS     over the corner list; survivors take consecutive slots of their ITEM (a wave-uniform running count).
 // The list has a fixed capacity; when a block would overflow it the scan runs the corner passes on what it has and spills the scored
 // corners to a per-wave area in global memory; they come back into the score tile before the NMS, which then walks the non-zero
 // bytes of the tile instead of the list.  Saturated images stay correct and merely lose batching.  Work distribution, geometry table
@@ -32,7 +36,8 @@
 //   cand[slot] = { y<<16 | x,  score<<24 | cell }   (coordinates relative to (16,16), as in vToDistributeKeys; cell = row-major cell index
 //                                                    of the level); one 8-byte store per survivor, ~20 records = two cache lines per item
 //   cell_count[image][first global cell of the item] = number of slots used (the entries of the item's other cells are not written).
-// Bound: instruction issue (integer VALU + LDS byte reads); HBM bytes = P per frame.
+// Bound: VALU issue (SQ_ACTIVE_INST_VALU: 77 % of the four SIMDs' issue slots, with 11 single-wave workgroups per CU — 10 -> 11 workgroups
+// buys 2 %, so more occupancy would not help); HBM bytes = P per frame.
 #include "hs_internal.h"
 #include <algorithm>
 #include <cstdlib>
