@@ -42,6 +42,7 @@ struct hs_orb {
     uint32_t* d_fast_ovf = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
+    uint8_t* d_qt_tabs = nullptr;      // geometric-key tables of the count-domain quadtree (hs_quadtree_build_tables)
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
     std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
     uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
@@ -109,6 +110,7 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
     hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear();
+    hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
     hipFree(h->d_cand); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
@@ -234,6 +236,14 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
             V.xofs = h->d_tables + tab_off[4 * l]; V.ialpha = h->d_tables + tab_off[4 * l + 1];
             V.yofs = h->d_tables + tab_off[4 * l + 2]; V.ibeta = h->d_tables + tab_off[4 * l + 3];
         }
+    }
+    {   // geometric-key tables of the quadtree kernel
+        std::vector<uint8_t> qblob;
+        std::vector<size_t> xo(L, 0), yo2(L, 0); std::vector<char> has(L, 0);
+        for (int l = 0; l < L; l++) has[l] = hs_quadtree_build_tables(h->lv[l], qblob, xo[l], yo2[l]) ? 1 : 0;
+        HIP_TRY(h, hipMalloc(&h->d_qt_tabs, std::max<size_t>(qblob.size() + 16, 256)));
+        if (!qblob.empty()) HIP_TRY(h, hipMemcpy(h->d_qt_tabs, qblob.data(), qblob.size(), hipMemcpyHostToDevice));
+        for (int l = 0; l < L; l++) if (has[l]) { h->lv[l].qt_xtab = h->d_qt_tabs + xo[l]; h->lv[l].qt_ytab = h->d_qt_tabs + yo2[l]; }
     }
     {   // which level pairs the fused pyramid kernel can produce (decided on the host copies of the tables)
         std::vector<const int16_t*> xt(L, nullptr), yo(L, nullptr);

@@ -34,6 +34,11 @@ struct HsLevel {
     int32_t n_ini;                 // round(qt_w / qt_h)
     float   hx;                    // qt_w / n_ini
     int32_t quota;                 // mnFeaturesPerLevel[level]
+    // geometric-key tables of the count-domain quadtree (kernels_quadtree.hip), built on the host from the level geometry: cell index of every
+    // pixel column within its root / of every pixel row at the depth of the histogram pyramid, first column of roots 1..7; nullptr = none
+    const uint8_t* qt_xtab;        // [qt_w + 1], 16-byte aligned, padded to a multiple of 16
+    const uint8_t* qt_ytab;        // [qt_h + 1]
+    int32_t qt_rbound[8];
     // candidate / selection storage (entries, per image)
     int32_t cand_cap;
     int32_t sel_cap;
@@ -162,6 +167,9 @@ bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels,
                     const HsFastKnobs& knobs, int item_first, int item_count /*the launch covers items [first, first + count) of every image*/,
                     int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
+// host side of the geometric-key tables: appends level `V`'s tables to `blob` (16-byte granules) and returns their offsets; false = the level does
+// not use them (more than 8 roots or a level wider than the tables)
+bool hs_quadtree_build_tables(HsLevel& V, std::vector<uint8_t>& blob, size_t& xoff, size_t& yoff);
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,

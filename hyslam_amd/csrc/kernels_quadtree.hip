@@ -164,34 +164,21 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     auto hoff = [&](int d) { return nIni * (((1 << (2 * DH + 2)) - (1 << (2 * d + 2))) / 3); };     // entries of the levels deeper than d
     // geometric key of a point: root << 2 DH | its DivideNode decisions down to depth DH (:121-177, :209).  DivideNode halves x and y
     // independently, so the key is the bit-interleave of two one-dimensional cell indices: TABLES (a byte per pixel column of every root and
-    // per pixel row, built once per workgroup in LDS that is idle during the gather) replace the six-step descent per point; the root comes
+    // per pixel row, built by the host, copied into LDS that is idle during the gather) replace the six-step descent per point; the root comes
     // from comparisons with the first column that the reference's float division assigns to each root.
     uint8_t* const xtab = reinterpret_cast<uint8_t*>(s_idx3);             // [qt_w + 1] cell index along x within the column's root
     uint8_t* const ytab = xtab + 8192;                                   // [qt_h + 1]
     __shared__ int s_rbound[8];                                          // first x of root i (i >= 1)
     static_assert(sizeof(s_idx3) >= 8192 + 4096, "geometric-key tables");
-    const bool use_tab = cf_geom && L.qt_w < 8192 && L.qt_h < 4096;
-    auto descend = [&](int x, int x0, int x1) {                          // the DH halvings of [x0, x1) that contain x -> cell index
-        int idx = 0;
-        for (int d = 0; d < DH; d++) {
-            const int mx = x0 + ((x1 - x0 + 1) >> 1);
-            if (x < mx) { x1 = mx; idx = 2 * idx; } else { x0 = mx; idx = 2 * idx + 1; }
-        }
-        return idx;
-    };
+    const bool use_tab = cf_geom && L.qt_xtab != nullptr;              // (qt_w < 8192 - 16 and qt_h < 4096 - 16: the host's condition)
     auto root_of = [&](int x) { return min((int)((float)x / hX), nIni - 1); };      // vpIniNodes[kp.pt.x/hX]
     if (use_tab) {
-        if (tid >= 1 && tid < nIni) {                                    // smallest x that lands in root tid: around tid * hX
-            int bnd = (int)(hX * (float)tid);
-            while (bnd > 0 && root_of(bnd - 1) >= tid) bnd--;
-            while (root_of(bnd) < tid) bnd++;
-            s_rbound[tid] = bnd;
-        }
-        for (int x = tid; x <= L.qt_w; x += QT_T) {
-            const int r = root_of(x);
-            xtab[x] = (uint8_t)descend(x, (int16_t)(int)(hX * (float)r), (int16_t)(int)(hX * (float)(r + 1)));
-        }
-        for (int y = tid; y <= L.qt_h; y += QT_T) ytab[y] = (uint8_t)descend(y, 0, (int16_t)L.qt_h);
+        // the tables depend on the level geometry alone: the host builds them once per configuration (hs_quadtree_build_tables: the same
+        // expressions, IEEE float division and multiplication), the workgroup copies them with 16-byte loads.  Building them here cost the
+        // level-0 workgroup of a 1080p frame 5 k of its 68 k cycles (a float division and six halvings per pixel column and row).
+        if (tid >= 1 && tid < nIni) s_rbound[tid] = L.qt_rbound[tid];
+        for (int i = tid * 16; i <= L.qt_w; i += QT_T * 16) *reinterpret_cast<hs_u32x4*>(xtab + i) = hs_gload<hs_u32x4>(L.qt_xtab + i);
+        for (int i = tid * 16; i <= L.qt_h; i += QT_T * 16) *reinterpret_cast<hs_u32x4*>(ytab + i) = hs_gload<hs_u32x4>(L.qt_ytab + i);
     }
     auto spread = [](uint32_t v) { v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u; return v; };   // bit i -> bit 2i
     auto geo_key = [&](int x, int y) {
@@ -884,4 +871,40 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
     dim3 grid(level_count, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
                        pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first);
+}
+
+// Host side of the geometric-key tables (see k_quadtree): the expressions of the kernel's former in-kernel build, evaluated once per
+// configuration.  hs_api.hip is compiled with -ffp-contract=off and IEEE division, like the device code, so the floats agree.
+bool hs_quadtree_build_tables(HsLevel& V, std::vector<uint8_t>& blob, size_t& xoff, size_t& yoff)
+{
+    V.qt_xtab = V.qt_ytab = nullptr;
+    for (int i = 0; i < 8; i++) V.qt_rbound[i] = 0;
+    const int nIni = V.n_ini;
+    if (nIni < 1 || nIni > 8 || V.qt_w <= 0 || V.qt_h <= 0 || V.qt_w >= 8192 - 16 || V.qt_h >= 4096 - 16) return false;
+    const float hX = V.hx;
+    const int DH = nIni <= 2 ? 6 : 5;
+    auto root_of = [&](int x) { return std::min((int)((float)x / hX), nIni - 1); };
+    auto descend = [&](int x, int x0, int x1) {
+        int idx = 0;
+        for (int d = 0; d < DH; d++) {
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            if (x < mx) { x1 = mx; idx = 2 * idx; } else { x0 = mx; idx = 2 * idx + 1; }
+        }
+        return idx;
+    };
+    for (int r = 1; r < nIni; r++) {                                 // smallest x that lands in root r: around r * hX
+        int bnd = (int)(hX * (float)r);
+        while (bnd > 0 && root_of(bnd - 1) >= r) bnd--;
+        while (root_of(bnd) < r) bnd++;
+        V.qt_rbound[r] = bnd;
+    }
+    auto grow = [&](size_t n) { const size_t o = (blob.size() + 15) & ~(size_t)15; blob.resize(o + ((n + 15) & ~(size_t)15), 0); return o; };
+    xoff = grow((size_t)V.qt_w + 1);
+    for (int x = 0; x <= V.qt_w; x++) {
+        const int r = root_of(x);
+        blob[xoff + x] = (uint8_t)descend(x, (int16_t)(int)(hX * (float)r), (int16_t)(int)(hX * (float)(r + 1)));
+    }
+    yoff = grow((size_t)V.qt_h + 1);
+    for (int y = 0; y <= V.qt_h; y++) blob[yoff + y] = (uint8_t)descend(y, 0, (int16_t)V.qt_h);
+    return true;
 }
