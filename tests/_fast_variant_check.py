@@ -31,7 +31,21 @@ def main():
         s.N_CELLS = cells
         gk, gd = HS.ORBExtractor(s)(img)
         assert_same_features(gk, gd, ok, od)
-    print("FAST_VARIANT_OK", {k: v for k, v in os.environ.items() if k.startswith("HS_FAST")})
+    # the stereo matcher on the same handle: golden pair, repeated calls (nothing may be left over between calls), identical views (median 0
+    # rejects everything)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stereo_640x480_1000.npz"))
+    ex = HS.ORBExtractor(settings(1000))
+    cam = HS.Camera(float(g["fx"]), float(g["fx"]) * 0.12, float(g["h"]))
+    sp = oracle.stereo_params(fx=float(g["fx"]), mbf=float(g["fx"]) * 0.12, n_rows=int(g["h"]))
+    for rep in range(3):
+        sm = HS.Stereomatcher(g["kL"], g["kR"], g["dL"], g["dR"], cam, extractor=ex)
+        sm.computeStereoMatches()
+        assert np.array_equal(sm.getData()[0], g["uRight"]) and np.array_equal(sm.getData()[1], g["depth"]), rep
+        sm = HS.Stereomatcher(g["kL"], g["kL"], g["dL"], g["dL"], cam, extractor=ex)
+        sm.computeStereoMatches()
+        ouR, odepth, _, _ = oracle.stereo_match(g["kL"], g["dL"], g["kL"], g["dL"], sp)
+        assert np.array_equal(sm.getData()[0], ouR) and np.array_equal(sm.getData()[1], odepth), rep
+    print("FAST_VARIANT_OK", {k: v for k, v in os.environ.items() if k.startswith("HS_")})
 
 
 if __name__ == "__main__":
