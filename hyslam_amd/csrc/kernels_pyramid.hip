@@ -15,6 +15,7 @@
 #include "hs_internal.h"
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void k_resize_level(const HsLevel* __restrict__ lv, int level, HsImg0 img0)
@@ -229,7 +230,10 @@ template <typename T> __device__ __forceinline__ void hs_gstore_off(uint8_t* uni
 {
     *(HS_GLOBAL T*)((HS_GLOBAL uint8_t*)(uintptr_t)uniform_base + lane_off) = v;
 }
-__global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 img0)
+// NW = wavefronts per workgroup: 4, or 8 when the launch has few workgroups per CU (small batches) — the same tile, half the rows per wave, so a
+// workgroup's life (the launch's critical path when every workgroup is resident at once) is shorter.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsImg0 img0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int TBX = F.tbx, lds_pitch = F.lds_pitch;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 i
         const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
         const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
         if (tx < rpw * nvec) {
-            for (int r = wave * rpw + rl; r < nSr; r += 4 * rpw) {
+            for (int r = wave * rpw + rl; r < nSr; r += NW * rpw) {
                 const hs_u32x4 v = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
                 *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
             }
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 i
         return c;
     };
     auto h_pass = [&](const uint8_t* src, int pitch, int nrow, const ColData& c) {
-        for (int r = wave; r < nrow; r += 4) {
+        for (int r = wave; r < nrow; r += NW) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(&src[r * pitch + c.wbase]);
             const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
             const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, c.wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, c.wshift);
@@ -301,9 +305,9 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 i
         const bool own_col = (int)acol < X.own_x1;
         // the row records are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic
         HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay0 + wave, Y.ay_last)]));
-        for (int ay = ay0 + wave; ay <= Y.ay_last; ay += 4) {
+        for (int ay = ay0 + wave; ay <= Y.ay_last; ay += NW) {
             const HsPyrRow rec = nxt;
-            nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay + 4, Y.ay_last)]));
+            nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay + NW, Y.ay_last)]));
             const uint32_t px = v_combine(rec.r0 - Y.sy_first, rec.r1 - Y.sy_first, rec.b0, rec.b1);
             *reinterpret_cast<uint32_t*>(&s_a[(ay - ay0) * FZ_APITCH + 4 * tx]) = px;
             if (own_col && ay < Y.own_y1) hs_gstore_off<uint32_t>(aimg + (size_t)ay * (uint32_t)F.apitch, acol, px);
@@ -317,12 +321,12 @@ __global__ __launch_bounds__(256) void k_resize_two_levels(HsPyrFuse F, HsImg0 i
     // ---- 5: the level-B tile
     if (4 * tx < TBX && bx0 + 4 * tx < F.bw) {
         uint8_t* const bimg = F.bbase + (size_t)img * F.b_img_stride;
-        HsPyrRow rec4[FZ_ROWS / 4];                                    // the four rows' records (scalar loads) before the first use
+        HsPyrRow rec4[FZ_ROWS / NW];                                    // the four rows' records (scalar loads) before the first use
 #pragma unroll
-        for (int rr = 0; rr < FZ_ROWS / 4; rr++) rec4[rr] = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowB[min(by0 + wave + 4 * rr, F.bh - 1)]));
+        for (int rr = 0; rr < FZ_ROWS / NW; rr++) rec4[rr] = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowB[min(by0 + wave + NW * rr, F.bh - 1)]));
 #pragma unroll
-        for (int rr = 0; rr < FZ_ROWS / 4; rr++) {
-            const int by = by0 + wave + 4 * rr;
+        for (int rr = 0; rr < FZ_ROWS / NW; rr++) {
+            const int by = by0 + wave + NW * rr;
             if (by >= F.bh) break;
             hs_gstore_off<uint32_t>(bimg + (size_t)by * (uint32_t)F.bpitch, (uint32_t)(bx0 + 4 * tx), v_combine(rec4[rr].r0 - ay0, rec4[rr].r1 - ay0, rec4[rr].b0, rec4[rr].b1));
         }
@@ -437,6 +441,12 @@ void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xt
     }
 }
 
+// launches with at most this many workgroups per CU use 8 waves per workgroup (HS_PYRAMID_NW8 = threshold; 0 = never; tuning / parity knob, read once)
+static int pyr_nw8_wg_per_cu()
+{
+    static int v = [] { const char* e = getenv("HS_PYRAMID_NW8"); return e ? atoi(e) : 3; }();
+    return v;
+}
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, int nlevels, HsImg0 img0, int batch, hipStream_t s)
 {
     for (int l = 1; l < nlevels; l++) {
@@ -449,7 +459,9 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse
                 const HsLevel& B = h_lv[l + 1];
                 const size_t lds = (size_t)D.fuse_pitch * D.fuse_sr + (size_t)std::max(D.fuse_sr, D.fuse_ar) * 256 * 2;
                 dim3 grid((B.w + D.fuse_tbx - 1) / D.fuse_tbx, (B.h + FZ_ROWS - 1) / FZ_ROWS, batch);
-                hipLaunchKernelGGL(k_resize_two_levels, grid, dim3(256), lds, s, fuse[l], img0);
+                // few workgroups per CU (small batches): 8 waves per workgroup shorten the workgroup's life, which is the launch's duration then
+                if ((size_t)grid.x * grid.y * grid.z <= (size_t)256 * pyr_nw8_wg_per_cu()) hipLaunchKernelGGL(k_resize_two_levels<8>, grid, dim3(512), lds, s, fuse[l], img0);
+                else hipLaunchKernelGGL(k_resize_two_levels<4>, grid, dim3(256), lds, s, fuse[l], img0);
                 l++;                                           // level l+1 is done too
                 continue;
             }
