@@ -529,7 +529,15 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
         if (FR_STOP <= 4) n_done = 0;
         // ---- the pixel tile is dead: its LDS becomes the dense score tile (rows 0..ih+1, zero except at the corners)
-        if (FR_STOP > 4) for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
+        if (FR_STOP > 4) {
+            if constexpr (TR <= 54) {                            // the whole tile region with compile-time offsets: 11 stores for TR = 40, no loop arithmetic
+#pragma unroll
+                for (int k = 0; k < (TR * PITCH + 1023) / 1024; k++)
+                    if (1024 * (k + 1) <= TR * PITCH || 1024 * k + 16 * tid < TR * PITCH) *reinterpret_cast<uint4*>(score + 1024 * k + 16 * tid) = make_uint4(0, 0, 0, 0);
+            } else {
+                for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
+            }
+        }
         for (int i = tid; i < n_done; i += 64) {
             const int pos = plist[i];
             score[(pos >> 8) * PITCH + (pos & 255)] = pscore[i];
