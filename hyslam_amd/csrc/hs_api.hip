@@ -45,6 +45,8 @@ struct hs_orb {
     uint8_t* d_qt_tabs = nullptr;      // geometric-key tables of the count-domain quadtree (hs_quadtree_build_tables)
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
     std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
+    std::vector<HsPyrChain> pyr_chain; // [level]: kernel argument of the chain launch that starts at this level (HsLevel::chain_n levels)
+    int chain_mode = -1;               // HS_PYRAMID_CHAIN (read once): -1 = a three-level chain for the tail of an odd number of levels, 0 = never, 2 = chains for every fused pair too (parity tests)
     uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
     int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
     uint32_t* d_sel = nullptr;
@@ -109,7 +111,7 @@ void free_geometry(hs_orb* h)
 {
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
-    hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear();
+    hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear();
     hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
@@ -254,8 +256,33 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         for (int l = 1; l < L; l++) ib[l] = tables.data() + tab_off[4 * l + 3];
         std::vector<uint64_t> blob;
         hs_pyramid_build_tables(h->lv.data(), L, xt.data(), yo.data(), ib.data(), blob, h->pyr_fuse);
+        // chains: the last three levels in one launch when the number of levels to make is odd (8 levels: (1,2) (3,4) (5,6,7))
+        h->pyr_chain.assign(L, HsPyrChain{});
+        for (int l = 0; l < L; l++) h->lv[l].chain_n = 0;
+        if (!h->no_fuse && h->chain_mode != 0) {
+            if (h->chain_mode == 2) {
+                for (int l = 1; l + 1 < L; l += 2) {
+                    int n = (l + 3 == L) ? 3 : 2;
+                    hs_pyramid_plan_chain(h->lv.data(), l, n, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l]);
+                    if (!h->pyr_chain[l].valid && n == 3) hs_pyramid_plan_chain(h->lv.data(), l, 2, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l]);
+                    if (h->pyr_chain[l].valid) { h->lv[l].chain_n = h->pyr_chain[l].nstage; if (h->pyr_chain[l].nstage == 3) l++; }
+                }
+            } else if (L >= 4 && ((L - 1) & 1)) {
+                const int l = L - 3;
+                hs_pyramid_plan_chain(h->lv.data(), l, 3, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l]);
+                if (h->pyr_chain[l].valid) h->lv[l].chain_n = 3;
+            }
+        }
         HIP_TRY(h, hipMalloc(&h->d_pyr_tabs, std::max<size_t>(blob.size() * 8, 256)));
         if (!blob.empty()) HIP_TRY(h, hipMemcpy(h->d_pyr_tabs, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+        for (HsPyrChain& C : h->pyr_chain) {                  // blob offsets -> device pointers
+            if (!C.valid) continue;
+            for (int i = 0; i < C.nstage; i++) {
+                HsPyrStage& S = C.st[i];
+                S.rows = reinterpret_cast<const HsPyrRow*>(h->d_pyr_tabs + (uintptr_t)S.rows);
+                S.tx = reinterpret_cast<const HsPyrStageX*>(h->d_pyr_tabs + (uintptr_t)S.tx); S.ty = reinterpret_cast<const HsPyrStageY*>(h->d_pyr_tabs + (uintptr_t)S.ty);
+            }
+        }
         for (HsPyrFuse& F : h->pyr_fuse) {                    // blob offsets -> device pointers
             if (!F.valid) continue;
             F.rowA = reinterpret_cast<const HsPyrRow*>(h->d_pyr_tabs + (uintptr_t)F.rowA); F.rowB = reinterpret_cast<const HsPyrRow*>(h->d_pyr_tabs + (uintptr_t)F.rowB);
@@ -379,14 +406,14 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         if (rc != HS_OK) return rc;
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
         rc = fast(items0, h->fast_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
     } else {
         mark(h, 0, s);
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
         mark(h, 1, s);
         const int rc = fast(0, h->fast_items, 0, s);
         if (rc != HS_OK) return rc;
@@ -488,6 +515,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->p = *p; h->device = device;
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
+    { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
     { const char* e = getenv("HS_EXTRACT_SPLIT"); h->split_mode = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;

@@ -55,6 +55,8 @@ struct HsLevel {
     // two-levels-per-launch pyramid kernel (kernels_pyramid.hip): this level and the next one are produced by one workgroup per tile of the NEXT
     // level; 0 = this pair is not fused.  Tile width of the next level, LDS rows for this level's region / the source rectangle, source pitch.
     int32_t fuse_tbx, fuse_ar, fuse_sr, fuse_pitch;
+    int32_t chain_n;               // levels produced by a k_resize_chain launch that starts at this level (0: none)
+    int32_t _r1;
 };
 
 // One work item of the FAST kernel (kernels_fast.hip): `ncell` horizontally adjacent cells of one cell row.  Everything that does not
@@ -147,8 +149,29 @@ struct HsPyrFuse {
     int32_t tbx, sr, lds_pitch, valid;                             // tile width of level B, LDS rows / pitch of the source rectangle; valid = this pair is fused
 };
 
+// A CHAIN of 2 or 3 levels per launch (k_resize_chain: the two-level scheme applied once more, so that the last three levels of an 8-level
+// pyramid are one launch instead of two).  Stage i produces level first+i from the LDS copy of the level before it (stage 0: from global
+// memory); a workgroup owns one tile of the LAST level and, of every other level, the part induced by the tiles' first source columns / rows.
+struct HsPyrStageX { int32_t x0, own_x1, ncols, src_x0, nvec, _r[3]; };      // region [x0, x0 + ncols) of the stage's level, owned up to own_x1; first column the source buffer holds; stage 0: 16-byte vectors per source row
+struct HsPyrStageY { int32_t y0, own_y1, y_last, src_y0, n_src, _r[3]; };    // region rows [y0, y_last], owned up to own_y1; first row / number of rows the source buffer holds
+static_assert(sizeof(HsPyrStageX) == 32 && sizeof(HsPyrStageY) == 32, "scalar-load records");
+struct HsPyrStage {
+    uint8_t* base; uint64_t img_stride; int32_t pitch, w, h, _r;              // the level the stage produces
+    const HsXTab* xt; const HsPyrRow* rows;                                    // its x table and row records
+    const HsPyrStageX* tx; const HsPyrStageY* ty;                              // [grid.x], [grid.y]
+};
+struct HsPyrChain {
+    const uint8_t* sbase; uint64_t s_img_stride; int32_t spitch, nstage;       // the source level (sbase == nullptr: the caller's frames)
+    HsPyrStage st[3];
+    int32_t tbx, lds_pitch, x_bytes, h_rows;                                   // tile width of the last level; LDS: pitch of the source rectangle, bytes of the level buffer, rows of the sums buffer
+    int32_t grid_x, grid_y, valid, _r;
+};
+
 // kernels_*.hip launchers (all asynchronous on `s`)
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s);
+// plans a chain over levels [first, first + n) (n = 2 or 3): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the geometry does not fit
+void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
+                           std::vector<uint64_t>& blob, HsPyrChain& C);
 // host side of HsPyrFuse for every fused pair: records appended to `blob` (device pointers are blob offsets until hs_api.hip relocates them)
 void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
                              std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse);

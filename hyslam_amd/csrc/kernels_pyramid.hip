@@ -333,6 +333,225 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A chain of 2 or 3 levels per launch: the scheme of k_resize_two_levels as a loop over stages.  Stage i stages (i = 0: from global memory)
+// or finds (i > 0: the region the previous stage left in LDS) its source, makes the horizontal sums of the source rows for its region's
+// columns, combines them vertically into its region, stores the part of the region the workgroup OWNS and keeps the region in LDS for the next
+// stage.  Everything wave-uniform comes from two 32-byte records per stage (HsPyrStageX / HsPyrStageY, hs_pyramid_plan_chain).  Used for
+// the last THREE levels of a pyramid with an odd number of levels to make (levels 5, 6, 7 of 8: one launch instead of two).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 img0)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const s_x = smem;                                                           // source rectangle (stage 0) / region of the previous stage
+    uint16_t* const s_h = reinterpret_cast<uint16_t*>(smem + F.x_bytes);                 // [h_rows][256] (H >> 4)
+    const int img = blockIdx.z;
+    const int tx = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint8_t* sbase; uint32_t spitch;
+    if (F.sbase == nullptr) { sbase = hs_img0_ptr(img0, img); spitch = (uint32_t)img0.row_stride; }
+    else { sbase = F.sbase + (size_t)img * F.s_img_stride; spitch = (uint32_t)F.spitch; }
+    int src_pitch = F.lds_pitch;
+    for (int st = 0; st < F.nstage; st++) {
+        const HsPyrStage& S = F.st[st];
+        const HsPyrStageX X = __builtin_bit_cast(HsPyrStageX, hs_cload<hs_u32x8>(&S.tx[blockIdx.x]));
+        const HsPyrStageY Y = __builtin_bit_cast(HsPyrStageY, hs_cload<hs_u32x8>(&S.ty[blockIdx.y]));
+        if (st == 0) {                                               // the source rectangle: a wave takes whole rows, floor(64 / nvec) at a time
+            const uint8_t* const src0 = hs_uniform_ptr(sbase + (size_t)Y.src_y0 * spitch + X.src_x0);
+            const int nvec = X.nvec;
+            const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
+            const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
+            if (tx < rpw * nvec) {
+                for (int r = wave * rpw + rl; r < Y.n_src; r += NW * rpw) {
+                    const hs_u32x4 v = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
+                    *reinterpret_cast<hs_u32x4*>(&s_x[r * src_pitch + 16 * q]) = v;
+                }
+            }
+        }
+        // per-lane column data of the stage's horizontal pass: window position, byte-pair selectors, coefficient pairs
+        int wbase, wshift; uint32_t sel[4], coef[4];
+        {
+            HsXTab t[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, hs_gload<uint64_t>(&S.xt[min(X.x0 + 4 * tx + i, S.w - 1)]));
+            const int o0 = t[0].sx - X.src_x0;
+            wbase = o0 & ~3; wshift = o0 & 3;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t q = (uint32_t)(t[i].sx - t[0].sx);
+                sel[i] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
+                coef[i] = ((uint32_t)(uint16_t)t[i].a0 << 4) | ((uint32_t)(uint16_t)t[i].a1 << 20);
+            }
+        }
+        __syncthreads();                                             // the source is in LDS (staged, or written by the previous stage)
+        if (4 * tx < X.ncols) {
+            for (int r = wave; r < Y.n_src; r += NW) {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_x[r * src_pitch + wbase]);
+                const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+                const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, wshift);
+                *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(whi, wlo, sel[0], sel[1], coef[0], coef[1]), pyr_hpair(whi, wlo, sel[2], sel[3], coef[2], coef[3]));
+            }
+        }
+        __syncthreads();                                             // the sums are complete, the source is dead: the region overlays it
+        {
+            uint8_t* const dimg = S.base + (size_t)img * S.img_stride;
+            const uint32_t col = (uint32_t)(X.x0 + 4 * tx);
+            const bool lane_on = 4 * tx < X.ncols, own_col = (int)col < X.own_x1;
+            const bool keep = st + 1 < F.nstage;                     // uniform: a later stage reads the region from LDS
+            HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&S.rows[min(Y.y0 + wave, Y.y_last)]));
+            for (int y = Y.y0 + wave; y <= Y.y_last; y += NW) {
+                const HsPyrRow rec = nxt;
+                nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&S.rows[min(y + NW, Y.y_last)]));
+                if (lane_on) {
+                    const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[(rec.r0 - Y.src_y0) * 256 + 4 * tx]);
+                    const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[(rec.r1 - Y.src_y0) * 256 + 4 * tx]);
+                    const uint32_t px = pyr_vquad(H0, H1, rec.b0, rec.b1);
+                    if (keep) *reinterpret_cast<uint32_t*>(&s_x[(y - Y.y0) * FZ_APITCH + 4 * tx]) = px;
+                    if (own_col && y < Y.own_y1) hs_gstore_off<uint32_t>(dimg + (size_t)y * (uint32_t)S.pitch, col, px);
+                }
+            }
+        }
+        src_pitch = FZ_APITCH;
+    }
+}
+
+// Host side of k_resize_chain for the levels [first, first + n): walks the tiles of the LAST level from the largest tile width downwards until every
+// stage's region fits 256 columns and the LDS buffers, with the expressions of hs_pyramid_build_tables / the two-level kernel.
+void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
+                           std::vector<uint64_t>& blob, HsPyrChain& C)
+{
+    C = HsPyrChain{};
+    if (n < 2 || n > 3 || first < 1) return;
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    for (int i = 0; i < n; i++) {
+        const HsLevel& D = h_lv[first + i]; const HsLevel& S = h_lv[first + i - 1];
+        if ((double)S.w / D.w > 2.0 || (double)S.h / D.h > 2.0 || D.w < 8 || D.h < 1) return;
+    }
+    const HsLevel& LAST = h_lv[first + n - 1];
+    const int nby = (LAST.h + FZ_ROWS - 1) / FZ_ROWS;
+    // ---- rows (independent of the tile width): part starts, owned ends, regions and source spans — the same three steps as for the columns below
+    std::vector<std::vector<HsPyrStageY>> ty(n, std::vector<HsPyrStageY>(nby));
+    int h_rows = 0, x_rows0 = 0, x_rows = 0;
+    for (int by = 0; by < nby; by++) {
+        int y0 = by * FZ_ROWS;
+        for (int i = n - 1; i >= 0; i--) {
+            ty[i][by] = HsPyrStageY{};
+            ty[i][by].y0 = y0;
+            if (i > 0) y0 = by == 0 ? 0 : clampi(yofs[first + i][y0], 0, h_lv[first + i - 1].h - 1);
+        }
+    }
+    for (int by = 0; by < nby; by++)
+        for (int i = n - 1; i >= 0; i--) {
+            HsPyrStageY& t = ty[i][by];
+            t.own_y1 = by + 1 < nby ? ty[i][by + 1].y0 : h_lv[first + i].h;
+            if (t.own_y1 < t.y0) return;
+        }
+    for (int by = 0; by < nby; by++) {
+        int need_last = std::min(by * FZ_ROWS + FZ_ROWS, LAST.h) - 1;              // last row of the stage's level that is really read
+        for (int i = n - 1; i >= 0; i--) {
+            const HsLevel& S = h_lv[first + i - 1];
+            const int16_t* yo = yofs[first + i];
+            HsPyrStageY& t = ty[i][by];
+            t.y_last = std::max(need_last, t.own_y1 - 1);
+            const int src_first = clampi(yo[t.y0], 0, S.h - 1), src_last = clampi(yo[t.y_last] + 1, 0, S.h - 1);
+            if (i > 0) {
+                if (src_first < ty[i - 1][by].y0) return;
+                t.src_y0 = ty[i - 1][by].y0;
+                need_last = src_last;
+            } else {
+                t.src_y0 = src_first; t.n_src = src_last - src_first + 1;
+                x_rows0 = std::max(x_rows0, t.n_src);
+                h_rows = std::max(h_rows, t.n_src);
+            }
+        }
+        for (int i = n - 1; i >= 1; i--) {                                          // the source of stage i is the whole region of stage i - 1
+            ty[i][by].n_src = ty[i - 1][by].y_last - ty[i - 1][by].y0 + 1;
+            x_rows = std::max(x_rows, ty[i][by].n_src);
+            h_rows = std::max(h_rows, ty[i][by].n_src);
+        }
+    }
+    // ---- columns: the largest tile width whose regions fit
+    for (int tbx = 256; tbx >= 64; tbx -= 4) {
+        const int nbx = (LAST.w + tbx - 1) / tbx;
+        std::vector<std::vector<HsPyrStageX>> txs(n, std::vector<HsPyrStageX>(nbx));
+        bool ok = true; int pitch = 0;
+        // first columns of every level's parts, last level first (a part starts at the first source column of the tile's part of the level below it)
+        for (int bx = 0; bx < nbx && ok; bx++) {
+            int x0 = bx * tbx;
+            for (int i = n - 1; i >= 0; i--) {
+                txs[i][bx] = HsPyrStageX{};
+                txs[i][bx].x0 = x0;
+                if (i > 0) x0 = bx == 0 ? 0 : (xtab[first + i][4 * x0] & ~3);
+            }
+        }
+        for (int bx = 0; bx < nbx && ok; bx++)
+            for (int i = n - 1; i >= 0; i--) {
+                const HsLevel& D = h_lv[first + i];
+                HsPyrStageX& t = txs[i][bx];
+                t.own_x1 = bx + 1 < nbx ? txs[i][bx + 1].x0 : ((D.w + 3) & ~3);
+                if (t.own_x1 < t.x0) ok = false;
+            }
+        // regions: last level = the tile; the level below it must hold the columns the region's last column reads
+        for (int bx = 0; bx < nbx && ok; bx++) {
+            int need_last = std::min(bx * tbx + tbx, LAST.w) - 1;                  // last column of the region of stage i that is really read
+            for (int i = n - 1; i >= 0; i--) {
+                const HsLevel& D = h_lv[first + i]; const HsLevel& S = h_lv[first + i - 1];
+                HsPyrStageX& t = txs[i][bx];
+                const int reg_last = std::max(need_last, std::min(t.own_x1, D.w) - 1);
+                t.ncols = ((std::max(reg_last + 1, t.own_x1) - t.x0) + 3) & ~3;
+                if (t.ncols > 256 || t.ncols <= 0) { ok = false; break; }
+                const int16_t* xt = xtab[first + i];
+                const int src_need_first = xt[4 * t.x0], src_need_last = std::min(xt[4 * std::min(reg_last, D.w - 1)] + 1, S.w - 1);
+                if (i > 0) {
+                    const HsPyrStageX& u = txs[i - 1][bx];
+                    if (src_need_first < u.x0) { ok = false; break; }
+                    t.src_x0 = u.x0;
+                    // the window of the last active lane (offset of its first column + 12 bytes) must stay inside the LDS row of the region below
+                    const int lastlane_col = std::min(t.x0 + t.ncols - 4, D.w - 1);
+                    if (xt[4 * lastlane_col] - u.x0 + 12 > FZ_APITCH) { ok = false; break; }
+                    need_last = src_need_last;
+                } else {
+                    t.src_x0 = src_need_first & ~15;
+                    t.nvec = ((src_need_last - t.src_x0) >> 4) + 1;
+                    pitch = std::max(pitch, t.nvec * 16 + 16);
+                    const int lastlane_col = std::min(t.x0 + t.ncols - 4, D.w - 1);
+                    if (xt[4 * lastlane_col] - t.src_x0 + 12 > t.nvec * 16 + 16) { ok = false; break; }
+                }
+            }
+        }
+        if (!ok) continue;
+        pitch = (pitch + 15) & ~15;
+        const size_t x_bytes = std::max((size_t)pitch * x_rows0, (size_t)FZ_APITCH * x_rows);
+        const size_t lds = ((x_bytes + 15) & ~(size_t)15) + (size_t)h_rows * 256 * 2;
+        if (lds > 60 * 1024) continue;
+        // ---- commit
+        if (blob.empty()) blob.push_back(0);
+        C.sbase = first == 1 ? nullptr : h_lv[first - 1].base; C.s_img_stride = h_lv[first - 1].img_stride; C.spitch = h_lv[first - 1].pitch; C.nstage = n;
+        for (int i = 0; i < n; i++) {
+            const HsLevel& D = h_lv[first + i];
+            HsPyrStage& S = C.st[i];
+            S.base = D.base; S.img_stride = D.img_stride; S.pitch = D.pitch; S.w = D.w; S.h = D.h;
+            S.xt = reinterpret_cast<const HsXTab*>(D.xofs);
+            const size_t orow = blob.size(); blob.resize(orow + (size_t)D.h + 8);
+            const int sh = h_lv[first + i - 1].h;
+            for (int dy = 0; dy < D.h; dy++) {
+                HsPyrRow r;
+                r.r0 = (int16_t)clampi(yofs[first + i][dy], 0, sh - 1); r.r1 = (int16_t)clampi(yofs[first + i][dy] + 1, 0, sh - 1);
+                r.b0 = (uint16_t)ibeta[first + i][2 * dy]; r.b1 = (uint16_t)ibeta[first + i][2 * dy + 1];
+                memcpy(&blob[orow + dy], &r, 8);
+            }
+            S.rows = reinterpret_cast<const HsPyrRow*>(orow * 8);
+            const size_t ox = blob.size(); blob.resize(ox + 4 * (size_t)nbx);
+            memcpy(&blob[ox], txs[i].data(), 32 * (size_t)nbx);
+            const size_t oy = blob.size(); blob.resize(oy + 4 * (size_t)nby);
+            memcpy(&blob[oy], ty[i].data(), 32 * (size_t)nby);
+            S.tx = reinterpret_cast<const HsPyrStageX*>(ox * 8); S.ty = reinterpret_cast<const HsPyrStageY*>(oy * 8);
+        }
+        C.tbx = tbx; C.lds_pitch = pitch; C.x_bytes = (int32_t)((x_bytes + 15) & ~(size_t)15); C.h_rows = h_rows; C.grid_x = nbx; C.grid_y = nby; C.valid = 1;
+        return;
+    }
+}
+
 // Host side of the table-driven kernel: for every fused pair the tile records (the geometry the kernel used to compute itself, same
 // expressions) and for both levels of the pair the row records; everything is appended to `blob`, pointers into it are byte offsets.
 void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
@@ -447,10 +666,23 @@ static int pyr_nw8_wg_per_cu()
     static int v = [] { const char* e = getenv("HS_PYRAMID_NW8"); return e ? atoi(e) : 3; }();
     return v;
 }
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, int nlevels, HsImg0 img0, int batch, hipStream_t s)
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s)
 {
     for (int l = 1; l < nlevels; l++) {
         const HsLevel& D = h_lv[l];
+        if (chain && D.chain_n > 0 && chain[l].valid && l + D.chain_n <= nlevels) {
+            bool vec16 = true;
+            if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((h_lv[0].w + 15) & ~15) <= (int)img0.row_stride;
+            if (vec16) {
+                const HsPyrChain& C = chain[l];
+                const size_t lds = (size_t)C.x_bytes + (size_t)C.h_rows * 256 * 2;
+                dim3 grid(C.grid_x, C.grid_y, batch);
+                if ((size_t)grid.x * grid.y * grid.z <= (size_t)256 * pyr_nw8_wg_per_cu()) hipLaunchKernelGGL(k_resize_chain<8>, grid, dim3(512), lds, s, C, img0);
+                else hipLaunchKernelGGL(k_resize_chain<4>, grid, dim3(256), lds, s, C, img0);
+                l += C.nstage - 1;
+                continue;
+            }
+        }
         if (D.fuse_tbx > 0 && l + 1 < nlevels && fuse && fuse[l].valid) {
             // 16-byte source vectors: always fine for our own levels (pitch % 64 == 0), checked for the caller's frames
             bool vec16 = true;
@@ -495,7 +727,7 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse
 int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels)
 {
     int n = 0;
-    for (int l = 1; l < nlevels; l++) { n++; if (h_lv[l].fuse_tbx > 0 && l + 1 < nlevels) l++; }
+    for (int l = 1; l < nlevels; l++) { n++; if (h_lv[l].chain_n > 0 && l + h_lv[l].chain_n <= nlevels) l += h_lv[l].chain_n - 1; else if (h_lv[l].fuse_tbx > 0 && l + 1 < nlevels) l++; }
     return n;
 }
 
