@@ -23,6 +23,7 @@ struct hs_orb {
     int split_mode = -1;               // HS_EXTRACT_SPLIT (read once): 1 = always run level 0's FAST + quadtree beside the pyramid, 0 = never, -1 = for small batches
     hipStream_t s_aux = nullptr; hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;      // the second launch sequence of the split and its fences
     bool qt_point_domain = false;      // HS_QT_POINT_DOMAIN=1 (read once): the quadtree's general point-domain passes only (parity tests of the fallback)
+    int fast_order = 1;                // HS_FAST_ORDER (read once): order of the FAST work items of an image: 1 = reduced levels deepest first, level 0 last; 0 = level 0 first (the order until round 3); 2 = reduced levels interleaved, level 0 last
     bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
@@ -216,6 +217,18 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     h->max_wcell = h->max_hcell = 1;
     for (int l = 0; l < L; l++) { h->max_wcell = std::max(h->max_wcell, h->lv[l].wcell); h->max_hcell = std::max(h->max_hcell, h->lv[l].hcell); }
     h->total_cells = cells; h->fast_items = items; h->cand_img_stride = cand; h->sel_img_stride = sel; h->max_kp = sel;
+    // Order of the FAST work items of an image: the REDUCED levels first, deepest level first, level 0 last.  An item of a reduced level
+    // costs 2-3 times an item of level 0 (the same number of pixels, denser corners), and the persistent FAST kernel walks the items in this
+    // order: with the cheap, uniform level-0 items at the end of every queue the tail of the launch — waves finishing their last item while
+    // the queues are empty — is short (a 32-frame launch spent ~17 % more per frame than a 128-frame launch with the expensive items last).
+    {
+        int pos = 0;
+        if (h->fast_order == 0) { for (int l = 0; l < L; l++) { h->lv[l].item_begin = pos; pos += h->lv[l].ngroups * h->lv[l].nrows; } }
+        else {
+            for (int l = L - 1; l >= 1; l--) { h->lv[l].item_begin = pos; pos += h->lv[l].ngroups * h->lv[l].nrows; }
+            h->lv[0].item_begin = pos;
+        }
+    }
 
     HIP_TRY(h, hipMalloc(&h->d_pyr, std::max<size_t>(pyr_per_img * batch, 256)));
     HIP_TRY(h, hipMalloc(&h->d_tables, std::max<size_t>(tables.size() * sizeof(int16_t), 256)));
@@ -293,6 +306,17 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     {
         std::vector<HsFastItem> fi(std::max(items, 1));
         hs_fast_build_items(h->lv.data(), L, fi.data());
+        if (h->fast_order == 2 && L > 2) {                     // experiment: the reduced levels interleaved in proportion (every stretch of the list has the same mix of levels), level 0 last
+            const int n_red = h->lv[0].item_begin;
+            std::vector<std::pair<double, int>> key(n_red);
+            for (int l = 1; l < L; l++) {
+                const int n = h->lv[l].ngroups * h->lv[l].nrows;
+                for (int k = 0; k < n; k++) key[h->lv[l].item_begin + k] = { (k + 0.5) / n, h->lv[l].item_begin + k };
+            }
+            std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+            std::vector<HsFastItem> t(fi.begin(), fi.begin() + n_red);
+            for (int i = 0; i < n_red; i++) fi[i] = t[key[i].second];
+        }
         HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
         HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch, h->fast_knobs), 256)));
@@ -372,7 +396,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     // results.  Measured: the 4000 x 3000 "Imaging" extraction 0.245 -> 0.16 ms (config C4: 2 350 -> 3 550 steps/s); a 1080p pair gets SLOWER
     // (0.132 -> 0.160 ms: the fork / join between the streams costs more than the overlap saves), 16 pairs too (0.468 -> 0.519 ms), hence the
     // size rule.  Not with stage events (they would serialise the two sequences).
-    const int items0 = L > 1 ? h->lv[1].item_begin : h->fast_items;            // work items of level 0 come first in the item list
+    const int items0 = h->lv[0].ngroups * h->lv[0].nrows, first0 = h->lv[0].item_begin;      // work items of level 0: the LAST items0 of the item list
     const bool split = !h->prof && L > 1 && items0 > 0 && items0 < h->fast_items && (h->split_mode == 1 || (h->split_mode < 0 && batch <= 2 && (size_t)h->w * (size_t)h->h * (size_t)batch >= 6000000));
     auto fast = [&](int item_first, int item_count, int spill_slot, hipStream_t st) -> int {
         // launch N uses work-queue counter set N & 3 and relies on launch N - 2 having zeroed it: the epoch advances only when a launch was
@@ -402,12 +426,12 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         }
         HIP_TRY(h, hipEventRecord(h->ev_sfork, s));                           // everything enqueued on s so far (the frames' upload, the previous call) comes first
         HIP_TRY(h, hipStreamWaitEvent(h->s_aux, h->ev_sfork, 0));
-        int rc = fast(0, items0, 1, h->s_aux);
+        int rc = fast(first0, items0, 1, h->s_aux);
         if (rc != HS_OK) return rc;
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
         hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
-        rc = fast(items0, h->fast_items - items0, 0, s);
+        rc = fast(0, h->fast_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
@@ -515,6 +539,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->p = *p; h->device = device;
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
+    { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
     { const char* e = getenv("HS_EXTRACT_SPLIT"); h->split_mode = e ? (atoi(e) != 0 ? 1 : 0) : -1; }

@@ -123,11 +123,25 @@ struct RowGeom {            // wave-uniform description of one work item in one 
     bool valid, aligned;
 };
 
-__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, int w)
+// Work unit w -> (image, item).  The item list of an image is ordered expensive items first (the reduced levels, deepest first; level 0 last:
+// hs_api.hip).  When the batch is a multiple of 8 every work queue (an eighth of the units) owns `grp` whole images and walks them ITEM-major:
+// item 0 of its images, item 1 of its images, ... — the queue's expensive items are all handed out early and its last units are the cheap
+// level-0 items of all its images, so the tail of the launch (every wave still holds its current and its pre-grabbed next item when the queue
+// runs dry) is two cheap items long.  Image-major (all items of image 0, then image 1, ...) a wave could pick up one of the LAST image's
+// 50-70 us items just before the queue ran dry: a third of the launch (63 of 192 us at 32 frames) was such a tail.
+__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, int grp, int w)
 {
     RowGeom g;
-    g.img = w / items_per_img;
-    const HsFastItem it = items[w - g.img * items_per_img];     // one s_load_dwordx16 (`items` already points at the launch's first item)
+    int item;
+    if (grp > 0) {
+        const int per_q = grp * items_per_img, q = w / per_q, u = w - q * per_q;
+        item = u / grp;
+        g.img = q * grp + (u - item * grp);
+    } else {
+        g.img = w / items_per_img;
+        item = w - g.img * items_per_img;
+    }
+    const HsFastItem it = items[item];                           // one s_load_dwordx16 (`items` already points at the launch's first item)
     g.ncell = it.ncell; g.c0 = it.c0; g.gcell0 = it.gcell0; g.slot0 = it.slot0; g.ccap = it.ccap;
     g.inv_w = it.inv_w; g.inv_w1 = it.inv_w1;
     g.xoff = it.xoff; g.yoff = it.yoff;
@@ -156,6 +170,14 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
 // 2 + list expansion, 3 + segment test, 4 + scores; results are meaningless (no candidates come out), only the SQ counters are read.
 #ifndef FR_STOP
 #define FR_STOP 99
+#endif
+#if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)   // make EXTRA=-DHS_FAST_WAVES: two real-time stamps per item and nothing else (tools/fast_wave_timeline.py)
+__device__ unsigned long long g_fr_wave[4096 * 8];           // per workgroup: first stamp, stamp after the first item, last stamp, items, longest item (10 ns ticks), its work index
+extern "C" void hs_debug_fast_waves(unsigned long long* out /*[4096 * 8]*/)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_wave), sizeof(unsigned long long) * 4096 * 8);
+}
 #endif
 #ifdef HS_FAST_PROFILE       // make EXTRA=-DHS_FAST_PROFILE: per-phase cycle totals over all waves (tools/fast_phase_profile.py)
 __device__ unsigned long long g_fr_prof[16];
@@ -191,7 +213,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
-                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base)
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base, int grp)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -273,8 +295,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     unsigned long long fr_acc[10] = {};
     FR_T(t_kernel0);
 #endif
+#if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
+    const unsigned long long fr_real0 = __builtin_amdgcn_s_memrealtime();     // the 100 MHz real-time counter: the same on every CU (s_memtime is not)
+    unsigned long long fr_prev = fr_real0, fr_first = 0, fr_long = 0, fr_long_w = 0, fr_items = 0;
+#endif
     hs_u32x4 pre[NL];
-    RowGeom g = row_geom(items, img0, items_per_img, w);
+    RowGeom g = row_geom(items, img0, items_per_img, grp, w);
     // All NL loads are issued unconditionally (rows beyond the tile re-read its last row, columns beyond it the last needed
     // 16 bytes): predicating them makes the compiler copy the whole register array at every merge point.
     auto prefetch = [&](const RowGeom& q) {
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         if (!g.valid) {
             if (tid == 0) cnt_out[0] = 0;
             w = resolve(raw_next);
-            if (w >= 0) { g = row_geom(items, img0, items_per_img, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
+            if (w >= 0) { g = row_geom(items, img0, items_per_img, grp, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
             continue;
         }
         // ---- stage the tile
@@ -318,7 +344,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
         // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
         const int w_next = resolve(raw_next);
-        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
+        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, grp, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
         FR_T(t2);
         FR_ACC(1, t1, t2);
 
@@ -585,6 +611,14 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         fr_acc[8] += 1;
         fr_acc[3] += n_ovf > 0;
 #endif
+#if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (fr_items == 0) fr_first = now;
+            if (now - fr_prev > fr_long) { fr_long = now - fr_prev; fr_long_w = (unsigned long long)(unsigned)w | ((unsigned long long)(n_ovf > 0) << 32); }
+            fr_prev = now; fr_items++;
+        }
+#endif
         w = w_next;
     }
 #ifdef HS_FAST_PROFILE
@@ -592,6 +626,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     fr_acc[9] = t_kernel1 - t_kernel0;
     if (tid == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_fr_prof[i], fr_acc[i]);
     if (tid == 0) atomicAdd(&g_fr_prof[10], 1ull);
+#endif
+#if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = &g_fr_wave[blockIdx.x * 8];
+        o[0] = fr_real0; o[1] = fr_first; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = fr_items; o[4] = fr_long; o[5] = fr_long_w;
+    }
 #endif
 }
 
@@ -649,6 +689,7 @@ HsFastKnobs hs_fast_read_knobs()
     if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) k.small_lists = atoi(e) != 0; // parity tests: force the spill paths
     if (const char* e = getenv("HS_FAST_WG_PER_CU")) k.wg_per_cu = atoi(e);               // tuning: workgroups per CU
     if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) k.force_scan_b = atoi(e) != 0;     // parity tests: NMS from the score tile
+    if (const char* e = getenv("HS_FAST_IMAGE_MAJOR")) k.image_major = atoi(e) != 0;      // tuning / parity tests: the work units image-major whatever the batch
     return k;
 }
 
@@ -713,9 +754,10 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
+    const int grp = (batch >= 8 && batch % 8 == 0 && !knobs.image_major) ? batch / 8 : 0;      // images per work queue walked item-major (row_geom)
     const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, grp)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
