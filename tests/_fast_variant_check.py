@@ -45,6 +45,13 @@ def main():
         sm.computeStereoMatches()
         ouR, odepth, _, _ = oracle.stereo_match(g["kL"], g["dL"], g["kL"], g["dL"], sp)
         assert np.array_equal(sm.getData()[0], ouR) and np.array_equal(sm.getData()[1], odepth), rep
+    # a batch of 8 frames in one call: the FAST work queues own whole images and walk them item-major (HS_FAST_IMAGE_MAJOR=1: image-major)
+    frames = [synth_image(40 + i, 640, 480) for i in range(8)]
+    ex8 = HS.ORBExtractor(settings(600))
+    kl, dl = ex8.extract_batch(frames)
+    for f, gk, gd in zip(frames, kl, dl):
+        ok, od = oracle.extract(oracle.default_params(600), f)
+        assert_same_features(gk, gd, ok, od)
     print("FAST_VARIANT_OK", {k: v for k, v in os.environ.items() if k.startswith("HS_")})
 
 
