@@ -123,20 +123,42 @@ struct RowGeom {            // wave-uniform description of one work item in one 
     bool valid, aligned;
 };
 
-// Work unit w -> (image, item).  The item list of an image is ordered expensive items first (the reduced levels, deepest first; level 0 last:
-// hs_api.hip).  When the batch is a multiple of 8 every work queue (an eighth of the units) owns `grp` whole images and walks them ITEM-major:
-// item 0 of its images, item 1 of its images, ... — the queue's expensive items are all handed out early and its last units are the cheap
-// level-0 items of all its images, so the tail of the launch (every wave still holds its current and its pre-grabbed next item when the queue
-// runs dry) is two cheap items long.  Image-major (all items of image 0, then image 1, ...) a wave could pick up one of the LAST image's
-// 50-70 us items just before the queue ran dry: a third of the launch (63 of 192 us at 32 frames) was such a tail.
-__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, int grp, int w)
+// How the work units of a launch are spread over the work queues (host: fast_sched()).  The item list of an image is ordered expensive items
+// first (the reduced levels, deepest first; level 0 last: hs_api.hip); a queue hands out its units in order, so its LAST units should be cheap —
+// every wave still holds its current and its pre-grabbed next item when the queue runs dry, and with heavy items among them the launch ended with
+// a third of its time spent draining (63 of 192 us at 32 frames; `tools/fast_wave_timeline.py`).  And there should be MANY queues: a queue is
+// one counter, a counter serves same-address atomics one after the other, and with 8 of them for 30 000 items the grabs themselves were late
+// (8 -> 32 queues: 0.175 -> 0.158 ms per 32 frames).
+//   mode 1  the batch is a multiple of the queue count: a queue owns `par` whole images and walks them ITEM-major (item 0 of its images, item 1,
+//           ...): its expensive items all go out early, its last units are the level-0 items of all its images
+//   mode 2  the queue count is a multiple of the batch: an image is dealt round-robin to `par` queues (item i -> queue i % par), every one of
+//           which sees the same mix of levels in the same order
+//   mode 3  anything else: the item-major list of ALL images (item 0 of every image, item 1, ...) dealt round-robin to the queues
+//   mode 0  contiguous ranges of the image-major order (HS_FAST_IMAGE_MAJOR=1: the scheme until the end of round 3, kept as a parity variant)
+struct FastSched { int32_t nq_log, mode, par, par_log, per_q; };
+__device__ __forceinline__ int fast_queue_size(const FastSched& S, int qq, int total_work, int items_per_img)
+{
+    if (S.mode == 1) return S.per_q;
+    if (S.mode == 2) return (items_per_img - (qq & (S.par - 1)) + S.par - 1) >> S.par_log;
+    if (S.mode == 3) return (total_work - qq + (1 << S.nq_log) - 1) >> S.nq_log;
+    return min(max(total_work - qq * S.per_q, 0), S.per_q);
+}
+__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, const FastSched& S, int w)
 {
     RowGeom g;
     int item;
-    if (grp > 0) {
-        const int per_q = grp * items_per_img, q = w / per_q, u = w - q * per_q;
-        item = u / grp;
-        g.img = q * grp + (u - item * grp);
+    if (S.mode == 1) {
+        const int q = w / S.per_q, u = w - q * S.per_q;
+        item = u / S.par;
+        g.img = q * S.par + (u - item * S.par);
+    } else if (S.mode == 2) {
+        const int q = w / S.per_q, u = w - q * S.per_q;
+        g.img = q >> S.par_log;
+        item = (u << S.par_log) + (q & (S.par - 1));
+    } else if (S.mode == 3) {
+        const int q = w / S.per_q, u = w - q * S.per_q, gidx = (u << S.nq_log) + q;      // position in the item-major list of all S.par images
+        item = gidx / S.par;
+        g.img = gidx - item * S.par;
     } else {
         g.img = w / items_per_img;
         item = w - g.img * items_per_img;
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
-                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base, int grp)
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base, FastSched S)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
     uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
     uint32_t* const queue = overflow + (size_t)(epoch & 3) * HS_FAST_QUEUE_DWORDS;   // 8 work counters, 128 bytes apart
-    if (blockIdx.x == 0 && threadIdx.x < 8) overflow[(size_t)((epoch + 2) & 3) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < HS_FAST_NQ_MAX) overflow[(size_t)((epoch + 2) & 3) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
     uint32_t* const ovf = overflow + 4 * HS_FAST_QUEUE_DWORDS + spill_base + (size_t)blockIdx.x * overflow_stride;   // this wave's spill area for scored corners (list overflow only)
     const uint32_t* const tile32 = reinterpret_cast<const uint32_t*>(tile);
     const uint32_t* const score32 = reinterpret_cast<const uint32_t*>(score);
@@ -255,9 +277,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     // Four counter sets rotate between launches: a launch uses set `epoch & 3` and its first workgroup zeroes set `(epoch + 2) & 3` for the
     // launch after next — no memset launch in the chain.  Two consecutive launches of a handle may run CONCURRENTLY (level 0 beside the
     // pyramid, the other levels after it: hs_api.hip), which is why the set a launch zeroes is not the next launch's.
-    const int per_x = (total_work + 7) >> 3, wpx = gridDim.x >> 3;
-    int q = (int)(blockIdx.x & 7);                               // current queue (wave-uniform)
-    auto q_size = [&](int qq) { return min(max(total_work - qq * per_x, 0), per_x); };
+    const int nq = 1 << S.nq_log, per_x = S.per_q, wpx = gridDim.x >> S.nq_log;
+    int q = (int)(blockIdx.x & (nq - 1));                        // current queue (wave-uniform); blockIdx % 8 = the XCD under round-robin placement
+    auto q_size = [&](int qq) { return fast_queue_size(S, qq, total_work, items_per_img); };
     // one lane asks; the value comes back in a VGPR and is only read (readfirstlane) an item later
     auto grab_async = [&](int qq) -> uint32_t {
         uint32_t v = 0;
@@ -274,10 +296,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         if (idx < q_size(q)) return q * per_x + idx;
         for (int tries = 0; tries < 8; tries++) {
             int rem = 0;
-            if (tid < 8) rem = q_size(tid) - wpx - (int)__hip_atomic_load(&queue[tid * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < nq) rem = q_size(tid) - wpx - (int)__hip_atomic_load(&queue[tid * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int best = 0, best_q = -1;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { const int r = __builtin_amdgcn_readlane(rem, i); if (r > best) { best = r; best_q = i; } }
+            for (int i = 0; i < nq; i++) { const int r = __builtin_amdgcn_readlane(rem, i); if (r > best) { best = r; best_q = i; } }
             if (best_q < 0) return -1;
             q = best_q;
             idx = (int)__builtin_amdgcn_readfirstlane(grab_async(q)) + wpx;      // synchronous: only at the very end of the launch
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         return -1;
     };
-    int w = (int)(blockIdx.x >> 3) < q_size(q) ? q * per_x + (int)(blockIdx.x >> 3) : (dynamic ? resolve(grab_async(q)) : -1);
+    int w = (int)(blockIdx.x >> S.nq_log) < q_size(q) ? q * per_x + (int)(blockIdx.x >> S.nq_log) : (dynamic ? resolve(grab_async(q)) : -1);
     if (w < 0) return;
     uint32_t raw_next = dynamic ? grab_async(q) : 0u;            // the second item
 
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     unsigned long long fr_prev = fr_real0, fr_first = 0, fr_long = 0, fr_long_w = 0, fr_items = 0;
 #endif
     hs_u32x4 pre[NL];
-    RowGeom g = row_geom(items, img0, items_per_img, grp, w);
+    RowGeom g = row_geom(items, img0, items_per_img, S, w);
     // All NL loads are issued unconditionally (rows beyond the tile re-read its last row, columns beyond it the last needed
     // 16 bytes): predicating them makes the compiler copy the whole register array at every merge point.
     auto prefetch = [&](const RowGeom& q) {
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         if (!g.valid) {
             if (tid == 0) cnt_out[0] = 0;
             w = resolve(raw_next);
-            if (w >= 0) { g = row_geom(items, img0, items_per_img, grp, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
+            if (w >= 0) { g = row_geom(items, img0, items_per_img, S, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
             continue;
         }
         // ---- stage the tile
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
         // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
         const int w_next = resolve(raw_next);
-        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, grp, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
+        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, S, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
         FR_T(t2);
         FR_ACC(1, t1, t2);
 
@@ -690,6 +711,7 @@ HsFastKnobs hs_fast_read_knobs()
     if (const char* e = getenv("HS_FAST_WG_PER_CU")) k.wg_per_cu = atoi(e);               // tuning: workgroups per CU
     if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) k.force_scan_b = atoi(e) != 0;     // parity tests: NMS from the score tile
     if (const char* e = getenv("HS_FAST_IMAGE_MAJOR")) k.image_major = atoi(e) != 0;      // tuning / parity tests: the work units image-major whatever the batch
+    if (const char* e = getenv("HS_FAST_NQ")) k.nq = atoi(e);                             // tuning / parity tests: at most this many work queues (8, 16, 32)
     return k;
 }
 
@@ -732,9 +754,27 @@ static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs)
 // workgroups of a launch over `total_work` items (non-decreasing in total_work)
 static int fast_rows_grid(const FastRowsCfg& c, int total_work)
 {
-    int nblk = 256 * c.per_cu;
-    while (nblk >= 16 && (nblk / 2) % 8 == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups; stays a multiple of 8 (XCD ranges)
+    int nblk = (256 * c.per_cu) & ~(HS_FAST_NQ_MAX - 1);         // a multiple of every queue count
+    while (nblk >= 2 * HS_FAST_NQ_MAX && (nblk / 2) % HS_FAST_NQ_MAX == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups
     return nblk;
+}
+// queue count and unit order of a launch over `batch` images (see FastSched)
+static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& knobs)
+{
+    FastSched S{};
+    int nq_log = 3;
+    const int want = knobs.nq > 0 ? knobs.nq : HS_FAST_NQ_MAX;
+    while ((2 << nq_log) <= want) nq_log++;
+    const int nq = 1 << nq_log;
+    S.nq_log = nq_log;
+    if (!knobs.image_major && batch >= nq && batch % nq == 0) { S.mode = 1; S.par = batch / nq; S.per_q = S.par * items_per_img; }
+    else if (!knobs.image_major && batch > 0 && nq % batch == 0) {
+        S.mode = 2; S.par = nq / batch;
+        while ((1 << S.par_log) < S.par) S.par_log++;
+        S.per_q = (items_per_img + S.par - 1) / S.par;
+    } else if (!knobs.image_major && batch > 0) { S.mode = 3; S.par = batch; S.per_q = (items_per_img * batch + nq - 1) / nq; }
+    else { S.mode = 0; S.per_q = (items_per_img * batch + nq - 1) / nq; }
+    return S;
 }
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
@@ -754,10 +794,10 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
-    const int grp = (batch >= 8 && batch % 8 == 0 && !knobs.image_major) ? batch / 8 : 0;      // images per work queue walked item-major (row_geom)
+    const FastSched S = fast_sched(batch, items_per_img, knobs);
     const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, grp)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, S)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH

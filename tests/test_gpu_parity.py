@@ -195,7 +195,7 @@ def test_empty_flat_and_noise_frames(gpu):
 @pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_EXTRACT_SPLIT": "1"}, {"HS_EXTRACT_SPLIT": "0"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"},
                                  {"HS_PYRAMID_CHAIN": "2"}, {"HS_PYRAMID_CHAIN": "0"}, {"HS_PYRAMID_NW8": "100000"}, {"HS_PYRAMID_NW8": "0"},
-                                 {"HS_FAST_ORDER": "0"}, {"HS_FAST_ORDER": "2"}, {"HS_FAST_IMAGE_MAJOR": "1"}])
+                                 {"HS_FAST_ORDER": "0"}, {"HS_FAST_ORDER": "2"}, {"HS_FAST_IMAGE_MAJOR": "1"}, {"HS_FAST_NQ": "8"}, {"HS_FAST_NQ": "16"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
     """the FAST kernel's tile-width variants, its list-overflow (flush) paths forced by a tiny LDS list, NMS driven from the score
     tile instead of the corner list, the quadtree's point-domain passes, the pyramid's chain kernel for every fused group / for none and its
