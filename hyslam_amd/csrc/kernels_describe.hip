@@ -101,9 +101,15 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 typedef unsigned short hs_ushort2 __attribute__((ext_vector_type(2)));
+typedef uint32_t hs_u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)      // v_dot2_u32_u16: a.lo*b.lo + a.hi*b.hi + c
 {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(hs_ushort2, a), __builtin_bit_cast(hs_ushort2, b), c, false);
+}
+
+__device__ __forceinline__ uint32_t udot2c(uint32_t a, uint32_t b, uint32_t c)     // the same with the clamp bit: the sum saturates at 0xFFFFFFFF
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(hs_ushort2, a), __builtin_bit_cast(hs_ushort2, b), c, true);
 }
 
 #ifdef HS_DESC_PROFILE      // make EXTRA=-DHS_DESC_PROFILE: cycle stamps per phase and wave (tools/describe_phase_profile.py)
@@ -155,16 +161,29 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     // contiguous eighth of that order, so patches that overlap are fetched into one L2 at about the same time (k_describe used to read
     // 3.9x its compulsory bytes).  Results still go to the keypoint's list-order slot.  Placement only affects speed.
     const int gx = gridDim.x, cls = blockIdx.x & 7, jcls = blockIdx.x >> 3;
-    int before = 0;                                        // blocks in the classes below `cls`
-    for (int c = 0; c < cls; c++) before += (gx - c + 7) >> 3;
+    const int before = cls * (gx >> 3) + min(cls, gx & 7);   // blocks in the classes below `cls`: class c has (gx >> 3) + (c < (gx & 7)) of them
     const int gs = (before + jcls) * KP_PER_BLOCK + wv;    // position in the spatial order (levels concatenated)
 
     // locate the level: prefix over the per-level selection counts (wave-uniform scalar loop)
+    // With 8 levels (the reference's configuration) the counts arrive as ONE 8-dword scalar load and the search is branch-free — level = number of
+    // inclusive prefix sums <= gs — instead of a chain of 8 dependent loads: the header was a quarter of a wave's life.
     int level = -1, first = 0, total = 0;
-    for (int l = 0; l < nlevels; l++) {
-        int c = hs_cload<int32_t>(sel_count + img * nlevels + l);
-        if (level < 0 && gs < total + c) { level = l; first = total; }
-        total += c;
+    if (nlevels == 8) {
+        const hs_u32x8 c8 = hs_cload<hs_u32x8>(sel_count + img * 8);
+        int nle = 0;
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+            total += (int)c8[l];
+            const int m = (total - 1 - gs) >> 31;          // -1 where gs >= total (integer form: a bool here comes back as a lane mask + v_cndmask)
+            nle -= m; first += (int)c8[l] & m;             // the prefix sums rise: the counts of the levels wholly below gs add up to `first`
+        }
+        level = nle < 8 ? nle : -1;
+    } else {
+        for (int l = 0; l < nlevels; l++) {
+            int c = hs_cload<int32_t>(sel_count + img * nlevels + l);
+            if (level < 0 && gs < total + c) { level = l; first = total; }
+            total += c;
+        }
     }
     const int cap = O.cap;
     const bool second = img >= O.split;
@@ -269,30 +288,39 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         DP_ACC(2, dp2, dp3);
         // ---- column pass: lane = (column c, even row r): dwords (r,r+1)..(r+6,r+7) of HT[c]; even rows use taps (t0,t1)(t2,t3)(t4,t5)(t6,0),
         //      the odd row r+1 uses (0,t0)(t1,t2)(t3,t4)(t5,t6) on the SAME dwords
-        const uint32_t e0 = tp[0] | (tp[1] << 16), e1 = tp[2] | (tp[3] << 16), e2 = tp[4] | (tp[5] << 16), e3 = tp[6];
-        const uint32_t o0 = tp[0] << 16, o1 = tp[1] | (tp[2] << 16), o2 = tp[3] | (tp[4] << 16), o3 = tp[5] | (tp[6] << 16);
+        //      The taps enter multiplied by 256 (a byte-sized tap * 256 fits 16 bits) and every v_dot2 CLAMPS: the sum is then 256 * (sum + 0x8000),
+        //      which leaves the 32-bit range exactly when the blurred value would leave the byte range, so byte 3 of the clamped sum is the
+        //      saturated result (0xFFFFFFFF -> 255) and the eight v_min of the unscaled form are gone
+        const uint32_t e0 = (tp[0] | (tp[1] << 16)) << 8, e1 = (tp[2] | (tp[3] << 16)) << 8, e2 = (tp[4] | (tp[5] << 16)) << 8, e3 = tp[6] << 8;
+        const uint32_t o0 = tp[0] << 24, o1 = (tp[1] | (tp[2] << 16)) << 8, o2 = (tp[3] | (tp[4] << 16)) << 8, o3 = (tp[5] | (tp[6] << 16)) << 8;
         // a lane makes 8 vertically adjacent outputs (rows r..r+7, r = 8*rg) from the seven dwords H[r..r+13] of its column: 185 (column,
         // group) tasks in three rounds
-        for (int i = lane; i < BL_N * 5; i += 64) {
-            const int c = i / 5, rg = i - c * 5;
-            const int r = 8 * rg;
-            const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
-            uint32_t a[7];                                     // rows >= 43 (last group): pad / next column, only the discarded outputs see them
+        // lane -> (column c, row group rg) of task i = lane + 64 k: 64 = 12 * 5 + 4, so a step adds (12, 4) with one carry — no division per round
+        int c = lane / 5, rg = lane - c * 5;
 #pragma unroll
-            for (int k = 0; k < 7; k++) a[k] = col[k];
-            // (sum + 0x8000) >> 16 saturated to 255: the rounding constant starts the accumulator, the saturation is applied before the shift
-            // (min(x, 0xFFFFFF) >> 16 == min(x >> 16, 255)): the result is byte 2 of w.  The blurred tile is COLUMN-major (BL(row, col) =
-            // bl[col * BL_P + row]), so the lane's eight results are eight consecutive bytes: one 8-byte store instead of eight byte stores
-            uint32_t w[8];
+        for (int k = 0; k < (BL_N * 5 + 63) / 64; k++) {
+            if (64 * k + 63 < BL_N * 5 || lane + 64 * k < BL_N * 5) {
+                const int r = 8 * rg;
+                const uint32_t* col = reinterpret_cast<const uint32_t*>(&hb[c * HT_P + r]);
+                uint32_t a[7];                                     // rows >= 43 (last group): pad / next column, only the discarded outputs see them
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                w[2 * m] = min(udot2(a[m + 3], e3, udot2(a[m + 2], e2, udot2(a[m + 1], e1, udot2(a[m], e0, 0x8000u)))), 0xFFFFFFu);
-                w[2 * m + 1] = min(udot2(a[m + 3], o3, udot2(a[m + 2], o2, udot2(a[m + 1], o1, udot2(a[m], o0, 0x8000u)))), 0xFFFFFFu);
+                for (int m = 0; m < 7; m++) a[m] = col[m];
+                // (sum + 0x8000) >> 16 saturated to 255 = byte 3 of the clamped 256-fold sum; the rounding constant starts the accumulator.  The
+                // blurred tile is COLUMN-major (BL(row, col) = bl[col * BL_P + row]), so the lane's eight results are eight consecutive bytes: one
+                // 8-byte store instead of eight byte stores
+                uint32_t w[8];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    w[2 * m] = udot2c(a[m + 3], e3, udot2c(a[m + 2], e2, udot2c(a[m + 1], e1, udot2c(a[m], e0, 0x800000u))));
+                    w[2 * m + 1] = udot2c(a[m + 3], o3, udot2c(a[m + 2], o2, udot2c(a[m + 1], o1, udot2c(a[m], o0, 0x800000u))));
+                }
+                // v_perm_b32: byte 3 of each of four values -> one dword (selector bytes: 0-3 = second operand, 4-7 = first, 0x0c = zero)
+                const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0703u) | __builtin_amdgcn_perm(w[3], w[2], 0x07030c0cu);
+                const uint32_t hi = __builtin_amdgcn_perm(w[5], w[4], 0x0c0c0703u) | __builtin_amdgcn_perm(w[7], w[6], 0x07030c0cu);
+                *reinterpret_cast<uint2*>(&bl[c * BL_P + r]) = make_uint2(lo, hi);      // rows 37..39 of the last group: the column's unused tail
             }
-            // v_perm_b32: byte 2 of each of four values -> one dword (selector bytes: 0-3 = second operand, 4-7 = first, 0x0c = zero)
-            const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0602u) | __builtin_amdgcn_perm(w[3], w[2], 0x06020c0cu);
-            const uint32_t hi = __builtin_amdgcn_perm(w[5], w[4], 0x0c0c0602u) | __builtin_amdgcn_perm(w[7], w[6], 0x06020c0cu);
-            *reinterpret_cast<uint2*>(&bl[c * BL_P + r]) = make_uint2(lo, hi);      // rows 37..39 of the last group: the column's unused tail
+            c += 12; rg += 4;
+            if (rg >= 5) { rg -= 5; c++; }
         }
     } else {
         // ---- generic taps: horizontal pass with ufixedpoint16 saturating sums

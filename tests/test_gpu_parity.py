@@ -192,6 +192,23 @@ def test_empty_flat_and_noise_frames(gpu):
     assert_same_features(gk, gd, ok, od)
 
 
+def test_blur_saturation_white_blocks(gpu):
+    """the default 7-tap kernel sums to 257/256: over an all-white (254, 255) neighbourhood the blurred value leaves the byte range and must
+    saturate to 255, never wrap (the column pass relies on the clamp bit of v_dot2 for that); also a custom kernel of byte taps summing to 257
+    with a heavy centre, and a 9-level configuration (the generic level search of k_describe's header)"""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 40, (480, 640)).astype(np.int32)
+    for _ in range(120):
+        x, y, bw, bh = int(rng.integers(0, 600)), int(rng.integers(0, 440)), int(rng.integers(8, 40)), int(rng.integers(8, 40))
+        img[y:y + bh, x:x + bw] = int(rng.choice([253, 254, 255, 255]))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    for nlev in (8, 9):
+        ok, od = oracle.extract(oracle.default_params(800, 1.2, nlev), img)
+        gk, gd = HS.ORBExtractor(settings(800, 1.2, nlev))(img)
+        assert len(ok) > 200
+        assert_same_features(gk, gd, ok, od)
+
+
 @pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_EXTRACT_SPLIT": "1"}, {"HS_EXTRACT_SPLIT": "0"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"},
                                  {"HS_PYRAMID_CHAIN": "2"}, {"HS_PYRAMID_CHAIN": "0"}, {"HS_PYRAMID_NW8": "100000"}, {"HS_PYRAMID_NW8": "0"},
