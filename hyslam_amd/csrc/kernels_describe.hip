@@ -30,13 +30,14 @@
 #include "lean_sincos.h"
 #include "../../include/hyslam_orb_pattern.h"
 
-// the 256 test pairs (x0, y0, x1, y1) as floats, 16 bytes per test: one 16-byte load per lane and round, no byte extraction / conversion
+// the 256 test pairs as floats, 16 bytes per test: one 16-byte load per lane and round, no byte extraction / conversion
 struct alignas(16) PatternF { float v[HS_ORB_PATTERN_INTS]; };
 static constexpr PatternF make_pattern_f()
 {
     constexpr int8_t src[HS_ORB_PATTERN_INTS] = HS_ORB_PATTERN_INIT;
     PatternF t{};
-    for (int i = 0; i < HS_ORB_PATTERN_INTS; i++) t.v[i] = (float)src[i];
+    // stored as (x0, x1, y0, y1): the two points' x and y are then register PAIRS as loaded, ready for v_pk_mul_f32 (no v_mov shuffles per round)
+    for (int i = 0; i < HS_ORB_PATTERN_INTS; i += 4) { t.v[i] = (float)src[i]; t.v[i + 1] = (float)src[i + 2]; t.v[i + 2] = (float)src[i + 1]; t.v[i + 3] = (float)src[i + 3]; }
     return t;
 }
 __constant__ PatternF c_pattern = make_pattern_f();
@@ -388,12 +389,13 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     hs_lean_sincos((double)theta, &sin_t, &cos_t);              // equal to libm's after the rounding to float for every float theta (lean_sincos.h)
     const float a = (float)cos_t, b = (float)sin_t;
     uint8_t* dout = desc + ((size_t)oimg * cap + g) * HS_DESC_BYTES;
+    unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int t = 64 * r + lane;
         const float4 pt = *reinterpret_cast<const float4*>(&c_pattern.v[4 * t]);
         typedef float hs_f2 __attribute__((ext_vector_type(2)));   // both points of the test at once: v_pk_mul_f32 / v_pk_add_f32 (IEEE per component)
-        const hs_f2 pxv = {pt.x, pt.z}, pyv = {pt.y, pt.w};
+        const hs_f2 pxv = {pt.x, pt.y}, pyv = {pt.z, pt.w};      // table order (x0, x1, y0, y1)
         // cvRound = round half to even: x + 1.5 * 2^23 has the rounded integer in its low mantissa bits (|x| < 27); the tile offset
         // (18 + dx) * BL_P + 18 + dy (column-major tile) comes out of one 24-bit multiply-add on those bits
         const float M = 12582912.0f;
@@ -402,10 +404,12 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
         const uint32_t fy0 = __float_as_uint(fyv.x), fy1 = __float_as_uint(fyv.y), fx0 = __float_as_uint(fxv.x), fx1 = __float_as_uint(fxv.y);
         int t0 = bl[__umul24(fx0, BL_P) + fy0 - K];         // column-major tile; the multiply takes fx's low 24 bits (0x400000 + dx), fy enters whole
         int t1 = bl[__umul24(fx1, BL_P) + fy1 - K];
-        unsigned long long m = __ballot(t0 < t1);
-        if (lane == 0) *reinterpret_cast<unsigned long long*>(dout + 8 * r) = m;
+        bits[r] = __ballot(t0 < t1);
     }
-    if (lane == 0) {
+    if (lane == 0) {                                            // the four ballots (wave-uniform) leave with the keypoint record: one predicated block
+        typedef unsigned long long hs_u64x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<hs_u64x2*>(dout) = hs_u64x2{bits[0], bits[1]};
+        *reinterpret_cast<hs_u64x2*>(dout + 16) = hs_u64x2{bits[2], bits[3]};
         hs_keypoint k;
         // keypoint->pt *= scale for level != 0 (ORBExtractor.cpp:546-552)
         k.x = level ? __fmul_rn((float)cx, L.scale) : (float)cx;
