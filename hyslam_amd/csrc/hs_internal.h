@@ -136,15 +136,15 @@ struct HsOut {                     // extractor outputs, split the same way
 struct HsXTab { int16_t sx, a0, a1, pad; };                       // x table of cv::resize: first source column and the two 11-bit weights
 struct HsPyrXTile { int32_t ax0, own_x1, col0, nvec, _r[4]; };    // first column / end of the owned columns of the level-A region; first source column (16-aligned), 16-byte vectors per source row
 struct HsPyrYTile { int32_t ay0, own_y1, ay_last, sy_first, n_sr, _r[3]; };   // level-A rows [ay0, ay_last], owned up to own_y1; source rows from sy_first, n_sr of them
-struct HsPyrRow { int16_t r0, r1; uint16_t b0, b1; };            // destination row: its two source rows (clamped, absolute) and vertical weights
+struct HsPyrRow { uint16_t off0, off1, b0, b1; };                 // a destination row OF ONE TILE: byte offsets of its two source rows in the tile's sums buffer ((row - first row held) * 512) and the vertical weights
 static_assert(sizeof(HsPyrXTile) == 32 && sizeof(HsPyrYTile) == 32 && sizeof(HsPyrRow) == 8, "scalar-load records");
 struct HsPyrFuse {
     const uint8_t* sbase;          // source level S = A - 1 (nullptr: level 0 = the caller's frames, HsImg0)
     uint64_t s_img_stride; int32_t spitch; int32_t _r0;
-    uint8_t* abase; uint64_t a_img_stride; int32_t apitch, aw, ah, _r1;
+    uint8_t* abase; uint64_t a_img_stride; int32_t apitch, aw, ah, slotA;   // slotA: records per y tile in rowA
     uint8_t* bbase; uint64_t b_img_stride; int32_t bpitch, bw, bh, _r2;
     const HsXTab* xtA; const HsXTab* xtB;
-    const HsPyrRow* rowA; const HsPyrRow* rowB;                    // [A.h], [B.h]
+    const HsPyrRow* rowA; const HsPyrRow* rowB;                    // per y tile: [grid.y][slotA] rows ay0.. of the tile's level-A region, [grid.y][FZ_ROWS + 8] rows of its level-B tile (padded with copies of the last row)
     const HsPyrXTile* xt; const HsPyrYTile* yt;                    // [grid.x], [grid.y]
     int32_t tbx, sr, lds_pitch, valid;                             // tile width of level B, LDS rows / pitch of the source rectangle; valid = this pair is fused
 };
@@ -156,8 +156,8 @@ struct HsPyrStageX { int32_t x0, own_x1, ncols, src_x0, nvec, _r[3]; };      // 
 struct HsPyrStageY { int32_t y0, own_y1, y_last, src_y0, n_src, _r[3]; };    // region rows [y0, y_last], owned up to own_y1; first row / number of rows the source buffer holds
 static_assert(sizeof(HsPyrStageX) == 32 && sizeof(HsPyrStageY) == 32, "scalar-load records");
 struct HsPyrStage {
-    uint8_t* base; uint64_t img_stride; int32_t pitch, w, h, _r;              // the level the stage produces
-    const HsXTab* xt; const HsPyrRow* rows;                                    // its x table and row records
+    uint8_t* base; uint64_t img_stride; int32_t pitch, w, h, slot;           // the level the stage produces; slot = row records per y tile
+    const HsXTab* xt; const HsPyrRow* rows;                                    // its x table and row records [grid.y][slot]: rows y0.. of the tile's region (padded with copies of the last row)
     const HsPyrStageX* tx; const HsPyrStageY* ty;                              // [grid.x], [grid.y]
 };
 struct HsPyrChain {

@@ -288,10 +288,12 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
             *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(whi, wlo, c.sel[0], c.sel[1], c.coef[0], c.coef[1]), pyr_hpair(whi, wlo, c.sel[2], c.sel[3], c.coef[2], c.coef[3]));
         }
     };
-    auto v_combine = [&](int r0, int r1, uint32_t b0, uint32_t b1) -> uint32_t {
-        const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[r0 * 256 + 4 * tx]);
-        const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[r1 * 256 + 4 * tx]);
-        return pyr_vquad(H0, H1, b0, b1);
+    // a destination row = one 8-byte record of the TILE's row table (scalar load): byte offsets of its two source rows in the sums buffer + weights
+    const uint8_t* const h_lane = reinterpret_cast<const uint8_t*>(s_h) + 8 * tx;
+    auto v_combine = [&](const HsPyrRow& rec) -> uint32_t {
+        const uint2 H0 = *reinterpret_cast<const uint2*>(h_lane + rec.off0);
+        const uint2 H1 = *reinterpret_cast<const uint2*>(h_lane + rec.off1);
+        return pyr_vquad(H0, H1, rec.b0, rec.b1);
     };
     const ColData cA = col_data(F.xtA, ax0 + 4 * tx, F.aw - 1, X.col0);
     __syncthreads();
@@ -303,14 +305,22 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
         uint8_t* const aimg = F.abase + (size_t)img * F.a_img_stride;
         const uint32_t acol = (uint32_t)(ax0 + 4 * tx);
         const bool own_col = (int)acol < X.own_x1;
-        // the row records are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic
-        HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay0 + wave, Y.ay_last)]));
-        for (int ay = ay0 + wave; ay <= Y.ay_last; ay += NW) {
+        // the row records are scalar loads: fetched ONE ROW AHEAD, so that their latency hides behind the current row's arithmetic; the table is
+        // per tile and padded, so the walk is `pointer += NW` with no clamp, and the store base advances by NW rows (no 64-bit multiply per row)
+        const HsPyrRow* recp = F.rowA + ((size_t)blockIdx.y * (uint32_t)F.slotA + (uint32_t)wave);
+        HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
+        uint8_t* rowp = aimg + (size_t)(ay0 + wave) * (uint32_t)F.apitch;
+        const uint32_t rstep = (uint32_t)NW * (uint32_t)F.apitch;
+        uint32_t* arow = reinterpret_cast<uint32_t*>(&s_a[wave * FZ_APITCH + 4 * tx]);
+        const int own_k1 = Y.own_y1 - ay0;
+        for (int k = wave; k < nAr; k += NW) {
             const HsPyrRow rec = nxt;
-            nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowA[min(ay + NW, Y.ay_last)]));
-            const uint32_t px = v_combine(rec.r0 - Y.sy_first, rec.r1 - Y.sy_first, rec.b0, rec.b1);
-            *reinterpret_cast<uint32_t*>(&s_a[(ay - ay0) * FZ_APITCH + 4 * tx]) = px;
-            if (own_col && ay < Y.own_y1) hs_gstore_off<uint32_t>(aimg + (size_t)ay * (uint32_t)F.apitch, acol, px);
+            recp += NW;
+            nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
+            const uint32_t px = v_combine(rec);
+            *arow = px;
+            if (own_col && k < own_k1) hs_gstore_off<uint32_t>(rowp, acol, px);
+            arow += NW * (FZ_APITCH / 4); rowp += rstep;
         }
     }
     const ColData cB = col_data(F.xtB, bx0 + 4 * tx, F.bw - 1, ax0);
@@ -321,14 +331,18 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
     // ---- 5: the level-B tile
     if (4 * tx < TBX && bx0 + 4 * tx < F.bw) {
         uint8_t* const bimg = F.bbase + (size_t)img * F.b_img_stride;
-        HsPyrRow rec4[FZ_ROWS / NW];                                    // the four rows' records (scalar loads) before the first use
+        const HsPyrRow* recp = F.rowB + ((size_t)blockIdx.y * (FZ_ROWS + 8) + (uint32_t)wave);
+        HsPyrRow rec4[FZ_ROWS / NW];                                    // the rows' records (scalar loads at constant offsets) before the first use
 #pragma unroll
-        for (int rr = 0; rr < FZ_ROWS / NW; rr++) rec4[rr] = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&F.rowB[min(by0 + wave + NW * rr, F.bh - 1)]));
+        for (int rr = 0; rr < FZ_ROWS / NW; rr++) rec4[rr] = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp + NW * rr));
+        uint8_t* rowp = bimg + (size_t)(by0 + wave) * (uint32_t)F.bpitch;
+        const uint32_t rstep = (uint32_t)NW * (uint32_t)F.bpitch;
 #pragma unroll
         for (int rr = 0; rr < FZ_ROWS / NW; rr++) {
             const int by = by0 + wave + NW * rr;
             if (by >= F.bh) break;
-            hs_gstore_off<uint32_t>(bimg + (size_t)by * (uint32_t)F.bpitch, (uint32_t)(bx0 + 4 * tx), v_combine(rec4[rr].r0 - ay0, rec4[rr].r1 - ay0, rec4[rr].b0, rec4[rr].b1));
+            hs_gstore_off<uint32_t>(rowp, (uint32_t)(bx0 + 4 * tx), v_combine(rec4[rr]));
+            rowp += rstep;
         }
     }
 }
@@ -398,17 +412,24 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
             const uint32_t col = (uint32_t)(X.x0 + 4 * tx);
             const bool lane_on = 4 * tx < X.ncols, own_col = (int)col < X.own_x1;
             const bool keep = st + 1 < F.nstage;                     // uniform: a later stage reads the region from LDS
-            HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&S.rows[min(Y.y0 + wave, Y.y_last)]));
+            const HsPyrRow* recp = S.rows + ((size_t)blockIdx.y * (uint32_t)S.slot + (uint32_t)wave);      // the tile's padded row table: `pointer += NW`, no clamp
+            HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
+            const uint8_t* const h_lane = reinterpret_cast<const uint8_t*>(s_h) + 8 * tx;
+            uint8_t* rowp = dimg + (size_t)(Y.y0 + wave) * (uint32_t)S.pitch;
+            const uint32_t rstep = (uint32_t)NW * (uint32_t)S.pitch;
+            uint32_t* xrow = reinterpret_cast<uint32_t*>(&s_x[wave * FZ_APITCH + 4 * tx]);
             for (int y = Y.y0 + wave; y <= Y.y_last; y += NW) {
                 const HsPyrRow rec = nxt;
-                nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(&S.rows[min(y + NW, Y.y_last)]));
+                recp += NW;
+                nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
                 if (lane_on) {
-                    const uint2 H0 = *reinterpret_cast<const uint2*>(&s_h[(rec.r0 - Y.src_y0) * 256 + 4 * tx]);
-                    const uint2 H1 = *reinterpret_cast<const uint2*>(&s_h[(rec.r1 - Y.src_y0) * 256 + 4 * tx]);
+                    const uint2 H0 = *reinterpret_cast<const uint2*>(h_lane + rec.off0);
+                    const uint2 H1 = *reinterpret_cast<const uint2*>(h_lane + rec.off1);
                     const uint32_t px = pyr_vquad(H0, H1, rec.b0, rec.b1);
-                    if (keep) *reinterpret_cast<uint32_t*>(&s_x[(y - Y.y0) * FZ_APITCH + 4 * tx]) = px;
-                    if (own_col && y < Y.own_y1) hs_gstore_off<uint32_t>(dimg + (size_t)y * (uint32_t)S.pitch, col, px);
+                    if (keep) *xrow = px;
+                    if (own_col && y < Y.own_y1) hs_gstore_off<uint32_t>(rowp, col, px);
                 }
+                xrow += NW * (FZ_APITCH / 4); rowp += rstep;
             }
         }
         src_pitch = FZ_APITCH;
@@ -532,15 +553,25 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
             HsPyrStage& S = C.st[i];
             S.base = D.base; S.img_stride = D.img_stride; S.pitch = D.pitch; S.w = D.w; S.h = D.h;
             S.xt = reinterpret_cast<const HsXTab*>(D.xofs);
-            const size_t orow = blob.size(); blob.resize(orow + (size_t)D.h + 8);
+            // row records per y tile: rows y0 .. y_last of the tile's region, offsets relative to the first row the tile's source buffer holds;
+            // every slot is padded with copies of its last row (the kernel prefetches one step of <= 8 rows past the end)
+            int slot = 0;
+            for (int by = 0; by < nby; by++) slot = std::max(slot, ty[i][by].y_last - ty[i][by].y0 + 1);
+            slot += 8;
+            const size_t orow = blob.size(); blob.resize(orow + (size_t)slot * nby);
             const int sh = h_lv[first + i - 1].h;
-            for (int dy = 0; dy < D.h; dy++) {
-                HsPyrRow r;
-                r.r0 = (int16_t)clampi(yofs[first + i][dy], 0, sh - 1); r.r1 = (int16_t)clampi(yofs[first + i][dy] + 1, 0, sh - 1);
-                r.b0 = (uint16_t)ibeta[first + i][2 * dy]; r.b1 = (uint16_t)ibeta[first + i][2 * dy + 1];
-                memcpy(&blob[orow + dy], &r, 8);
+            for (int by = 0; by < nby; by++) {
+                const HsPyrStageY& t = ty[i][by];
+                for (int k = 0; k < slot; k++) {
+                    const int dy = std::min(t.y0 + k, t.y_last);
+                    HsPyrRow r;
+                    r.off0 = (uint16_t)((clampi(yofs[first + i][dy], 0, sh - 1) - t.src_y0) * 512);
+                    r.off1 = (uint16_t)((clampi(yofs[first + i][dy] + 1, 0, sh - 1) - t.src_y0) * 512);
+                    r.b0 = (uint16_t)ibeta[first + i][2 * dy]; r.b1 = (uint16_t)ibeta[first + i][2 * dy + 1];
+                    memcpy(&blob[orow + (size_t)by * slot + k], &r, 8);
+                }
             }
-            S.rows = reinterpret_cast<const HsPyrRow*>(orow * 8);
+            S.rows = reinterpret_cast<const HsPyrRow*>(orow * 8); S.slot = slot;
             const size_t ox = blob.size(); blob.resize(ox + 4 * (size_t)nbx);
             memcpy(&blob[ox], txs[i].data(), 32 * (size_t)nbx);
             const size_t oy = blob.size(); blob.resize(oy + 4 * (size_t)nby);
@@ -559,20 +590,6 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
 {
     fuse.assign(nlevels, HsPyrFuse{});
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    std::vector<size_t> row_off(nlevels, 0);
-    auto rows_of = [&](int l) {                                  // row records of level l (source = level l-1), built once
-        if (row_off[l]) return row_off[l];
-        const int sh = h_lv[l - 1].h;
-        const size_t o = blob.size();
-        blob.resize(o + (size_t)h_lv[l].h);
-        for (int dy = 0; dy < h_lv[l].h; dy++) {
-            HsPyrRow r;
-            r.r0 = (int16_t)clampi(yofs[l][dy], 0, sh - 1); r.r1 = (int16_t)clampi(yofs[l][dy] + 1, 0, sh - 1);
-            r.b0 = (uint16_t)ibeta[l][2 * dy]; r.b1 = (uint16_t)ibeta[l][2 * dy + 1];
-            memcpy(&blob[o + dy], &r, 8);
-        }
-        return row_off[l] = o;                                   // o > 0: the blob starts with a pad word
-    };
     if (blob.empty()) blob.push_back(0);
     for (int l = 1; l + 1 < nlevels; l++) {
         const HsLevel& A = h_lv[l];
@@ -585,7 +602,6 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
         F.abase = A.base; F.a_img_stride = A.img_stride; F.apitch = A.pitch; F.aw = A.w; F.ah = A.h;
         F.bbase = B.base; F.b_img_stride = B.img_stride; F.bpitch = B.pitch; F.bw = B.w; F.bh = B.h;
         F.xtA = reinterpret_cast<const HsXTab*>(A.xofs); F.xtB = reinterpret_cast<const HsXTab*>(B.xofs);
-        F.rowA = reinterpret_cast<const HsPyrRow*>(rows_of(l) * 8); F.rowB = reinterpret_cast<const HsPyrRow*>(rows_of(l + 1) * 8);
         F.tbx = tbx; F.sr = A.fuse_sr; F.lds_pitch = A.fuse_pitch; F.valid = 1;
         const size_t ox = blob.size(); blob.resize(ox + 4 * (size_t)nbx);
         for (int bx = 0; bx < nbx; bx++) {
@@ -611,6 +627,30 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
             memcpy(&blob[oy + 4 * (size_t)by], &t, 32);
         }
         F.xt = reinterpret_cast<const HsPyrXTile*>(ox * 8); F.yt = reinterpret_cast<const HsPyrYTile*>(oy * 8);
+        // row records per y tile (offsets relative to the first row the tile's sums buffer holds), padded with copies of the tile's last row: the
+        // kernel prefetches one step of <= 8 rows past the end
+        const int slotA = A.fuse_ar + 8, slotB = FZ_ROWS + 8;
+        const size_t oa = blob.size(); blob.resize(oa + (size_t)slotA * nby);
+        const size_t ob = blob.size(); blob.resize(ob + (size_t)slotB * nby);
+        for (int by = 0; by < nby; by++) {
+            HsPyrYTile t; memcpy(&t, &blob[oy + 4 * (size_t)by], 32);
+            const int by0 = by * FZ_ROWS;
+            for (int k = 0; k < slotA; k++) {
+                const int ay = std::min(t.ay0 + k, t.ay_last);
+                HsPyrRow r;
+                r.off0 = (uint16_t)((clampi(yA[ay], 0, S.h - 1) - t.sy_first) * 512); r.off1 = (uint16_t)((clampi(yA[ay] + 1, 0, S.h - 1) - t.sy_first) * 512);
+                r.b0 = (uint16_t)ibeta[l][2 * ay]; r.b1 = (uint16_t)ibeta[l][2 * ay + 1];
+                memcpy(&blob[oa + (size_t)by * slotA + k], &r, 8);
+            }
+            for (int k = 0; k < slotB; k++) {
+                const int y = std::min(by0 + k, B.h - 1);
+                HsPyrRow r;
+                r.off0 = (uint16_t)((clampi(yB[y], 0, A.h - 1) - t.ay0) * 512); r.off1 = (uint16_t)((clampi(yB[y] + 1, 0, A.h - 1) - t.ay0) * 512);
+                r.b0 = (uint16_t)ibeta[l + 1][2 * y]; r.b1 = (uint16_t)ibeta[l + 1][2 * y + 1];
+                memcpy(&blob[ob + (size_t)by * slotB + k], &r, 8);
+            }
+        }
+        F.rowA = reinterpret_cast<const HsPyrRow*>(oa * 8); F.rowB = reinterpret_cast<const HsPyrRow*>(ob * 8); F.slotA = slotA;
     }
 }
 

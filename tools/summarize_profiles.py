@@ -136,10 +136,11 @@ with open("profiles/%s_kernel_timeline.txt" % rnd, "w") as o:
     o.write("## default (16 stereo pairs per call)\n"); timeline("kt16", o)
 for name in ("qt_phase_1080p", "qt_phase_4000x3000"):
     try:
+        body = open(os.path.join(src, name + ".txt")).read()      # read FIRST: a missing source (no HS_QT_PROFILE build on the box) must not truncate the committed file
         open("profiles/%s_%s.txt" % (rnd, name), "w").write(
             "# tools/quadtree_phase_profile.py: shader-clock stamps of the level-0 quadtree workgroup of image 0 (HS_QT_PROFILE build); tags: 20 set-up, 22 item scan, 23/25 record run\n"
             "# (search / fetch+key+histogram), 1 gather done, 30 pyramid, 31 closed form, 5 list built, 110 order, 11 child counts, 12 cut+children, 13 survivors, 14 relabel (point domain),\n"
-            "# 3 geometric keys -> nodes, 40 best point per node, 41 emitted, 4 tile order\n" + open(os.path.join(src, name + ".txt")).read())
+            "# 3 geometric keys -> nodes, 40 best point per node, 41 emitted, 4 tile order\n" + body)
     except OSError:
         pass
 b = summary["bench"]
