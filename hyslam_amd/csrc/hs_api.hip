@@ -57,7 +57,7 @@ struct hs_orb {
     uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
-    int32_t* d_strip_count = nullptr; uint16_t* d_strip_list = nullptr; size_t strip_count_entries = 0, strip_list_entries = 0;
+    int32_t* d_strip_count = nullptr; void* d_strip_list = nullptr; size_t strip_count_entries = 0, strip_list_entries = 0;
     // persistent staging of hs_stereo_match (host-pointer call): device keypoints / descriptors / counts and one pinned host block
     hs_keypoint* d_sm_kps = nullptr; uint8_t* d_sm_desc = nullptr; int32_t* d_sm_n = nullptr; int sm_cap = 0;
     uint8_t* h_pin = nullptr; size_t pin_bytes = 0;
@@ -368,7 +368,7 @@ int ensure_stereo_strips(hs_orb* h, int pairs, int cap, int n_rows)
     }
     if (need_list > h->strip_list_entries) {
         hipFree(h->d_strip_list); h->d_strip_list = nullptr; h->strip_list_entries = 0;
-        HIP_TRY(h, hipMalloc(&h->d_strip_list, need_list * 2));
+        HIP_TRY(h, hipMalloc(&h->d_strip_list, need_list * HS_STRIP_ENTRY_BYTES));
         h->strip_list_entries = need_list;
     }
     return HS_OK;

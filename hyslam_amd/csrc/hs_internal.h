@@ -205,7 +205,8 @@ void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
                       int32_t* best_dist /*[pairs][cap] scratch*/,
-                      int32_t* strip_count /*[pairs][strips]*/, uint16_t* strip_list /*[pairs][strips][cap]*/, hipStream_t s);
+                      int32_t* strip_count /*[pairs][strips]*/, void* strip_list /*[pairs][strips][cap] entries of HS_STRIP_ENTRY_BYTES*/, hipStream_t s);
+#define HS_STRIP_ENTRY_BYTES 16
 inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
 void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist,
                              int32_t* strip_count /*zero on entry of hs_launch_stereo; zeroed again here*/, int n_rows, hipStream_t s);

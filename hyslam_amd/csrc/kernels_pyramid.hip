@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
 // record (HsPyrRow: clamped source rows + weights, fetched one row ahead) and stores use a scalar row base + a 32-bit lane offset.
 typedef uint32_t hs_u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t hs_u32x2 __attribute__((ext_vector_type(2)));
+#ifndef FZ_ROWS
 #define FZ_ROWS 16
+#endif
 #define FZ_APITCH 272             // LDS pitch of the level-A region: 256 columns + the 3-dword window over-read of the last lane
 template <typename T> __device__ __forceinline__ void hs_gstore_off(uint8_t* uniform_base, uint32_t lane_off, T v)
 {

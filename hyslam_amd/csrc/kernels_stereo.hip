@@ -24,9 +24,14 @@
 // record is loaded up front, and the counters are written out whole, so nothing has to be zeroed between calls.
 #define STRIPS_T 1024
 #define STRIPS_MAX 2048            // 65536 rows / 32
+// A strip entry carries everything the candidate test needs, so that the matcher's chain of dependent loads is entry -> descriptor instead of
+// index -> keypoint record -> descriptor: the right keypoint's u, its octave, its index and its row band CUT TO THE STRIP (two 5-bit row numbers:
+// a left keypoint that scans strip s has its row in [32 s, 32 s + 31], so the cut band decides exactly what the whole band decides).
+struct __attribute__((aligned(16))) HsStripEntry { float uR; int32_t octave; uint32_t idx_band; uint32_t _pad; };   // idx_band = iR | lo << 16 | hi << 24
+static_assert(sizeof(HsStripEntry) == HS_STRIP_ENTRY_BYTES, "hs_api.hip sizes the strip lists with HS_STRIP_ENTRY_BYTES");
 __global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* __restrict__ kpsR, const int32_t* __restrict__ nRs, int cap,
                                                             float size_ref, int n_rows, int n_strips,
-                                                            int32_t* __restrict__ strip_count, uint16_t* __restrict__ strip_list)
+                                                            int32_t* __restrict__ strip_count, HsStripEntry* __restrict__ strip_list)
 {
     __shared__ int s_cnt[STRIPS_MAX];
     const int pair = blockIdx.x, tid = threadIdx.x;
@@ -35,12 +40,12 @@ __global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* _
     constexpr int KPT = 4;                                    // keypoints per thread whose records are in flight together
     __syncthreads();
     for (int i0 = 0; i0 < nR; i0 += STRIPS_T * KPT) {
-        float ky[KPT], ks[KPT];
+        float kx[KPT], ky[KPT], ks[KPT]; int ko[KPT];
 #pragma unroll
         for (int k = 0; k < KPT; k++) {
             const int i = min(i0 + tid + STRIPS_T * k, nR - 1);
             const hs_keypoint* kr = &kpsR[(size_t)pair * cap + i];
-            ky[k] = kr->y; ks[k] = kr->size;
+            kx[k] = kr->x; ky[k] = kr->y; ks[k] = kr->size; ko[k] = kr->octave;
         }
 #pragma unroll
         for (int k = 0; k < KPT; k++) {
@@ -52,7 +57,9 @@ __global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* _
             minr = max(minr, 0); maxr = min(maxr, n_rows - 1);
             for (int s = minr >> STRIP_SHIFT; s <= (maxr >> STRIP_SHIFT); s++) {
                 const int slot = atomicAdd(&s_cnt[s], 1);
-                strip_list[((size_t)pair * n_strips + s) * cap + slot] = (uint16_t)i;
+                const int lo = max(minr - (s << STRIP_SHIFT), 0), hi = min(maxr - (s << STRIP_SHIFT), 31);
+                HsStripEntry e; e.uR = kx[k]; e.octave = ko[k]; e.idx_band = (uint32_t)i | ((uint32_t)lo << 16) | ((uint32_t)hi << 24); e._pad = 0;
+                strip_list[((size_t)pair * n_strips + s) * cap + slot] = e;
             }
         }
     }
@@ -60,7 +67,10 @@ __global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* _
     for (int s = tid; s < n_strips; s += STRIPS_T) strip_count[(size_t)pair * n_strips + s] = s_cnt[s];
 }
 
-__global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict__ strip_count, const uint16_t* __restrict__ strip_list, int n_strips,
+// One wavefront owns TWO left keypoints and walks both strips together (the kernel is a chain of dependent loads — strip entry, then the
+// descriptors of the candidates that pass — and nothing else: twice the loads in flight per wave, half the waves).
+template <int SM_KPW>              // left keypoints per wavefront: 2, or 1 when the launch has too few workgroups to fill the chip anyway (single pairs)
+__global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict__ strip_count, const HsStripEntry* __restrict__ strip_list, int n_strips,
                                                       const hs_keypoint* __restrict__ kpsL, const uint8_t* __restrict__ descL,
                                                       const int32_t* __restrict__ nLs,
                                                       const hs_keypoint* __restrict__ kpsR, const uint8_t* __restrict__ descR,
@@ -68,88 +78,105 @@ __global__ __launch_bounds__(256) void k_stereo_match(const int32_t* __restrict_
                                                       int cap, hs_stereo_params sp,
                                                       float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ best_dist)
 {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the left keypoint's record comes through scalar loads
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: the left keypoints' records come through scalar loads
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 4 + wv;
+    const int iL0 = (blockIdx.x * 4 + wv) * SM_KPW;
     const int nL = min(nLs[pair], cap);
-    if (iL >= cap) return;
+    if (iL0 >= cap) return;
     const size_t o = (size_t)pair * cap;
-    if (iL >= nL) { if (lane == 0) { uRight[o + iL] = -1.0f; depth[o + iL] = -1.0f; best_dist[o + iL] = -1; } return; }
-
-    const hs_keypoint kl = kpsL[o + iL];
-    const float vL = kl.y, uL = kl.x;
-    const int levelL = kl.octave;
     const float mbf = sp.mbf, mb = sp.mbf / sp.fx;
     const float minD = 0.f, maxD = mbf / mb;                 // :66-68
-    const float minU = uL - maxD, maxU = uL - minD;
-    const int rowL = (int)vL;                                // vRowIndices[vL]
-    bool ok = (vL >= 0.f) && rowL < sp.n_rows && !(maxU < 0.f);
-
-    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(descL + (o + iL) * 32);
-    const unsigned long long l0 = dl[0], l1 = dl[1], l2 = dl[2], l3 = dl[3];
-
-    // bestDist starts at TH_HIGH and only strictly smaller distances replace it (:92,114)
-    uint32_t best = 0xFFFFFFFFu;
     const float th_high = sp.th_high;
-    if (ok) {
-        const size_t sb = (size_t)pair * n_strips + (rowL >> STRIP_SHIFT);
-        const int nc = strip_count[sb];
-        const uint16_t* cl = strip_list + sb * cap;
-        // two candidates per lane and round (a strip holds ~100): index -> record -> descriptor is a chain of three dependent loads, and
-        // a plain loop walked it once per 64 candidates; here the chains of both candidates advance together.  Lanes without a candidate
-        // re-read the strip's first entry (a valid index) and are masked at the end.
-        for (int c0 = 0; c0 < nc; c0 += 128) {
-            int iR[2]; hs_keypoint kr[2]; bool in[2];
+
+    float uL[SM_KPW], minU[SM_KPW], maxU[SM_KPW]; int levelL[SM_KPW], rowIn[SM_KPW], nc[SM_KPW];
+    const HsStripEntry* cl[SM_KPW]; const unsigned long long* dl[SM_KPW];
+    bool live[SM_KPW];
+    int ncmax = 0;
 #pragma unroll
-            for (int j = 0; j < 2; j++) { const int c = c0 + 64 * j + lane; in[j] = c < nc; iR[j] = cl[in[j] ? c : 0]; }
+    for (int t = 0; t < SM_KPW; t++) {
+        const int iL = iL0 + t;
+        live[t] = iL < nL;
+        const hs_keypoint kl = kpsL[o + min(iL, max(nL - 1, 0))];
+        const float vL = kl.y;
+        uL[t] = kl.x; levelL[t] = kl.octave;
+        minU[t] = uL[t] - maxD; maxU[t] = uL[t] - minD;
+        const int rowL = (int)vL;                             // vRowIndices[vL]
+        const bool ok = live[t] && (vL >= 0.f) && rowL < sp.n_rows && !(maxU[t] < 0.f);
+        const size_t sb = (size_t)pair * n_strips + (ok ? (rowL >> STRIP_SHIFT) : 0);
+        nc[t] = ok ? strip_count[sb] : 0;
+        cl[t] = strip_list + sb * cap;
+        rowIn[t] = rowL & 31;
+        dl[t] = reinterpret_cast<const unsigned long long*>(descL + (o + min(iL, max(nL - 1, 0))) * 32);
+        ncmax = max(ncmax, nc[t]);
+    }
+    // bestDist starts at TH_HIGH and only strictly smaller distances replace it (:92,114)
+    uint32_t best[SM_KPW];
 #pragma unroll
-            for (int j = 0; j < 2; j++) kr[j] = kpsR[o + iR[j]];
-            bool pass[2];
+    for (int t = 0; t < SM_KPW; t++) best[t] = 0xFFFFFFFFu;
+    // two candidates per lane, keypoint and round (a strip holds ~100).  Lanes without a candidate re-read the strip's first entry and are masked.
+    for (int c0 = 0; c0 < ncmax; c0 += 128) {
+        HsStripEntry e[SM_KPW][2]; bool pass[SM_KPW][2];
+#pragma unroll
+        for (int t = 0; t < SM_KPW; t++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const float r = 2.0f * kr[j].size / sp.size_ref;    // :56
-                const int maxr = (int)ceilf(kr[j].y + r);
-                const int minr = (int)floorf(kr[j].y - r);
-                pass[j] = in[j] && !(rowL < minr || rowL > maxr);
-                pass[j] = pass[j] && !(kr[j].octave < levelL - 1 || kr[j].octave > levelL + 1);
-                const float uR = kr[j].x;
-                pass[j] = pass[j] && (uR >= minU && uR <= maxU);
+                const int c = c0 + 64 * j + lane;
+                pass[t][j] = c < nc[t];
+                e[t][j] = cl[t][pass[t][j] ? c : 0];
             }
-            unsigned long long dr[2][4];                     // descriptors only of the candidates that passed (a fifth of them)
+#pragma unroll
+        for (int t = 0; t < SM_KPW; t++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const unsigned long long* p = reinterpret_cast<const unsigned long long*>(descR + (o + iR[j]) * 32);
-                if (pass[j]) { dr[j][0] = p[0]; dr[j][1] = p[1]; dr[j][2] = p[2]; dr[j][3] = p[3]; }
-                else { dr[j][0] = dr[j][1] = dr[j][2] = dr[j][3] = 0ull; }
+                const int lo = (int)((e[t][j].idx_band >> 16) & 0xFFu), hi = (int)(e[t][j].idx_band >> 24);
+                pass[t][j] = pass[t][j] && !(rowIn[t] < lo || rowIn[t] > hi);
+                pass[t][j] = pass[t][j] && !(e[t][j].octave < levelL[t] - 1 || e[t][j].octave > levelL[t] + 1);
+                pass[t][j] = pass[t][j] && (e[t][j].uR >= minU[t] && e[t][j].uR <= maxU[t]);
+            }
+        unsigned long long dr[SM_KPW][2][4];                  // descriptors only of the candidates that passed (a fifth of them)
+#pragma unroll
+        for (int t = 0; t < SM_KPW; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const unsigned long long* p = reinterpret_cast<const unsigned long long*>(descR + (o + (e[t][j].idx_band & 0xFFFFu)) * 32);
+                if (pass[t][j]) { dr[t][j][0] = p[0]; dr[t][j][1] = p[1]; dr[t][j][2] = p[2]; dr[t][j][3] = p[3]; }
+                else { dr[t][j][0] = dr[t][j][1] = dr[t][j][2] = dr[t][j][3] = 0ull; }
             }
 #pragma unroll
+        for (int t = 0; t < SM_KPW; t++) {
+            const unsigned long long l0 = dl[t][0], l1 = dl[t][1], l2 = dl[t][2], l3 = dl[t][3];      // uniform: scalar loads
+#pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int d = __popcll(l0 ^ dr[j][0]) + __popcll(l1 ^ dr[j][1]) + __popcll(l2 ^ dr[j][2]) + __popcll(l3 ^ dr[j][3]);
-                if (pass[j] && (float)d < th_high) best = min(best, ((uint32_t)d << 16) | (uint32_t)iR[j]);
+                const int d = __popcll(l0 ^ dr[t][j][0]) + __popcll(l1 ^ dr[t][j][1]) + __popcll(l2 ^ dr[t][j][2]) + __popcll(l3 ^ dr[t][j][3]);
+                if (pass[t][j] && (float)d < th_high) best[t] = min(best[t], ((uint32_t)d << 16) | (e[t][j].idx_band & 0xFFFFu));
             }
         }
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
-
-    if (lane == 0) {
-        float ur_out = -1.0f, depth_out = -1.0f; int bd = -1;
-        if (best != 0xFFFFFFFFu) {
-            const float bestDist = (float)(best >> 16);
-            const int bestIdxR = best & 0xFFFF;
-            const float dist_threshold = (sp.th_high + sp.th_low) / 2;          // :41
-            if (bestDist < dist_threshold) {
-                float uR0 = kpsR[o + bestIdxR].x;
-                float disparity = uL - uR0;
-                if (disparity >= minD && disparity < maxD) {
-                    if (disparity <= 0) { disparity = 0.01; uR0 = uL - 0.01; }    // double constants, as in the reference (:130-131)
-                    depth_out = mbf / disparity;
-                    ur_out = uR0;
-                    bd = (int)(best >> 16);
+    for (int t = 0; t < SM_KPW; t++) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) best[t] = min(best[t], (uint32_t)__shfl_xor((int)best[t], s, 64));
+        const int iL = iL0 + t;
+        if (iL >= cap) break;
+        if (lane == 0) {
+            float ur_out = -1.0f, depth_out = -1.0f; int bd = -1;
+            if (live[t] && best[t] != 0xFFFFFFFFu) {
+                const float bestDist = (float)(best[t] >> 16);
+                const int bestIdxR = best[t] & 0xFFFF;
+                const float dist_threshold = (sp.th_high + sp.th_low) / 2;          // :41
+                if (bestDist < dist_threshold) {
+                    float uR0 = kpsR[o + bestIdxR].x;
+                    float disparity = uL[t] - uR0;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) { disparity = 0.01; uR0 = uL[t] - 0.01; }    // double constants, as in the reference (:130-131)
+                        depth_out = mbf / disparity;
+                        ur_out = uR0;
+                        bd = (int)(best[t] >> 16);
+                    }
                 }
             }
+            uRight[o + iL] = ur_out; depth[o + iL] = depth_out; best_dist[o + iL] = bd;
         }
-        uRight[o + iL] = ur_out; depth[o + iL] = depth_out; best_dist[o + iL] = bd;
     }
 }
 
@@ -211,13 +238,19 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int32_t* __restrict
 void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth, int32_t* best_dist,
-                      int32_t* strip_count, uint16_t* strip_list, hipStream_t s)
+                      int32_t* strip_count, void* strip_list, hipStream_t s)
 {
     if (pairs <= 0 || cap <= 0) return;
+    HsStripEntry* const sl = reinterpret_cast<HsStripEntry*>(strip_list);
     const int n_strips = hs_stereo_strips(sp.n_rows);
-    hipLaunchKernelGGL(k_stereo_strips, dim3(pairs), dim3(STRIPS_T), 0, s, kpsR, nR, cap, sp.size_ref, sp.n_rows, n_strips, strip_count, strip_list);
-    dim3 grid((cap + 3) / 4, pairs, 1);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, s, strip_count, strip_list, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    hipLaunchKernelGGL(k_stereo_strips, dim3(pairs), dim3(STRIPS_T), 0, s, kpsR, nR, cap, sp.size_ref, sp.n_rows, n_strips, strip_count, sl);
+    if ((size_t)pairs * cap >= (size_t)8 * 2048) {
+        dim3 grid((cap + 7) / 8, pairs, 1);
+        hipLaunchKernelGGL(k_stereo_match<2>, grid, dim3(256), 0, s, strip_count, sl, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    } else {
+        dim3 grid((cap + 3) / 4, pairs, 1);
+        hipLaunchKernelGGL(k_stereo_match<1>, grid, dim3(256), 0, s, strip_count, sl, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    }
 }
 
 void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist,
