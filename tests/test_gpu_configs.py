@@ -249,7 +249,8 @@ def test_hamming_knn2_device(gpu):
 
 def test_stereo_match_batch_device(gpu):
     """hs_stereo_match_batch_device on three pairs with different counts laid out like the extractor's outputs (stride cap), then a second
-    call with MORE pairs but a smaller cap on the same handle (the strip counters and strip lists grow independently)."""
+    call with MORE pairs but a smaller cap on the same handle (the strip counters and strip lists grow independently), then batches large enough
+    for the two-keypoints-per-wavefront matcher."""
     p = oracle.default_params(1000)
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=1000))
     feats = []
@@ -282,6 +283,44 @@ def test_stereo_match_batch_device(gpu):
     run([2], 1100, 600)                   # 1 pair, large cap, 19 strips
     run([0, 1, 2, 0, 1, 2, 0, 1], 400, 600)   # 8 pairs, small cap: pairs*strips grows while pairs*strips*cap shrinks
     run([0, 1], 1100, 480)
+    # pairs * cap >= 16384: the matcher gives TWO left keypoints to a wavefront (k_stereo_match<2>, the bench's 16-pair path); an odd cap and odd
+    # counts put a wavefront's second keypoint past the end
+    run([0, 1, 2] * 5 + [0], 1100, 600)
+    run([2, 0, 1] * 3, 1999, 600)
+
+
+def test_stereo_front_end_nine_pairs_one_call(gpu):
+    """hs_stereo_frontend_batch_device as the bench drives it — several pairs in ONE call: 9 distinct 640x480 pairs at 2000 features put
+    pairs * cap over the matcher's two-keypoints-per-wavefront threshold; every pair's keypoints, descriptors, uRight and depth vs the oracle"""
+    W, H, P = 640, 480, 9
+    p = oracle.default_params(2000)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000))
+    pairs = [synth_stereo_pair(300 + i, W, H) for i in range(P)]
+    left = np.stack([a for a, _ in pairs]); right = np.stack([b for _, b in pairs])
+    ex.reserve(W, H, 2 * P)
+    cap = ex.max_keypoints()
+    assert P * cap >= 16384
+    dl, dr = hipmem.DevBuf.from_numpy(left), hipmem.DevBuf.from_numpy(right)
+    kb, db = cap * N.KP_DTYPE.itemsize, cap * 32
+    dk = [hipmem.DevBuf(P * kb) for _ in range(2)]; dd = [hipmem.DevBuf(P * db) for _ in range(2)]; dn = [hipmem.DevBuf(P * 4) for _ in range(2)]
+    du, dz = hipmem.DevBuf(P * cap * 4), hipmem.DevBuf(P * cap * 4)
+    sp = N.StereoParams(500.0, 60.0, H, 100.0, 50.0, 31.0)
+    ex.stereo_frontend_batch_device(dl.ptr, dr.ptr, P, W, H, W, W * H, dk[0].ptr, dd[0].ptr, dn[0].ptr, dk[1].ptr, dd[1].ptr, dn[1].ptr, cap, sp, du.ptr, dz.ptr, 0)
+    ex.synchronize()
+    nL, nR = dn[0].to_numpy(np.int32, P), dn[1].to_numpy(np.int32, P)
+    kL = dk[0].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap); kR = dk[1].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap)
+    dL = dd[0].to_numpy(np.uint8, P * db).reshape(P, cap, 32); dR = dd[1].to_numpy(np.uint8, P * db).reshape(P, cap, 32)
+    u, z = du.to_numpy(np.float32, P * cap).reshape(P, cap), dz.to_numpy(np.float32, P * cap).reshape(P, cap)
+    osp = oracle.stereo_params(fx=500.0, mbf=60.0, n_rows=H)
+    matched = 0
+    for i, (L, R) in enumerate(pairs):
+        okL, odL, okR, odR, ou, oz = oracle.stereo_frontend(p, osp, L, R)
+        assert nL[i] == len(okL) and nR[i] == len(okR), i
+        assert kL[i, :nL[i]].tobytes() == okL.tobytes() and kR[i, :nR[i]].tobytes() == okR.tobytes(), i
+        assert np.array_equal(dL[i, :nL[i]], odL) and np.array_equal(dR[i, :nR[i]], odR), i
+        assert np.array_equal(u[i, :nL[i]], ou) and np.array_equal(z[i, :nL[i]], oz), i
+        matched += int((oz > 0).sum())
+    assert matched > 50 * P
 
 
 def test_reserve_failure_leaves_handle_usable(gpu):
