@@ -66,9 +66,12 @@ def parse_args():
     ap.add_argument("--density", type=int, choices=[1, 3], default=1,
                     help="scene density: 1 = the default synthetic scene (w*h/800 shapes: ~5 k FAST corners on level 0 of a 1080p frame), "
                          "3 = three times the shapes (>= 12 k level-0 corners): FAST's sparse phases scale with the corner load")
-    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+    ap.add_argument("--min-timed-ms", type=float, default=200.0,
                     help="every timed step repeats its batch `inner_repeats` times so that the K timed steps cover at least this much GPU time "
                          "(0 = one pass per step); value counts every pass")
+    ap.add_argument("--call-site", type=int, choices=[0, 1], default=1,
+                    help="c2, N = 1: also run tests/cpp/_build/bench_adaptor (when __graft_entry__.build() has made it) AFTER the timed loop and report, as "
+                         "`call_site`, what hySLAM's own call sites would see through the drop-in C++ classes (ProcessStereoImage ms per pair, split gather / C ABI / scatter)")
     ap.add_argument("--pcie-seconds", type=float, default=1.5, help="c2, N = 1: budget of the host-fed (PCIe-inclusive) secondary measurement (0 = skip)")
     ap.add_argument("--c4-split", type=int, choices=[0, 1], default=1,
                     help="c4: hs_orb_set_split(1) on both camera handles (level 0's FAST + quadtree on a second stream beside the pyramid); 0 = the library default")
@@ -146,13 +149,33 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert int(t.item()) == world
+    line = {"metric": "dry run (no GPU work)", "value": 0.0, "unit": "stereo_pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "dry_run": True}
+    rc = 0
+    if args.config == "c5":
+        # the self-check of the cross-camera exchange on CPU tensors: seeded stand-in records (no extraction), the real all-gather + verify_exchange;
+        # HS_BENCH_TEST_CORRUPT_RANK makes one rank flip a byte of ITS copy of the gathered buffer so that the check is seen to fire
+        import numpy as np
+        from hyslam_amd import distributed as D
+        from hyslam_amd._native import KP_DTYPE
+        cap = 64
+        rng = np.random.default_rng(500 + rank)
+        n = 40 + rank
+        k = np.zeros(n, KP_DTYPE); k["x"] = rng.random(n); k["y"] = rng.random(n); k["octave"] = rng.integers(0, 8, n)
+        rec = torch.from_numpy(D.pack_record(k, rng.integers(0, 256, (n, 32), dtype=np.uint8), cap))
+        g = D.all_gather_records(rec) if world > 1 else rec.view(1, -1).clone()
+        if os.environ.get("HS_BENCH_TEST_CORRUPT_RANK") == str(rank):
+            g[(rank + 1) % world, 100] ^= 0xFF
+        check = D.verify_exchange(g, n, rank, world)
+        line["ranks_consistent"] = check["ranks_consistent"]
+        line["exchange_check"] = check
+        rc = 0 if check["ranks_consistent"] else 4
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "stereo_pairs/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "dry_run": True}), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc
 
 
 # ------------------------------------------------------------------------------------------------ accounting
@@ -261,20 +284,24 @@ def fence_fn(torch, dist, world):
 
 
 def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, pause=None):
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.
+    """W untimed warm-up steps (twice: once with stage events, once without — the second sizes `inner_repeats`), then exactly K steps bracketed by
+    barrier + synchronize on both sides; MAX over ranks.
     The per-stage HIP events (begin / pause / end) are recorded on the FIRST `profiled_steps(args)` of the K timed steps only: an event record
     drains the stream between two stages (28 us per step on MI355X: 5 % of a 16-pair step, 16 % of a single-pair step), so instrumenting every
     step would make the measured throughput a property of the instrumentation."""
     if begin:
         begin()
-    torch.cuda.synchronize()
-    tw = time.perf_counter()
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 1)):        # first warm-up: instrumented (the event pool is created here), includes first-touch costs
         step()
     torch.cuda.synchronize()
-    t_pass = (time.perf_counter() - tw) / max(args.warmup, 1)
     if end:
         end()
+    nw = max(args.warmup, 3)                     # second warm-up: exactly what the timed steps run (no events) -> the duration of one pass
+    tw = time.perf_counter()
+    for _ in range(nw):
+        step()
+    torch.cuda.synchronize()
+    t_pass = (time.perf_counter() - tw) / nw
     # the driver may ask for so few steps that the timed region is a few milliseconds (20 steps = 10 ms): repeat the batch inside a step so that
     # the K steps cover >= --min-timed-ms of GPU time.  `steps` stays the caller's unit; every rank uses the same factor.
     inner = 1
@@ -299,6 +326,7 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, paus
     t1 = time.perf_counter()
     prof = end() if end else None
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    args.local_elapsed = t1 - t0                 # this rank's own time for the K steps (the line reports min / max over ranks beside the aggregate)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     return float(elapsed.item()), prof
@@ -375,6 +403,18 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     value = world * B * args.steps * args.inner_repeats / elapsed
     n_left = nL.cpu().numpy()
     n_match = int((depth.view(B, cap)[0] > 0).sum().item())
+    # what the timed loop left in pair 0's output buffers, hashed like tools/make_golden.py hashed the oracle's outputs for the same seeded pair
+    # (tests/golden/bench_c2_seed1000.json: data only); every rank checks its own pair, the line carries the conjunction
+    parity = parity_checksum(rank, args, N, cap, kL, dL, nL, kR, dR, nR, uR, depth)
+    per_rank = [B * args.steps * args.inner_repeats / args.local_elapsed]
+    if world > 1:
+        t = torch.tensor([1 if parity["ok"] else (0 if parity["ok"] is False else 2), int(per_rank[0])], dtype=torch.int64, device=dev)
+        allt = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allt.view(-1), t)
+        flags, per_rank = allt[:, 0].tolist(), [float(v) for v in allt[:, 1].tolist()]
+        parity["ok"] = None if all(f == 2 for f in flags) else all(f != 0 for f in flags)
+        parity["ranks_checked"] = sum(f != 2 for f in flags)
+        parity["ranks_failed"] = [r for r, f in enumerate(flags) if f == 0]
     if rank != 0:
         return
     px = pyramid_pixels(ex, W, H)
@@ -394,6 +434,10 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
                                        "no address reuse inside a step, every step re-reads the same %d MB of frames" % (nd, B, nd, 2 * B * W * H // 1000000),
                      "sharding": "pairs sharded over ranks, no collective",
                      "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match}
+    out["parity_checksum_ok"] = parity["ok"]
+    out["parity_checksum"] = {k: v for k, v in parity.items() if k != "ok"}
+    out["per_rank_pairs_per_s"] = {"min": round(min(per_rank), 1), "max": round(max(per_rank), 1)}
+    out["timed_region_ms"] = round(elapsed * 1e3, 1)
     out["roofline"] = rls[dom]
     out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
     out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
@@ -407,9 +451,65 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["end_to_end"]["frac_on_moved_bytes"] = round(value / world * moved_pair / 1e9 / HBM_PEAK_GBS, 5)
     if world == 1 and args.pcie_seconds > 0:
         out["pcie_inclusive"] = pcie_inclusive(HS, exs[0], sp, pairs, B, args.pcie_seconds)
+    if world == 1 and args.call_site:
+        cs = call_site()
+        if cs is not None:
+            out["call_site"] = cs
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
     print(json.dumps(out), flush=True)
+
+
+def parity_checksum(rank, args, N, cap, kL, dL, nL, kR, dR, nR, uR, depth):
+    """sha256 of pair 0's outputs (keypoints L, descriptors L, keypoints R, descriptors R, uRight, depth — the valid prefixes) against the committed
+    oracle checksum of the same seeded pair.  ok = True / False, or None when no committed checksum applies (--density 3, rank > 7)."""
+    import hashlib
+    res = {"ok": None, "fixture": "tests/golden/bench_c2_seed1000.json", "rank0_outputs_sha256": None}
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_c2_seed1000.json")))["ranks"].get(str(rank))
+    except Exception:
+        gold = None
+    n_l, n_r = int(nL[0].item()), int(nR[0].item())
+    kb = N.KP_DTYPE.itemsize
+    h = hashlib.sha256()
+    for buf, n, item in ((kL, n_l, kb), (dL, n_l, 32), (kR, n_r, kb), (dR, n_r, 32)):
+        h.update(buf[:n * item].cpu().numpy().tobytes())
+    h.update(uR[:n_l].cpu().numpy().tobytes())
+    h.update(depth[:n_l].cpu().numpy().tobytes())
+    res["rank0_outputs_sha256"] = h.hexdigest()
+    if gold is not None and args.density == 1 and (W, H, NFEAT) == (1920, 1080, 2000):
+        res["ok"] = (h.hexdigest() == gold["outputs_sha256"]) and n_l == gold["nL"] and n_r == gold["nR"]
+        res["expected_sha256"] = gold["outputs_sha256"]
+    return res
+
+
+def call_site():
+    """What hySLAM's call sites would see through the drop-in C++ classes (tests/cpp/bench_adaptor.cpp compiled against hyslam_amd/host/*.h by
+    __graft_entry__.build(); INTEGRATION.md §6): ImageProcessing::ProcessStereoImage with two HipORBExtractor threads + HipStereomatcher, and the
+    optional one-call HipStereoFrontend, in ms per 1080p pair, split into gather / C ABI / scatter.  A child process, run after the timed loop."""
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_adaptor")
+    if not os.path.exists(exe):
+        return None
+    import tempfile
+    from hyslam_amd.synth import synth_stereo_pair
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            L, R = synth_stereo_pair(1000, W, H)
+            fl, fr = os.path.join(td, "L.raw"), os.path.join(td, "R.raw")
+            L.tofile(fl); R.tofile(fr)
+            r = subprocess.run([exe, str(W), str(H), fl, fr, "20", "5000"], capture_output=True, timeout=120)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr).decode(errors="replace")[-200:]}
+        d = json.loads(r.stdout.decode())
+        p, f = d["ProcessStereoImage_ms"], d["HipStereoFrontend_ms"]
+        return {"source": "tests/cpp/bench_adaptor (the C++ adaptors on host/cv_compat.h's stand-ins for cv::Mat / FeatureDescriptor / FeatureViews)",
+                "ProcessStereoImage_ms_per_pair": p["total"], "ProcessStereoImage_pairs_per_s": round(1e3 / p["total"], 1) if p["total"] > 0 else None,
+                "ProcessStereoImage_split_ms": {"extract_LR_threads": p["extract_LR_threads"], "of_which_c_abi": p["extract_c_abi"], "of_which_scatter": p["extract_scatter"],
+                                                "FeatureViews_ctor": p["FeatureViews_ctor"], "stereo_gather": p["stereo_gather"], "stereo_c_abi": p["stereo_c_abi"], "getData": p["getData"]},
+                "HipStereoFrontend_ms_per_pair": f["process_total"], "HipStereoFrontend_split_ms": {"submit_plus_wait": f["submit_plus_wait"], "FeatureViews_build": f["FeatureViews_build"]},
+                "HipStereoFrontend_pipelined_ms_per_pair": f["pipelined_per_pair"], "keypoints": d["keypoints"], "stereo_matches": d["stereo_matches"]}
+    except Exception as e:      # a secondary figure must never take the headline down
+        return {"error": str(e)[:200]}
 
 
 def pcie_inclusive(HS, ex, sp, pairs, B, seconds):
@@ -608,6 +708,15 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
     stream = s.cuda_stream
     outs = tuple(torch.zeros((world, cap), dtype=torch.int32, device=dev) for _ in range(3))
     xc = None
+    exchange_note = None
+    if world > 1 and args.c5_comm == "hs":
+        # hs_comm_create blocks in ncclCommInitRank until ALL ranks arrive: ask every rank first (non-collective probe) and fall back TOGETHER
+        ok, why = D.comm_available()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            args.c5_comm = "torch"
+            exchange_note = "hs_comm unavailable on at least one rank (%s): fell back to torch.distributed.all_gather_into_tensor before any collective" % (why or "another rank")
     if world > 1 and args.c5_comm == "hs":
         ident = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
@@ -640,6 +749,10 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
 
     elapsed, _ = timed(step, args, fence_fn(torch, dist, world), torch, dist, world, dev)
     counts = gathered[:, :4].view(torch.int32)[:, 0].cpu().tolist()
+    # every rank must hold the same gathered bytes, and record r must be rank r's own frame (hyslam_amd.distributed.verify_exchange)
+    check = D.verify_exchange(gathered, counts[rank], rank, world, match_outputs=(outs if bow is None else (bow.match12, bow.n_matches)))
+    if xc is not None:
+        xc.close()
     good = 0
     if bow is None:
         n = counts[rank]
@@ -650,6 +763,8 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
     else:
         good = bow.total_matches(rank)
     if rank != 0:
+        if not check["ranks_consistent"]:
+            sys.exit(4)                      # every rank holds the same verdict (it was all-gathered): the whole job fails, not just rank 0
         return
     out = base_line("mono frames/sec ORB extract + all-gather + cross-camera match, 1920x1080 @2000 feat", world * args.steps * args.inner_repeats / elapsed, "frames/s",
                     args, world, elapsed)
@@ -657,7 +772,14 @@ def run_c5(args, rank, world, local_rank, dev, torch, dist, HS, N):
                                  % (rb, "brute-force Hamming 2-NN" if bow is None else "vocabulary transform + BoW-grouped match (synthetic 10-ary vocabulary)"),
                      "exchange": "none (one rank)" if world == 1 else ("hs_comm_allgather_records (RCCL through the C ABI), in place" if xc is not None else "torch.distributed.all_gather_into_tensor"),
                      "keypoints_rank0": counts[0], "matches_rank0": good}
+    if exchange_note:
+        out["config"]["exchange_note"] = exchange_note
+    out["ranks_consistent"] = check["ranks_consistent"]
+    out["exchange_check"] = check
     print(json.dumps(out), flush=True)
+    if not check["ranks_consistent"]:
+        sys.stderr.write("bench.py: the ranks disagree on the gathered records (%s)\n" % json.dumps(check))
+        sys.exit(4)
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline

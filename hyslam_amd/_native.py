@@ -76,7 +76,7 @@ EXPORTS = [
     "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
-    "hs_comm_get_unique_id", "hs_comm_create", "hs_comm_destroy", "hs_comm_world", "hs_comm_rank", "hs_comm_last_error", "hs_comm_allgather_records",
+    "hs_comm_available", "hs_comm_unavailable_reason", "hs_orb_borrowers", "hs_comm_get_unique_id", "hs_comm_create", "hs_comm_destroy", "hs_comm_world", "hs_comm_rank", "hs_comm_last_error", "hs_comm_allgather_records",
     "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_pause", "hs_orb_profile_end", "hs_debug_stream_copy",
     "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
@@ -189,6 +189,10 @@ def lib():
     L.hs_orb_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(i32)]
     L.hs_orb_wait.argtypes = [vp, i32, vp, vp, vp, C.c_int, vp, vp]
     L.hs_comm_get_unique_id.argtypes = [vp]
+    L.hs_comm_available.argtypes = []
+    L.hs_comm_unavailable_reason.argtypes = []
+    L.hs_comm_unavailable_reason.restype = C.c_char_p
+    L.hs_orb_borrowers.argtypes = [vp]
     L.hs_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.hs_comm_destroy.argtypes = [vp]
     L.hs_comm_destroy.restype = None

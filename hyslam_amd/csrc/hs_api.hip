@@ -4,6 +4,7 @@
 // sequence.  The whole extraction of a batch is GPU-resident: pyramid -> FAST/NMS cells -> quadtree
 // distribution -> blur+orientation+rBRIEF, 10 kernel launches for an 8-level pyramid regardless of batch size.
 #include "hs_internal.h"
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,10 @@
 struct hs_orb {
     hs_orb_params p;
     int device = 0;
+    // communicators created on this handle (hs_comm_create) BORROW it — its device and its stream: while one is alive hs_orb_destroy only marks the
+    // handle (`zombie`) and the last hs_comm_destroy frees it, so the two destroy calls are safe in either order
+    std::atomic<int> borrowers{0};
+    std::atomic<bool> zombie{false};
     hipStream_t stream = nullptr;
     std::string err;
     uint16_t taps[7];
@@ -24,6 +29,7 @@ struct hs_orb {
     hipStream_t s_aux = nullptr; hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;      // the second launch sequence of the split and its fences
     bool qt_point_domain = false;      // HS_QT_POINT_DOMAIN=1 (read once): the quadtree's general point-domain passes only (parity tests of the fallback)
     int fast_order = 1;                // HS_FAST_ORDER (read once): order of the FAST work items of an image: 1 = reduced levels deepest first, level 0 last; 0 = level 0 first (the order until round 3); 2 = reduced levels interleaved, level 0 last
+    bool stereo_fuse = true;           // HS_STEREO_FUSE=0 (read once): the stereo front end with a separate k_stereo_strips launch instead of the strips binned by an extra workgroup of the describe launch
     bool no_fuse = false;              // HS_PYRAMID_NO_FUSE=1 (read once): one pyramid level per launch (parity tests of the unfused kernel)
     bool fast_taps = false;            // every tap fits a byte and the 16-bit row sums cannot saturate
     // ORBExtractor ctor tables (ORBExtractor.cpp:86-118)
@@ -32,14 +38,17 @@ struct hs_orb {
     // geometry currently configured
     int w = 0, h = 0, batch_cap = 0;
     std::vector<HsLevel> lv;
+    std::vector<HsLevel> lv_n;         // the same levels with the NARROW FAST work items (grp_cells / ngroups / item_begin differ); device copy at d_lv + nlevels
     int total_cells = 0, max_wcell = 1, max_hcell = 1;
     int fast_items = 0;                // FAST work items per image (HsLevel::item_begin)
+    int fast_items_n = 0;              // narrow items per image; 0 = no narrow list (a cell wider than the narrow tile)
     uint64_t cand_img_stride = 0;      // candidate entries per image
     int sel_img_stride = 0;            // selection entries per image
     int max_kp = 0;
     // device memory
     HsLevel* d_lv = nullptr;
     HsFastItem* d_fast_items = nullptr;
+    HsFastItem* d_fast_items_n = nullptr;
     uint32_t* d_fast_ovf = nullptr;
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
@@ -115,6 +124,7 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear();
     hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
+    hipFree(h->d_fast_items_n); h->d_fast_items_n = nullptr; h->fast_items_n = 0;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
     hipFree(h->d_cand); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
     h->d_cand = nullptr; h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
@@ -161,10 +171,10 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         V.nrows = height > 0 ? (int)(height / W) : 0;
         if (V.ncols < 1 || V.nrows < 1) { V.ncols = V.nrows = 0; V.wcell = V.hcell = 0; }   // reference: division by zero (UB); no keypoints here
         else { V.wcell = (int)ceilf(width / V.ncols); V.hcell = (int)ceilf(height / V.nrows); }
-        if (V.wcell > hs_fast_max_cell_w() || V.hcell > HS_MAX_CELL_H)
+        if (V.wcell > hs_fast_max_cell_w(6) || V.hcell > HS_MAX_CELL_H)
             return fail(h, HS_ERR_INVALID, "FAST cell wider than 247 px or taller than 125 px is not supported");
         V.cell_begin = cells; cells += V.ncols * V.nrows;
-        V.grp_cells = hs_fast_group_cells(V.wcell, V.ncols);
+        V.grp_cells = hs_fast_group_cells(V.wcell, V.ncols, 6);
         V.ngroups = V.grp_cells > 0 ? (V.ncols + V.grp_cells - 1) / V.grp_cells : 0;
         V.item_begin = items; items += V.ngroups * V.nrows;
         V.inv_wcell = V.wcell > 0 ? (65536 + V.wcell - 1) / V.wcell : 0;
@@ -221,14 +231,16 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     // costs 2-3 times an item of level 0 (the same number of pixels, denser corners), and the persistent FAST kernel walks the items in this
     // order: with the cheap, uniform level-0 items at the end of every queue the tail of the launch — waves finishing their last item while
     // the queues are empty — is short (a 32-frame launch spent ~17 % more per frame than a 128-frame launch with the expensive items last).
-    {
+    auto order_items = [&](std::vector<HsLevel>& lv) {
         int pos = 0;
-        if (h->fast_order == 0) { for (int l = 0; l < L; l++) { h->lv[l].item_begin = pos; pos += h->lv[l].ngroups * h->lv[l].nrows; } }
+        if (h->fast_order == 0) { for (int l = 0; l < L; l++) { lv[l].item_begin = pos; pos += lv[l].ngroups * lv[l].nrows; } }
         else {
-            for (int l = L - 1; l >= 1; l--) { h->lv[l].item_begin = pos; pos += h->lv[l].ngroups * h->lv[l].nrows; }
-            h->lv[0].item_begin = pos;
+            for (int l = L - 1; l >= 1; l--) { lv[l].item_begin = pos; pos += lv[l].ngroups * lv[l].nrows; }
+            lv[0].item_begin = pos; pos += lv[0].ngroups * lv[0].nrows;
         }
-    }
+        return pos;
+    };
+    order_items(h->lv);
 
     HIP_TRY(h, hipMalloc(&h->d_pyr, std::max<size_t>(pyr_per_img * batch, 256)));
     HIP_TRY(h, hipMalloc(&h->d_tables, std::max<size_t>(tables.size() * sizeof(int16_t), 256)));
@@ -302,24 +314,44 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
             F.xt = reinterpret_cast<const HsPyrXTile*>(h->d_pyr_tabs + (uintptr_t)F.xt); F.yt = reinterpret_cast<const HsPyrYTile*>(h->d_pyr_tabs + (uintptr_t)F.yt);
         }
     }
-    HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
-    {
-        std::vector<HsFastItem> fi(std::max(items, 1));
-        hs_fast_build_items(h->lv.data(), L, fi.data());
-        if (h->fast_order == 2 && L > 2) {                     // experiment: the reduced levels interleaved in proportion (every stretch of the list has the same mix of levels), level 0 last
-            const int n_red = h->lv[0].item_begin;
-            std::vector<std::pair<double, int>> key(n_red);
-            for (int l = 1; l < L; l++) {
-                const int n = h->lv[l].ngroups * h->lv[l].nrows;
-                for (int k = 0; k < n; k++) key[h->lv[l].item_begin + k] = { (k + 0.5) / n, h->lv[l].item_begin + k };
-            }
-            std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
-            std::vector<HsFastItem> t(fi.begin(), fi.begin() + n_red);
-            for (int i = 0; i < n_red; i++) fi[i] = t[key[i].second];
+    // the same levels with NARROW work items (tiles of 32 dwords: <= 119 px of interior per item), for the launches of small batches: the list
+    // differs in the grouping of the cells only, so everything downstream of the FAST kernel (the quadtree's gather) reads the grouping it was
+    // launched with from ITS copy of the level array (d_lv + L)
+    h->lv_n = h->lv;
+    bool narrow_ok = h->fast_knobs.cols != 64;
+    for (int l = 0; l < L; l++) if (h->lv[l].wcell > hs_fast_max_cell_w(5)) narrow_ok = false;
+    if (narrow_ok) {
+        for (int l = 0; l < L; l++) {
+            HsLevel& V = h->lv_n[l];
+            V.grp_cells = hs_fast_group_cells(V.wcell, V.ncols, 5);
+            V.ngroups = V.grp_cells > 0 ? (V.ncols + V.grp_cells - 1) / V.grp_cells : 0;
         }
-        HIP_TRY(h, hipMalloc(&h->d_fast_items, fi.size() * sizeof(HsFastItem)));
-        HIP_TRY(h, hipMemcpy(h->d_fast_items, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, items * batch, h->fast_knobs), 256)));
+        h->fast_items_n = order_items(h->lv_n);
+    }
+    HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_lv + L, h->lv_n.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
+    {
+        auto upload_items = [&](const std::vector<HsLevel>& lv, int n_items, HsFastItem** d_out) -> hipError_t {
+            std::vector<HsFastItem> fi(std::max(n_items, 1));
+            hs_fast_build_items(lv.data(), L, fi.data());
+            if (h->fast_order == 2 && L > 2) {                 // experiment: the reduced levels interleaved in proportion (every stretch of the list has the same mix of levels), level 0 last
+                const int n_red = lv[0].item_begin;
+                std::vector<std::pair<double, int>> key(n_red);
+                for (int l = 1; l < L; l++) {
+                    const int n = lv[l].ngroups * lv[l].nrows;
+                    for (int k = 0; k < n; k++) key[lv[l].item_begin + k] = { (k + 0.5) / n, lv[l].item_begin + k };
+                }
+                std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+                std::vector<HsFastItem> t(fi.begin(), fi.begin() + n_red);
+                for (int i = 0; i < n_red; i++) fi[i] = t[key[i].second];
+            }
+            hipError_t e = hipMalloc(d_out, fi.size() * sizeof(HsFastItem));
+            if (e != hipSuccess) return e;
+            return hipMemcpy(*d_out, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(h, upload_items(h->lv, items, &h->d_fast_items));
+        if (h->fast_items_n > 0) HIP_TRY(h, upload_items(h->lv_n, h->fast_items_n, &h->d_fast_items_n));
+        HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, std::max(items, h->fast_items_n) * batch, h->fast_knobs), 256)));
         HIP_TRY(h, hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4));       // all four work-queue counter sets start at zero
     }
     h->w = w; h->h = hh; h->batch_cap = batch;      // configured only now
@@ -387,7 +419,8 @@ int ensure_stereo_scratch(hs_orb* h, size_t entries)
     return HS_OK;
 }
 
-int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
+// `sf`: the stereo front end — the describe launch also bins the right images' keypoints into the matcher's strips (HsStripFuse, kernels_describe.hip)
+int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, const HsStripFuse* sf = nullptr)
 {
     const int L = h->p.nlevels;
     // Level 0 needs no pyramid.  For one or two LARGE frames the chain of launches is latency-bound (dependent pyramid launches, a FAST launch
@@ -396,14 +429,23 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
     // results.  Measured: the 4000 x 3000 "Imaging" extraction 0.245 -> 0.16 ms (config C4: 2 350 -> 3 550 steps/s); a 1080p pair gets SLOWER
     // (0.132 -> 0.160 ms: the fork / join between the streams costs more than the overlap saves), 16 pairs too (0.468 -> 0.519 ms), hence the
     // size rule.  Not with stage events (they would serialise the two sequences).
-    const int items0 = h->lv[0].ngroups * h->lv[0].nrows, first0 = h->lv[0].item_begin;      // work items of level 0: the LAST items0 of the item list
-    const bool split = !h->prof && L > 1 && items0 > 0 && items0 < h->fast_items && (h->split_mode == 1 || (h->split_mode < 0 && batch <= 2 && (size_t)h->w * (size_t)h->h * (size_t)batch >= 6000000));
+    // Item width by batch (round 4): a launch of few frames lasts as long as its slowest wave (one stereo pair: 1 904 wide items for 2 816
+    // resident single-wave workgroups), so it gets the NARROW items — twice as many, half as long; measured at 1080p (pairs per call: narrow / wide pairs/s): 1: 9 949 / 8 403,
+    // 2: 16 029 / 15 642, 4: 23 004 / 22 660, 8: 32 657 / 33 240, 16: 40 917 / 41 507 — from ~18 k items on the wide ones win (fewer, fuller tiles).  HS_FAST_COLS = 32 / 64 forces one list, HS_FAST_NARROW_MAX moves the threshold.
+    const int narrow_max = h->fast_knobs.narrow_max > 0 ? h->fast_knobs.narrow_max : 18000;
+    const bool narrow = h->fast_items_n > 0 && (h->fast_knobs.cols == 32 || (h->fast_knobs.cols != 64 && (long long)h->fast_items_n * batch <= narrow_max));
+    const std::vector<HsLevel>& lvh = narrow ? h->lv_n : h->lv;
+    const HsLevel* const d_lv = h->d_lv + (narrow ? L : 0);
+    const HsFastItem* const d_items = narrow ? h->d_fast_items_n : h->d_fast_items;
+    const int n_items = narrow ? h->fast_items_n : h->fast_items, lc = narrow ? 5 : 6;
+    const int items0 = lvh[0].ngroups * lvh[0].nrows, first0 = lvh[0].item_begin;      // work items of level 0: the LAST items0 of the item list
+    const bool split = !h->prof && L > 1 && items0 > 0 && items0 < n_items && (h->split_mode == 1 || (h->split_mode < 0 && batch <= 2 && (size_t)h->w * (size_t)h->h * (size_t)batch >= 6000000));
     auto fast = [&](int item_first, int item_count, int spill_slot, hipStream_t st) -> int {
         // launch N uses work-queue counter set N & 3 and relies on launch N - 2 having zeroed it: the epoch advances only when a launch was
         // enqueued without error; after a failed launch all sets are zeroed again so that the next one starts from a known state
-        const bool launched = hs_launch_fast(h->d_lv, h->d_fast_items, L, img0, batch, h->total_cells, h->fast_items, h->p.fast_threshold,
+        const bool launched = hs_launch_fast(d_lv, d_items, L, img0, batch, h->total_cells, n_items, h->p.fast_threshold,
                                              h->d_cand, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs,
-                                             item_first, item_count, spill_slot, st);
+                                             item_first, item_count, spill_slot, lc, st);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             (void)hipDeviceSynchronize();
@@ -414,7 +456,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         return HS_OK;
     };
     auto quadtree = [&](int level_first, int level_count, hipStream_t st) {
-        hs_launch_quadtree(h->d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
+        hs_launch_quadtree(d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
                            h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0,
                            level_first, level_count, st);
     };
@@ -431,7 +473,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
         hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
-        rc = fast(0, h->fast_items - items0, 0, s);
+        rc = fast(0, n_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
@@ -439,14 +481,14 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s)
         mark(h, 0, s);
         hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
         mark(h, 1, s);
-        const int rc = fast(0, h->fast_items, 0, s);
+        const int rc = fast(0, n_items, 0, s);
         if (rc != HS_OK) return rc;
         mark(h, 2, s);
         quadtree(0, L, s);
     }
     mark(h, 3, s);
     hs_launch_describe(h->d_lv, L, img0, batch, h->d_sel, h->d_sel_count, h->d_sel_perm, h->sel_img_stride, h->max_kp,
-                       h->d_taps, out, s, h->fast_taps);
+                       h->d_taps, out, s, h->fast_taps, sf ? *sf : HsStripFuse{});
     mark(h, -1, s);
     HIP_TRY(h, hipGetLastError());
     h->last_batch = batch; h->last_img0 = img0;
@@ -478,6 +520,20 @@ void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32
 {
     mark(h, 4, s);
     hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
+    mark(h, 5, s);
+    hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, h->d_strip_count, sp.n_rows, s);
+    mark(h, -1, s);
+}
+
+// the stereo front end's matcher: the strips were binned by an extra workgroup of the describe launch (HsStripFuse): two launches where
+// run_stereo needs three.  (Round 4 also built the median rejection into the matcher — each pair's last workgroup, found with a ticket counter,
+// the three result arrays written through with agent-scope atomic stores so that no L2 write-back is needed: bit-exact, but the write-through
+// stores cost more than the launch they save: 0.056 against 0.022 + 0.006 ms per 16 pairs, 10.0 against 4.8 + 4.8 us for one pair.  Dropped.)
+void run_stereo_fused(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32_t* nL, const hs_keypoint* kR, const uint8_t* dR,
+                      const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
+{
+    mark(h, 4, s);
+    hs_launch_stereo_match_only(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
     mark(h, 5, s);
     hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, h->d_strip_count, sp.n_rows, s);
     mark(h, -1, s);
@@ -539,6 +595,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->p = *p; h->device = device;
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
+    { const char* e = getenv("HS_STEREO_FUSE"); h->stereo_fuse = !(e && atoi(e) == 0); }
     { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
@@ -565,7 +622,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
 
     if (hipSetDevice(device) != hipSuccess) { delete h; return HS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&h->d_lv, sizeof(HsLevel) * HS_MAX_LEVELS) != hipSuccess ||
+        hipMalloc(&h->d_lv, sizeof(HsLevel) * 2 * HS_MAX_LEVELS) != hipSuccess ||
         hipMalloc(&h->d_taps, 16) != hipSuccess ||
         hipMemcpy(h->d_taps, h->taps, 14, hipMemcpyHostToDevice) != hipSuccess) {
         hs_orb_destroy(h);
@@ -575,9 +632,24 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     return HS_OK;
 }
 
+static void orb_destroy_now(hs_orb* h);
 void hs_orb_destroy(hs_orb* h)
 {
     if (!h) return;
+    if (h->borrowers.load() > 0) { h->zombie.store(true); return; }      // a communicator still uses the handle: the last hs_comm_destroy frees it
+    orb_destroy_now(h);
+}
+int hs_orb_borrowers(const hs_orb* h) { return h ? h->borrowers.load() : 0; }
+} // extern "C"
+// hs_comm.hip: +1 when a communicator is created on the handle, -1 when it is destroyed (which also completes a deferred hs_orb_destroy)
+void hs_orb_borrow(hs_orb* h, int delta)
+{
+    if (!h) return;
+    const int left = h->borrowers.fetch_add(delta) + delta;
+    if (delta < 0 && left <= 0 && h->zombie.load()) orb_destroy_now(h);
+}
+static void orb_destroy_now(hs_orb* h)
+{
     hipSetDevice(h->device);
     if (h->lane2) { hs_orb_destroy(h->lane2); h->lane2 = nullptr; }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -608,6 +680,7 @@ void hs_orb_destroy(hs_orb* h)
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
+extern "C" {
 
 const char* hs_orb_last_error(const hs_orb* h) { return h ? h->err.c_str() : "null handle"; }
 int hs_orb_get_levels(const hs_orb* h) { return h ? h->p.nlevels : 0; }
@@ -852,9 +925,16 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     HsImg0 img0{ d_left, d_right, pairs, (uint64_t)row_stride, (uint64_t)image_stride };
     HsOut out{ d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap };
-    rc = run_extract(h, img0, 2 * pairs, out, s);
-    if (rc != HS_OK) return rc;
-    run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
+    if (h->stereo_fuse) {
+        const HsStripFuse sf{ 1, sp->n_rows, hs_stereo_strips(sp->n_rows), 0, sp->size_ref, h->d_strip_count, reinterpret_cast<HsStripEntry*>(h->d_strip_list) };
+        rc = run_extract(h, img0, 2 * pairs, out, s, &sf);
+        if (rc != HS_OK) return rc;
+        run_stereo_fused(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
+    } else {
+        rc = run_extract(h, img0, 2 * pairs, out, s);
+        if (rc != HS_OK) return rc;
+        run_stereo(h, d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, pairs, cap, *sp, d_uRight, d_depth, s);
+    }
     HIP_TRY(h, hipGetLastError());
     return HS_OK;
 }
@@ -939,10 +1019,18 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
     if (sp) {      // images [0, pairs) are the left frames, [pairs, 2 pairs) the right ones (hs_stereo_frontend_batch_device's layout)
         HsImg0 img0{ sl->d_in, sl->d_in + per_img * pairs, pairs, (uint64_t)pitch, (uint64_t)per_img };
         HsOut out{ d_k, d_d, d_n, d_k + (size_t)pairs * cap, d_d + (size_t)pairs * cap * HS_DESC_BYTES, d_n + pairs, pairs, cap };
-        rc = run_extract(h, img0, batch, out, s);
-        if (rc != HS_OK) return rc;
-        run_stereo(h, out.kps, out.desc, out.n, out.kps2, out.desc2, out.n2, pairs, cap, *sp,
-                   reinterpret_cast<float*>(sl->d_out + sl->off_u), reinterpret_cast<float*>(sl->d_out + sl->off_z), s);
+        if (h->stereo_fuse) {
+            const HsStripFuse sf{ 1, sp->n_rows, hs_stereo_strips(sp->n_rows), 0, sp->size_ref, h->d_strip_count, reinterpret_cast<HsStripEntry*>(h->d_strip_list) };
+            rc = run_extract(h, img0, batch, out, s, &sf);
+            if (rc != HS_OK) return rc;
+            run_stereo_fused(h, out.kps, out.desc, out.n, out.kps2, out.desc2, out.n2, pairs, cap, *sp,
+                             reinterpret_cast<float*>(sl->d_out + sl->off_u), reinterpret_cast<float*>(sl->d_out + sl->off_z), s);
+        } else {
+            rc = run_extract(h, img0, batch, out, s);
+            if (rc != HS_OK) return rc;
+            run_stereo(h, out.kps, out.desc, out.n, out.kps2, out.desc2, out.n2, pairs, cap, *sp,
+                       reinterpret_cast<float*>(sl->d_out + sl->off_u), reinterpret_cast<float*>(sl->d_out + sl->off_z), s);
+        }
         HIP_TRY(h, hipGetLastError());
     } else {
         HsImg0 img0{ sl->d_in, sl->d_in, batch, (uint64_t)pitch, (uint64_t)per_img };

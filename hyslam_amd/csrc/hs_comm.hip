@@ -16,6 +16,7 @@
 void hs_set_error(hs_orb* h, const char* msg);       // hs_api.hip
 int hs_orb_device_of(const hs_orb* h);              // hs_api.hip
 hipStream_t hs_orb_stream_of(const hs_orb* h);      // hs_api.hip
+void hs_orb_borrow(hs_orb* h, int delta);           // hs_api.hip: a communicator borrows the handle it was created on
 
 // the RCCL types this file needs (rccl.h: ncclResult_t is an enum, ncclComm_t an opaque pointer, ncclUniqueId 128 opaque bytes, ncclChar = 0)
 typedef int hs_nccl_result;
@@ -65,6 +66,16 @@ struct hs_comm {
 
 extern "C" {
 
+// non-collective probe: can this process create a communicator at all (librccl loads and has the entry points)?  A multi-rank caller asks every
+// rank BEFORE the first hs_comm_create — which blocks in ncclCommInitRank until all ranks arrive — and falls back to its own exchange when any
+// rank says no (bench.py --config c5 does).
+int hs_comm_available(void)
+{
+    Rccl& r = rccl();
+    return r.so ? HS_OK : HS_ERR_NO_DEVICE;
+}
+const char* hs_comm_unavailable_reason(void) { Rccl& r = rccl(); return r.so ? "" : r.why.c_str(); }
+
 int hs_comm_get_unique_id(uint8_t* id)
 {
     if (!id) return HS_ERR_INVALID;
@@ -91,6 +102,7 @@ int hs_comm_create(hs_orb* h, const uint8_t* id, int world, int rank, hs_comm** 
     c->h = h; c->world = world; c->rank = rank;
     const hs_nccl_result rc = r.CommInitRank(&c->comm, world, u, rank);      // blocks until all `world` ranks have called it
     if (rc != 0) { hs_set_error(h, nccl_text(r, "ncclCommInitRank", rc).c_str()); delete c; return HS_ERR_HIP; }
+    hs_orb_borrow(h, +1);                                   // hs_orb_destroy(h) is deferred until this communicator is gone
     *out = c;
     return HS_OK;
 }
@@ -100,7 +112,9 @@ void hs_comm_destroy(hs_comm* c)
     if (!c) return;
     Rccl& r = rccl();
     if (c->comm && r.so) { hipSetDevice(hs_orb_device_of(c->h)); r.CommDestroy(c->comm); }
+    hs_orb* const h = c->h;
     delete c;
+    hs_orb_borrow(h, -1);                                   // completes a deferred hs_orb_destroy when this was the last borrower
 }
 
 int hs_comm_world(const hs_comm* c) { return c ? c->world : 0; }

@@ -167,6 +167,20 @@ struct HsPyrChain {
     int32_t grid_x, grid_y, valid, _r;
 };
 
+#define HS_STRIP_ENTRY_BYTES 16
+#define HS_STRIP_SHIFT 5           // right keypoints are binned into strips of 32 rows (kernels_stereo.hip)
+// A strip entry carries everything the candidate test needs, so that the matcher's chain of dependent loads is entry -> descriptor instead of
+// index -> keypoint record -> descriptor: the right keypoint's u, its octave, its index and its row band CUT TO THE STRIP (two 5-bit row numbers:
+// a left keypoint that scans strip s has its row in [32 s, 32 s + 31], so the cut band decides exactly what the whole band decides).
+struct __attribute__((aligned(16))) HsStripEntry { float uR; int32_t octave; uint32_t idx_band; uint32_t _pad; };   // idx_band = iR | lo << 16 | hi << 24
+static_assert(sizeof(HsStripEntry) == HS_STRIP_ENTRY_BYTES, "hs_api.hip sizes the strip lists with HS_STRIP_ENTRY_BYTES");
+#define HS_STRIPS_MAX 2048         // 65536 rows / 32
+// The stereo front end (extract L + R, then match; hs_stereo_frontend_batch_device): the describe launch carries one extra workgroup per RIGHT
+// image that bins the image's selected keypoints into the strips (position, level and list index are known since the quadtree kernel; the
+// describe workgroups next to it fill in angle and descriptor) — no k_stereo_strips launch.  enabled = 0: a plain describe launch.
+struct HsStripFuse { int32_t enabled, n_rows, n_strips, _r; float size_ref; int32_t* strip_count; HsStripEntry* strip_list; };
+inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
+
 // kernels_*.hip launchers (all asynchronous on `s`)
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s);
 // plans a chain over levels [first, first + n) (n = 2 or 3): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the geometry does not fit
@@ -178,18 +192,18 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
 // decides, from the host copies of the resize tables, whether levels (l, l+1) can be produced by the fused kernel and with which tile geometry
 void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/);
 int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kernel launches of one hs_launch_pyramid call
-int hs_fast_group_cells(int wcell, int ncols);      // cells per FAST work item for a level (0 when the level has no cells)
-int hs_fast_max_cell_w();                           // widest FAST cell the kernel's tile holds (247 px)
+int hs_fast_group_cells(int wcell, int ncols, int lc);   // cells per FAST work item for a level (0 when the level has no cells); lc = 6 / 5: wide / narrow tiles
+int hs_fast_max_cell_w(int lc);                          // widest FAST cell the kernel's tile holds (247 px wide tiles, 119 px narrow ones)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
 #define HS_FAST_NQ_MAX 32          // work queues of the FAST kernel: 8, 16 or 32 (kernels_fast.hip: FastSched)
 #define HS_FAST_QUEUE_DWORDS (32 * HS_FAST_NQ_MAX)   // head of the FAST overflow buffer: FOUR rotating sets of up to 32 work-queue counters on 128-byte lines of their own
-struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b, image_major, nq; };   // HS_FAST_* test / tuning knobs, read once per handle
+struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b, image_major, nq, cols, narrow_max, no_fold; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand /*{y<<16|x, score<<24|cell} per slot*/, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
                     const HsFastKnobs& knobs, int item_first, int item_count /*the launch covers items [first, first + count) of every image*/,
-                    int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, hipStream_t s);
+                    int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, int lc /*6 / 5: the tile width `d_items` was built for*/, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 // host side of the geometric-key tables: appends level `V`'s tables to `blob` (16-byte granules) and returns their offsets; false = the level does
 // not use them (more than 8 roots or a level wider than the tables)
@@ -200,16 +214,19 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count, hipStream_t s);
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
-                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps);
+                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps, HsStripFuse strips);
 void hs_launch_stereo(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
                       const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
                       int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth,
                       int32_t* best_dist /*[pairs][cap] scratch*/,
                       int32_t* strip_count /*[pairs][strips]*/, void* strip_list /*[pairs][strips][cap] entries of HS_STRIP_ENTRY_BYTES*/, hipStream_t s);
-#define HS_STRIP_ENTRY_BYTES 16
-inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
 void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRight, float* depth, const int32_t* best_dist,
                              int32_t* strip_count /*zero on entry of hs_launch_stereo; zeroed again here*/, int n_rows, hipStream_t s);
+// the matcher alone, on strips that the describe launch of the stereo front end has already binned (HsStripFuse)
+void hs_launch_stereo_match_only(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
+                                 const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
+                                 int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth, int32_t* best_dist,
+                                 const int32_t* strip_count, const void* strip_list, hipStream_t s);
 
 // kernels_match.hip
 size_t hs_frame_grid_bytes(int n);               // cells + cell lists of n keypoints

@@ -143,14 +143,79 @@ __device__ __forceinline__ int wave_sum(int x)
 }
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)   // lgkmcnt(0)
 
+// The extra workgroup of a RIGHT image in the stereo front end's describe launch (HsStripFuse): bins the image's selected keypoints into the
+// 32-row strips the stereo matcher scans (k_stereo_strips' job, kernels_stereo.hip; Stereomatcher.cpp:46-63).  Everything an entry needs is known
+// since the quadtree kernel: position (scaled to level 0 with the same single fp32 multiplication the keypoint record gets, ORBExtractor.cpp:546-552),
+// level, size and the keypoint's slot in the output list (levels concatenated, list order).  Eight keypoints per thread in flight.
+__device__ __forceinline__ void describe_strips_block(const HsLevel* __restrict__ lv, int nlevels, const uint32_t* __restrict__ sel_xys,
+                                                      const int32_t* __restrict__ sel_count, int sel_img_stride, int img, int pair, int cap,
+                                                      const HsStripFuse& SF, int* s_cnt)
+{
+    const int tid = threadIdx.x;
+    constexpr int T = 64 * KP_PER_BLOCK, KPT = 8;
+    for (int s = tid; s < SF.n_strips; s += T) s_cnt[s] = 0;
+    // per-level counts, list offsets, scales and sizes: wave-uniform, fetched once (scalar loads), selected per keypoint with compare chains
+    int cnt[HS_MAX_LEVELS], soff[HS_MAX_LEVELS], total = 0; float lsc[HS_MAX_LEVELS], lsz[HS_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < HS_MAX_LEVELS; l++) {
+        const bool on = l < nlevels;
+        cnt[l] = on ? hs_cload<int32_t>(sel_count + img * nlevels + l) : 0;
+        soff[l] = on ? lv[l].sel_off : 0; lsc[l] = on ? lv[l].scale : 1.f; lsz[l] = on ? lv[l].kp_size : 0.f;
+        total += cnt[l];
+    }
+    total = min(total, cap);
+    __syncthreads();
+    for (int i0 = 0; i0 < total; i0 += T * KPT) {
+        uint32_t cx[KPT], cy[KPT]; int lvl[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; k++) {
+            const int g = min(i0 + tid + T * k, total - 1);
+            int l = 0, adj = soff[0], acc = 0;                  // entry of list slot g: adj + g, adj = the level's offset minus the slots of the levels before it
+#pragma unroll
+            for (int q = 0; q + 1 < HS_MAX_LEVELS; q++) { acc += cnt[q]; if (g >= acc) { l = q + 1; adj = soff[q + 1] - acc; } }
+            const uint32_t* sel = sel_xys + ((size_t)img * sel_img_stride + (size_t)(adj + g)) * 3;
+            cx[k] = hs_gload<uint32_t>(sel); cy[k] = hs_gload<uint32_t>(sel + 1); lvl[k] = l;
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; k++) {
+            const int g = i0 + tid + T * k;
+            if (g >= total) continue;
+            const int l = lvl[k];
+            float sc = lsc[0], ksz = lsz[0];
+#pragma unroll
+            for (int q = 1; q < HS_MAX_LEVELS; q++) if (l == q) { sc = lsc[q]; ksz = lsz[q]; }
+            const float kx = l ? __fmul_rn((float)(int)cx[k], sc) : (float)(int)cx[k];
+            const float ky = l ? __fmul_rn((float)(int)cy[k], sc) : (float)(int)cy[k];
+            const float r = 2.0f * ksz / SF.size_ref;         // Stereomatcher.cpp:56
+            int maxr = (int)ceilf(ky + r), minr = (int)floorf(ky - r);
+            if (maxr < 0 || minr >= SF.n_rows) continue;      // rows outside [0, nRows) do not exist (D2)
+            minr = max(minr, 0); maxr = min(maxr, SF.n_rows - 1);
+            for (int s = minr >> HS_STRIP_SHIFT; s <= (maxr >> HS_STRIP_SHIFT); s++) {
+                const int slot = atomicAdd(&s_cnt[s], 1);
+                const int lo = max(minr - (s << HS_STRIP_SHIFT), 0), hi = min(maxr - (s << HS_STRIP_SHIFT), 31);
+                HsStripEntry e; e.uR = kx; e.octave = l; e.idx_band = (uint32_t)g | ((uint32_t)lo << 16) | ((uint32_t)hi << 24); e._pad = 0;
+                SF.strip_list[((size_t)pair * SF.n_strips + s) * cap + slot] = e;
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < SF.n_strips; s += T) SF.strip_count[(size_t)pair * SF.n_strips + s] = s_cnt[s];
+}
+
 template <bool FT>
 __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* __restrict__ lv, int nlevels, HsImg0 img0,
                                                                  const uint32_t* __restrict__ sel_xys, const int32_t* __restrict__ sel_count,
                                                                  const uint16_t* __restrict__ sel_perm, int sel_img_stride, const uint16_t* __restrict__ taps7,
-                                                                 HsOut O)
+                                                                 HsOut O, HsStripFuse SF)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[KP_PER_BLOCK][RAW_BYTES];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[KP_PER_BLOCK][H_ELEMS];
+    static_assert(sizeof(s_raw) >= HS_STRIPS_MAX * 4, "the strip counters of the extra workgroup live in the raw tiles");
+    const int gx = (int)gridDim.x - (SF.enabled ? 1 : 0);    // describe workgroups per image
+    if (SF.enabled && (int)blockIdx.x == gx) {               // the extra workgroup (uniform per workgroup)
+        if ((int)blockIdx.y >= O.split) describe_strips_block(lv, nlevels, sel_xys, sel_count, sel_img_stride, blockIdx.y, (int)blockIdx.y - O.split, O.cap, SF, reinterpret_cast<int*>(&s_raw[0][0]));
+        return;
+    }
     DP_T(dp0);
 #ifdef HS_DESC_PROFILE
     const int dp_slot = (blockIdx.y * gridDim.x + blockIdx.x) * KP_PER_BLOCK + (threadIdx.x >> 6);
@@ -161,7 +226,7 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
     // block -> position map gives each residue class of blockIdx.x % 8 — the blocks that share an XCD under round-robin placement — one
     // contiguous eighth of that order, so patches that overlap are fetched into one L2 at about the same time (k_describe used to read
     // 3.9x its compulsory bytes).  Results still go to the keypoint's list-order slot.  Placement only affects speed.
-    const int gx = gridDim.x, cls = blockIdx.x & 7, jcls = blockIdx.x >> 3;
+    const int cls = blockIdx.x & 7, jcls = blockIdx.x >> 3;
     const int before = cls * (gx >> 3) + min(cls, gx & 7);   // blocks in the classes below `cls`: class c has (gx >> 3) + (c < (gx & 7)) of them
     const int gs = (before + jcls) * KP_PER_BLOCK + wv;    // position in the spatial order (levels concatenated)
 
@@ -425,13 +490,14 @@ __global__ __launch_bounds__(64 * KP_PER_BLOCK) void k_describe(const HsLevel* _
 
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
-                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps)
+                        const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps, HsStripFuse strips)
 {
     int per_img = max_sel < out.cap ? max_sel : out.cap;
     dim3 grid((per_img + KP_PER_BLOCK - 1) / KP_PER_BLOCK, batch, 1);
     if (grid.x == 0) grid.x = 1;
+    if (strips.enabled) grid.x += 1;                           // the strips workgroup of every image (acts for the right images only)
     if (fast_taps)
-        hipLaunchKernelGGL(k_describe<true>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out);
+        hipLaunchKernelGGL(k_describe<true>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out, strips);
     else
-        hipLaunchKernelGGL(k_describe<false>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out);
+        hipLaunchKernelGGL(k_describe<false>, grid, dim3(64 * KP_PER_BLOCK), 0, s, d_lv, nlevels, img0, sel_xys, sel_count, sel_perm, sel_img_stride, taps7, out, strips);
 }

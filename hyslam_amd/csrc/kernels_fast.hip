@@ -121,6 +121,9 @@ struct RowGeom {            // wave-uniform description of one work item in one 
     const uint8_t* rows;    // address of (a0, iniY): first dword of the first tile row
     size_t pitch;
     bool valid, aligned;
+#if defined(HS_FAST_WAVES)
+    int level;
+#endif
 };
 
 // How the work units of a launch are spread over the work queues (host: fast_sched()).  The item list of an image is ordered expensive items
@@ -135,6 +138,11 @@ struct RowGeom {            // wave-uniform description of one work item in one 
 //           which sees the same mix of levels in the same order
 //   mode 3  anything else: the item-major list of ALL images (item 0 of every image, item 1, ...) dealt round-robin to the queues
 //   mode 0  contiguous ranges of the image-major order (HS_FAST_IMAGE_MAJOR=1: the scheme until the end of round 3, kept as a parity variant)
+//   mode 4  FOLDED STATIC schedule for small launches (at most two units per workgroup; round 4): workgroup b takes unit b of the item-major
+//           list of all images and then unit 2 * grid - 1 - b — the list is ordered expensive first, so the workgroups whose first item is the
+//           cheapest get the (cheap) second items and the heaviest items run alone; no counter, no look-ahead grab.  At one stereo pair per
+//           call the launch lasts as long as its slowest wave: with the look-ahead of the work queues the waves that started on the HEAVIEST
+//           items were the first to grab a second one (`tools/fast_b1_timeline.py`: 28.8 us span, the slowest waves all "level 7 + another")
 struct FastSched { int32_t nq_log, mode, par, par_log, per_q; };
 __device__ __forceinline__ int fast_queue_size(const FastSched& S, int qq, int total_work, int items_per_img)
 {
@@ -159,6 +167,9 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
         const int q = w / S.per_q, u = w - q * S.per_q, gidx = (u << S.nq_log) + q;      // position in the item-major list of all S.par images
         item = gidx / S.par;
         g.img = gidx - item * S.par;
+    } else if (S.mode == 4) {
+        item = w / S.par;                                            // w = position in the item-major list of all S.par images
+        g.img = w - item * S.par;
     } else {
         g.img = w / items_per_img;
         item = w - g.img * items_per_img;
@@ -170,6 +181,9 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
     g.th = it.th; g.ih = g.th - 6; g.iw = it.iw;
     g.off = it.off; g.ndw = it.ndw;
     g.valid = it.th != 0;
+#if defined(HS_FAST_WAVES)
+    g.level = it.level;
+#endif
     const uint8_t* base;
     if (it.base == nullptr) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
     else { base = it.base + (size_t)g.img * it.img_stride; g.pitch = (size_t)it.pitch; }
@@ -194,11 +208,12 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
 #define FR_STOP 99
 #endif
 #if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)   // make EXTRA=-DHS_FAST_WAVES: two real-time stamps per item and nothing else (tools/fast_wave_timeline.py)
-__device__ unsigned long long g_fr_wave[4096 * 8];           // per workgroup: first stamp, stamp after the first item, last stamp, items, longest item (10 ns ticks), its work index
-extern "C" void hs_debug_fast_waves(unsigned long long* out /*[4096 * 8]*/)
+__device__ unsigned long long g_fr_wave[4096 * 16];          // per workgroup: first stamp, stamp after the first item, last stamp, items, longest item (10 ns ticks), its work index,
+                                                             // level << 32 | corners of the FIRST item, then its phase stamps: tile staged, next item prefetched, scan A done, corners scored, NMS done
+extern "C" void hs_debug_fast_waves(unsigned long long* out /*[4096 * 16]*/)
 {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_wave), sizeof(unsigned long long) * 4096 * 8);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_wave), sizeof(unsigned long long) * 4096 * 16);
 }
 #endif
 #ifdef HS_FAST_PROFILE       // make EXTRA=-DHS_FAST_PROFILE: per-phase cycle totals over all waves (tools/fast_phase_profile.py)
@@ -215,6 +230,11 @@ extern "C" void hs_debug_fast_profile(unsigned long long* out16)
 #else
 #define FR_T(var)
 #define FR_ACC(i, a, b)
+#endif
+#if defined(HS_FAST_WAVES)
+#define FR_W(i) do { if (fr_items == 0) fr_ph[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FR_W(i) do {} while (0)
 #endif
 
 // inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, no LDS)
@@ -289,8 +309,12 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     // raw counter value -> work unit, stealing from the other queues when the home queue is exhausted; -1 = nothing left anywhere.
     // A thief first LOOKS at all eight counters with one load (lanes 0..7; plain loads do not serialise like atomics) and only then grabs
     // from the fullest queue: at the end of a launch thousands of waves would otherwise queue up failing atomics on eight addresses.
-    const bool dynamic = wpx < per_x;                            // fewer items than waves: the static first items are the whole job
+    const bool fold = S.mode == 4;                               // folded static schedule: no counters at all
+    int fold_next = -1;
+    if (fold) { const int u2 = 2 * (int)gridDim.x - 1 - (int)blockIdx.x; if (u2 < total_work) fold_next = u2; }
+    const bool dynamic = !fold && wpx < per_x;                   // fewer items than waves: the static first items are the whole job
     auto resolve = [&](uint32_t raw) -> int {
+        if (fold) { const int r = fold_next; fold_next = -1; return r; }
         if (!dynamic) return -1;
         int idx = (int)__builtin_amdgcn_readfirstlane(raw) + wpx;
         if (idx < q_size(q)) return q * per_x + idx;
@@ -306,7 +330,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         }
         return -1;
     };
-    int w = (int)(blockIdx.x >> S.nq_log) < q_size(q) ? q * per_x + (int)(blockIdx.x >> S.nq_log) : (dynamic ? resolve(grab_async(q)) : -1);
+    int w = fold ? ((int)blockIdx.x < total_work ? (int)blockIdx.x : -1)
+                 : (int)(blockIdx.x >> S.nq_log) < q_size(q) ? q * per_x + (int)(blockIdx.x >> S.nq_log) : (dynamic ? resolve(grab_async(q)) : -1);
     if (w < 0) return;
     uint32_t raw_next = dynamic ? grab_async(q) : 0u;            // the second item
 
@@ -319,6 +344,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
     const unsigned long long fr_real0 = __builtin_amdgcn_s_memrealtime();     // the 100 MHz real-time counter: the same on every CU (s_memtime is not)
     unsigned long long fr_prev = fr_real0, fr_first = 0, fr_long = 0, fr_long_w = 0, fr_items = 0;
+    unsigned fr_codes = 0;
+    unsigned long long fr_ph[6] = {};                         // first item: level << 32 | corners, phase stamps
 #endif
     hs_u32x4 pre[NL];
     RowGeom g = row_geom(items, img0, items_per_img, S, w);
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         if (!g.valid) {
             if (tid == 0) cnt_out[0] = 0;
             w = resolve(raw_next);
-            if (w >= 0) { g = row_geom(items, img0, items_per_img, S, w); prefetch(g); raw_next = grab_async(q); }      // w >= 0 implies `dynamic`
+            if (w >= 0) { g = row_geom(items, img0, items_per_img, S, w); prefetch(g); if (dynamic) raw_next = grab_async(q); }
             continue;
         }
         // ---- stage the tile
@@ -360,14 +387,16 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_FENCE();
         FR_T(t1);
         FR_ACC(0, t0, t1);
+        FR_W(1);
         const RowGeom cur = g;
         const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1;
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
         // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
         const int w_next = resolve(raw_next);
-        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, S, w_next); prefetch(g); raw_next = grab_async(q); }   // in flight during the passes
+        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, S, w_next); prefetch(g); if (dynamic) raw_next = grab_async(q); }   // in flight during the passes
         FR_T(t2);
         FR_ACC(1, t1, t2);
+        FR_W(2);
 
         const int c_first = cur.off + 3;                         // tile column of the first interior pixel
         uint32_t vmask8 = 0;                                     // this lane's pixels that are interior columns: byte j = pixel j, one bit per row of a scan block
@@ -386,6 +415,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             if (FR_STOP <= 2) { npx = n_done = 0; return; }
             FR_FENCE();
             FR_T(tc0);
+#if defined(HS_FAST_WAVES)
+            const int fr_n0 = n_done;
+#endif
             int n_corner = n_done;
             int nend = npx;                                  // list end including the re-queued pixels (below)
             for (int i0 = n_done; i0 < nend; i0 += 64) {
@@ -439,6 +471,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             FR_T(tc1);
             FR_ACC(4, tc0, tc1);
             if (FR_STOP <= 4 && FR_STOP >= 3) { npx = n_done = 0; return; }
+#if defined(HS_FAST_WAVES)
+            if (fr_items == 0) fr_codes += (unsigned)(nend - fr_n0);
+#endif
             npx = n_done = n_corner;
             FR_FENCE();
         };
@@ -570,7 +605,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 if (FR_STOP <= 1) { if (M == 0x12345u) plist[tid] = 1; continue; }      // keeps M live
                 emit_mask(M, y0, false, b);
             }
+            FR_W(3);
             corners_and_scores();
+            FR_W(4);
         }
         FR_T(t4);
         FR_ACC(2, t3, t4);                                       // scan A including corners_and_scores (4, 5 are subsets)
@@ -635,7 +672,11 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
         {
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (fr_items == 0) fr_first = now;
+            if (fr_items == 0) { fr_first = now;
+#if defined(HS_FAST_WAVES)
+                fr_ph[0] = ((unsigned long long)(unsigned)cur.level << 32) | ((unsigned long long)(fr_codes & 0xFFFFu) << 16) | (unsigned)(n_done & 0xFFFF); fr_ph[5] = now;
+#endif
+            }
             if (now - fr_prev > fr_long) { fr_long = now - fr_prev; fr_long_w = (unsigned long long)(unsigned)w | ((unsigned long long)(n_ovf > 0) << 32); }
             fr_prev = now; fr_items++;
         }
@@ -650,25 +691,26 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #endif
 #if defined(HS_FAST_PROFILE) || defined(HS_FAST_WAVES)
     if (tid == 0 && blockIdx.x < 4096) {
-        unsigned long long* o = &g_fr_wave[blockIdx.x * 8];
+        unsigned long long* o = &g_fr_wave[blockIdx.x * 16];
         o[0] = fr_real0; o[1] = fr_first; o[2] = __builtin_amdgcn_s_memrealtime(); o[3] = fr_items; o[4] = fr_long; o[5] = fr_long_w;
+#if defined(HS_FAST_WAVES)
+        for (int i = 0; i < 6; i++) o[8 + i] = fr_ph[i];
+#endif
     }
 #endif
 }
 
 // cells per work item for a level: as many as fit the tile (interior <= 4*COLS - 9 px, <= FR_MAXG), spread evenly over the row
-static int fast_rows_lc()
-{
-    static int lc = [] { const char* e = getenv("HS_FAST_COLS"); return (e && atoi(e) == 32) ? 5 : 6; }();
-    return lc;
-}
-int hs_fast_max_cell_w() { return 4 * (1 << fast_rows_lc()) - 9; }
-int hs_fast_group_cells(int wcell, int ncols)
+// Tile width: LC = 6 (64 dwords: items of <= 8 cells / 247 px of interior; the throughput shape) or LC = 5 (32 dwords: <= 119 px, two half-waves
+// on different rows).  A handle keeps BOTH item lists; the launcher picks per call (hs_api.hip: narrow items for small batches, where the
+// launch lasts as long as its slowest wave and twice as many, half as long items are what shortens it).
+int hs_fast_max_cell_w(int lc) { return 4 * (1 << lc) - 9; }
+int hs_fast_group_cells(int wcell, int ncols, int lc)
 {
     if (wcell <= 0 || ncols <= 0) return 0;
-    const int iw_max = 4 * (1 << fast_rows_lc()) - 9;
+    const int iw_max = 4 * (1 << lc) - 9;
     int gmax = std::min(FR_MAXG, iw_max / wcell);
-    if (gmax < 1) gmax = 1;                                   // cannot happen: configure() rejects wcell > hs_fast_max_cell_w()
+    if (gmax < 1) gmax = 1;                                   // cannot happen: configure() rejects wcell > hs_fast_max_cell_w(6) and builds no narrow list for wcell > hs_fast_max_cell_w(5)
     const int ngroups = (ncols + gmax - 1) / gmax;
     return (ncols + ngroups - 1) / ngroups;
 }
@@ -712,15 +754,18 @@ HsFastKnobs hs_fast_read_knobs()
     if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) k.force_scan_b = atoi(e) != 0;     // parity tests: NMS from the score tile
     if (const char* e = getenv("HS_FAST_IMAGE_MAJOR")) k.image_major = atoi(e) != 0;      // tuning / parity tests: the work units image-major whatever the batch
     if (const char* e = getenv("HS_FAST_NQ")) k.nq = atoi(e);                             // tuning / parity tests: at most this many work queues (8, 16, 32)
+    if (const char* e = getenv("HS_FAST_COLS")) k.cols = atoi(e);                         // tuning / parity tests: 32 / 64 = narrow / wide items whatever the batch (default: by batch)
+    if (const char* e = getenv("HS_FAST_NARROW_MAX")) k.narrow_max = atoi(e);             // tuning: narrow items for launches of at most this many (narrow) work items
+    if (const char* e = getenv("HS_FAST_NO_FOLD")) k.no_fold = atoi(e) != 0;              // tuning / parity tests: work queues even for launches of <= 2 units per workgroup
     return k;
 }
 
 // launch configuration shared by the launcher and by hs_fast_overflow_bytes()
 struct FastRowsCfg { int lc, tr, per_cu; uint32_t ovf_stride; FastRowsLds lds; };
-static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs)
+static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs, int lc)
 {
     FastRowsCfg c;
-    c.lc = fast_rows_lc();
+    c.lc = lc;
     const int cols = 1 << c.lc, pitch = 4 * cols + FR_PAD;
     // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
     // LDS (the lists follow) and those rows are masked out.  Template instances below.
@@ -733,7 +778,8 @@ static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs)
     constexpr int GRAN = 1280, LDS_CU = 160 * 1024;
     const int fixed = c.tr * pitch + 4 * FR_MAXG;             // pixel tile (later the score tile: rows 0..ih+1 <= th-4) + per-cell counters
     const int floor_bytes = std::max(fixed + 3 * 1024, (c.tr + 8) * pitch);   // >= 1024 list entries; the over-read of the last scan block stays inside
-    const int granules = (floor_bytes + GRAN - 1) / GRAN;
+    int granules = (floor_bytes + GRAN - 1) / GRAN;
+    while (LDS_CU / (granules * GRAN) > 16 && LDS_CU / ((granules + 1) * GRAN) >= 16) granules++;      // at most 16 workgroups per CU anyway (narrow tiles): the list takes the LDS that would stay unused
     L.pcap = ((granules * GRAN - fixed) / 3) & ~15;           // 2 bytes position + 1 byte score per entry; >= 4*cols (one tile row of pixels)
     // floor: one row step of a scan block (64 lanes x 4 pixels, whatever the tile width) must fit an empty list — the scored corners leave
     // their scores in `pscore` while the rest of the list is still being read, so the list may never run past its end
@@ -758,10 +804,14 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
     while (nblk >= 2 * HS_FAST_NQ_MAX && (nblk / 2) % HS_FAST_NQ_MAX == 0 && nblk / 2 >= total_work) nblk /= 2;   // tiny jobs: fewer idle workgroups
     return nblk;
 }
-// queue count and unit order of a launch over `batch` images (see FastSched)
-static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& knobs)
+// queue count and unit order of a launch over `batch` images with `nblk` workgroups (see FastSched)
+static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& knobs, int nblk)
 {
     FastSched S{};
+    if (!knobs.no_fold && !knobs.image_major && batch > 0 && (long long)items_per_img * batch <= 2LL * nblk) {
+        S.nq_log = 3; S.mode = 4; S.par = batch; S.per_q = items_per_img * batch;
+        return S;
+    }
     int nq_log = 3;
     const int want = knobs.nq > 0 ? knobs.nq : HS_FAST_NQ_MAX;
     while ((2 << nq_log) <= want) nq_log++;
@@ -778,23 +828,27 @@ static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& kno
 }
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
 {
-    const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
-    return (size_t)4 * HS_FAST_QUEUE_DWORDS * 4 + (size_t)2 * fast_rows_grid(c, total_work_max) * c.ovf_stride * 4;      // two launches may be in flight
+    size_t spill = 0;                                             // either tile width may be launched on this workspace
+    for (int lc = 5; lc <= 6; lc++) {
+        const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs, lc);
+        spill = std::max(spill, (size_t)2 * fast_rows_grid(c, total_work_max) * c.ovf_stride * 4);      // two launches may be in flight
+    }
+    return (size_t)4 * HS_FAST_QUEUE_DWORDS * 4 + spill;
 }
 
 static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int spill_slot, int items_all, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int spill_slot, int items_all, int lc_in, hipStream_t s)
 {
     (void)max_wcell;
-    const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs);
+    const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs, lc_in);
     const FastRowsLds& L = c.lds;
     const int lc = c.lc, tr = c.tr;
     const int total_work = items_per_img * batch;
     if (total_work <= 0) return false;
     const int nblk = fast_rows_grid(c, total_work);
     const int force_scan_b = knobs.force_scan_b;
-    const FastSched S = fast_sched(batch, items_per_img, knobs);
+    const FastSched S = fast_sched(batch, items_per_img, knobs, nblk);
     const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, S)
@@ -808,10 +862,10 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 // so the caller advances its epoch only for launches that happened
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int item_count, int spill_slot, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int item_count, int spill_slot, int lc, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0 || item_count <= 0) return false;
     return launch_fast_rows(d_items, img0, batch, total_cells, item_count, fast_th, cand, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs,
-                            item_first, spill_slot, items_per_img, s);
+                            item_first, spill_slot, items_per_img, lc, s);
 }

@@ -18,17 +18,12 @@
 // Right keypoints binned into 32-row strips once per pair: a right keypoint lists itself in every strip its row band
 // [floor(y-r), ceil(y+r)] touches (1-2 strips), so a left keypoint at row v only scans strip v>>5 — ~100 candidates instead of all
 // 2000 (the reference's per-row table, Stereomatcher.cpp:46-63, at 1/32 of its size).  The exact band test is repeated per candidate.
-#define STRIP_SHIFT 5
+#define STRIP_SHIFT HS_STRIP_SHIFT
 
 // One workgroup per pair: the strip counters live in LDS (a slot is an LDS atomic away, not a round trip to L2), every right keypoint's
 // record is loaded up front, and the counters are written out whole, so nothing has to be zeroed between calls.
 #define STRIPS_T 1024
-#define STRIPS_MAX 2048            // 65536 rows / 32
-// A strip entry carries everything the candidate test needs, so that the matcher's chain of dependent loads is entry -> descriptor instead of
-// index -> keypoint record -> descriptor: the right keypoint's u, its octave, its index and its row band CUT TO THE STRIP (two 5-bit row numbers:
-// a left keypoint that scans strip s has its row in [32 s, 32 s + 31], so the cut band decides exactly what the whole band decides).
-struct __attribute__((aligned(16))) HsStripEntry { float uR; int32_t octave; uint32_t idx_band; uint32_t _pad; };   // idx_band = iR | lo << 16 | hi << 24
-static_assert(sizeof(HsStripEntry) == HS_STRIP_ENTRY_BYTES, "hs_api.hip sizes the strip lists with HS_STRIP_ENTRY_BYTES");
+#define STRIPS_MAX HS_STRIPS_MAX   // 65536 rows / 32 (HsStripEntry: hs_internal.h)
 __global__ __launch_bounds__(STRIPS_T) void k_stereo_strips(const hs_keypoint* __restrict__ kpsR, const int32_t* __restrict__ nRs, int cap,
                                                             float size_ref, int n_rows, int n_strips,
                                                             int32_t* __restrict__ strip_count, HsStripEntry* __restrict__ strip_list)
@@ -258,4 +253,22 @@ void hs_launch_stereo_median(const int32_t* nL, int pairs, int cap, float* uRigh
 {
     if (pairs <= 0 || cap <= 0) return;
     hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, nL, cap, uRight, depth, best_dist, strip_count, hs_stereo_strips(n_rows));
+}
+
+// the matcher alone, on strips that the describe launch of the stereo front end has already binned (HsStripFuse)
+void hs_launch_stereo_match_only(const hs_keypoint* kpsL, const uint8_t* descL, const int32_t* nL,
+                                 const hs_keypoint* kpsR, const uint8_t* descR, const int32_t* nR,
+                                 int pairs, int cap, hs_stereo_params sp, float* uRight, float* depth, int32_t* best_dist,
+                                 const int32_t* strip_count, const void* strip_list, hipStream_t s)
+{
+    if (pairs <= 0 || cap <= 0) return;
+    const HsStripEntry* const sl = reinterpret_cast<const HsStripEntry*>(strip_list);
+    const int n_strips = hs_stereo_strips(sp.n_rows);
+    if ((size_t)pairs * cap >= (size_t)8 * 2048) {
+        dim3 grid((cap + 7) / 8, pairs, 1);
+        hipLaunchKernelGGL(k_stereo_match<2>, grid, dim3(256), 0, s, strip_count, sl, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    } else {
+        dim3 grid((cap + 3) / 4, pairs, 1);
+        hipLaunchKernelGGL(k_stereo_match<1>, grid, dim3(256), 0, s, strip_count, sl, n_strips, kpsL, descL, nL, kpsR, descR, nR, cap, sp, uRight, depth, best_dist);
+    }
 }

@@ -71,6 +71,62 @@ def all_gather_records(record, group=None):
     return out
 
 
+def checksum64(data):
+    """64-bit checksum (blake2b-8, as a non-negative Python int < 2^63) of a numpy array / bytes: what the ranks exchange to compare what they hold"""
+    import hashlib
+    b = data if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data).tobytes()
+    return int.from_bytes(hashlib.blake2b(b, digest_size=8).digest(), "little") >> 1
+
+
+def verify_exchange(gathered, local_count, rank, world, match_outputs=None, group=None):
+    """After a cross-camera step: do all ranks hold the SAME gathered records, and is record r really rank r's frame?
+
+    gathered       torch uint8 [world, record_bytes] on this rank (any device)
+    local_count    the number of keypoints this rank extracted in the step the records belong to
+    match_outputs  optional tensors / arrays (this rank's matcher outputs): their checksum is gathered and reported per rank
+
+    Every rank computes a 64-bit checksum of each gathered record, the checksums are all-gathered (torch.distributed, backend of the caller's
+    process group: RCCL on GPUs, gloo in the CPU tests) and compared: `records_identical` = every rank saw the same bytes for every record,
+    `counts_match` = record r's header count equals the count rank r reports for itself.  Returns a dict (the same on every rank);
+    `ranks_consistent` is the conjunction.  SURVEY.md C5: "identical match lists on every rank" needs identical inputs on every rank first."""
+    import torch
+    import torch.distributed as dist
+    g = gathered.detach().cpu().numpy()
+    sums = [checksum64(g[r]) for r in range(world)]
+    counts = [int(g[r, :4].view(np.int32)[0]) for r in range(world)]
+    msum = 0
+    if match_outputs is not None:
+        import hashlib
+        h = hashlib.blake2b(digest_size=8)
+        for t in match_outputs:
+            h.update(np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t).tobytes())
+        msum = int.from_bytes(h.digest(), "little") >> 1
+    mine = torch.tensor(sums + [int(local_count), msum], dtype=torch.int64)
+    if world > 1:
+        dev = gathered.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        allv = torch.empty((world, world + 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allv.view(-1), mine.to(dev), group=group)
+        allv = allv.cpu()
+    else:
+        allv = mine.view(1, -1)
+    rec = allv[:, :world]
+    records_identical = bool((rec == rec[0:1]).all().item())
+    own_counts = allv[:, world].tolist()
+    counts_match = records_identical and counts == own_counts
+    bad = [r for r in range(world) if not bool((rec[r] == rec[0]).all().item())]
+    return {"ranks_consistent": bool(records_identical and counts_match), "records_identical": records_identical, "counts_match": bool(counts_match),
+            "record_counts": counts, "rank_counts": own_counts, "ranks_that_differ_from_rank0": bad,
+            "record_checksums": ["%016x" % v for v in rec[0].tolist()], "match_checksums": ["%016x" % v for v in allv[:, world + 1].tolist()]}
+
+
+def comm_available():
+    """(ok, reason): can this process create an hs_comm communicator (librccl loads)?  Non-collective — ask on every rank before RecordExchange."""
+    from . import _native as N
+    L = N.lib()
+    ok = L.hs_comm_available() == N.HS_OK
+    return ok, ("" if ok else L.hs_comm_unavailable_reason().decode())
+
+
 class RecordExchange:
     """The exchange through the C ABI (hs_comm_*: RCCL's all-gather without torch).  One rank calls unique_id() and hands the 128 bytes to
     the others (any channel: a file, a socket, torch.distributed.broadcast); every rank then builds RecordExchange(extractor, id, world, rank),

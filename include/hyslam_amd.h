@@ -365,9 +365,16 @@ int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_s
  * (NULL = the handle's stream): d_gathered [world][record_bytes]; in place when d_record == d_gathered + rank * record_bytes.  With the
  * extraction before it and the matcher after it on the same stream a config-5 step needs no event and no host synchronisation.
  * librccl is loaded on first use (dlopen): HS_ERR_NO_DEVICE when it or a GPU is missing.  Asynchronous.
- * Destroy a communicator BEFORE the handle it was created on. */
+ * hs_comm_available(): non-collective probe (HS_OK / HS_ERR_NO_DEVICE, reason in hs_comm_unavailable_reason()) — ask it on every rank before
+ * the first hs_comm_create, which blocks until all ranks arrive, and fall back together when any rank cannot.
+ * Lifetime: a communicator BORROWS its handle (device, stream).  hs_orb_destroy on a handle that still has communicators is deferred: the
+ * handle is only marked and the last hs_comm_destroy frees it, so the two destroy calls are safe in either order; the handle must not be
+ * used for anything else after its hs_orb_destroy.  hs_orb_borrowers() = communicators alive on the handle. */
 #define HS_COMM_ID_BYTES 128
 typedef struct hs_comm hs_comm;
+int  hs_comm_available(void);
+const char* hs_comm_unavailable_reason(void);
+int  hs_orb_borrowers(const hs_orb* h);
 int  hs_comm_get_unique_id(uint8_t* id /* [HS_COMM_ID_BYTES] */);
 int  hs_comm_create(hs_orb* h, const uint8_t* id, int world, int rank, hs_comm** out);
 void hs_comm_destroy(hs_comm* c);

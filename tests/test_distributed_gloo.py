@@ -122,3 +122,61 @@ def test_spawned_bench_fails_fast_when_a_rank_dies():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "a rank failed" in r.stderr, r.stdout + r.stderr
     assert time.time() - t0 < 120
+
+
+def test_c5_self_check_over_gloo_and_a_corrupted_rank():
+    """bench.py --config c5 verifies what it measured: every rank checksums every gathered record, the checksums are all-gathered and the job
+    fails unless all ranks hold the same bytes and record r carries rank r's own count (hyslam_amd.distributed.verify_exchange).  Here over gloo
+    at world 2 through bench.py's own spawn path (--dry-run: stand-in records, the real all-gather and check): consistent ranks pass, and when one
+    rank's copy of the gathered buffer is corrupted the line says so and the job exits non-zero."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HS_BENCH_TEST_CORRUPT_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--config", "c5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ranks_consistent"] is True and line["exchange_check"]["record_counts"] == [40, 41] == line["exchange_check"]["rank_counts"]
+    for bad in ("0", "1"):
+        r = subprocess.run(cmd, env=dict(env, HS_BENCH_TEST_CORRUPT_RANK=bad), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0, r.stdout + r.stderr
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["ranks_consistent"] is False and line["exchange_check"]["records_identical"] is False
+        assert line["exchange_check"]["ranks_that_differ_from_rank0"] == [1]          # two ranks: whichever copy is corrupt, rank 1's differs from rank 0's
+
+
+def _verify_worker(rank, world, port, q, lie):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from hyslam_amd import distributed as D
+    from hyslam_amd._native import KP_DTYPE
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(9 + rank)
+    n = 20 + 3 * rank
+    k = np.zeros(n, KP_DTYPE); k["x"] = rng.random(n)
+    g = D.all_gather_records(torch.from_numpy(D.pack_record(k, rng.integers(0, 256, (n, 32), dtype=np.uint8), 32)))
+    # `lie`: rank 1 claims another local count than its record carries (a stale buffer: the step alternates two instants for exactly this)
+    q.put((rank, D.verify_exchange(g, n + (lie if rank == 1 else 0), rank, world, match_outputs=(torch.arange(4) + rank,))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lie", [0, 1])
+def test_verify_exchange_counts(lie):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, q, lie)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1], "the verdict itself must be the same on every rank"
+    assert res[0]["records_identical"] is True and res[0]["record_counts"] == [20, 23]
+    assert res[0]["ranks_consistent"] is (lie == 0) and res[0]["counts_match"] is (lie == 0)
+    assert res[0]["match_checksums"][0] != res[0]["match_checksums"][1]

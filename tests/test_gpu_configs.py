@@ -289,9 +289,14 @@ def test_stereo_match_batch_device(gpu):
     run([2, 0, 1] * 3, 1999, 600)
 
 
-def test_stereo_front_end_nine_pairs_one_call(gpu):
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_stereo_front_end_nine_pairs_one_call(gpu, fuse, monkeypatch):
     """hs_stereo_frontend_batch_device as the bench drives it — several pairs in ONE call: 9 distinct 640x480 pairs at 2000 features put
-    pairs * cap over the matcher's two-keypoints-per-wavefront threshold; every pair's keypoints, descriptors, uRight and depth vs the oracle"""
+    pairs * cap over the matcher's two-keypoints-per-wavefront threshold; every pair's keypoints, descriptors, uRight and depth vs the oracle.
+    fuse = 1 (the default): the right keypoints are binned into the strips by an extra workgroup of the describe launch (two stereo launches);
+    fuse = 0: a separate k_stereo_strips launch (three).  The call is repeated on the same handle (nothing may be left over between calls), then
+    run with one pair (one left keypoint per wavefront) and with identical views (median 0: everything is rejected)."""
+    monkeypatch.setenv("HS_STEREO_FUSE", fuse)
     W, H, P = 640, 480, 9
     p = oracle.default_params(2000)
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=2000))
@@ -305,22 +310,31 @@ def test_stereo_front_end_nine_pairs_one_call(gpu):
     dk = [hipmem.DevBuf(P * kb) for _ in range(2)]; dd = [hipmem.DevBuf(P * db) for _ in range(2)]; dn = [hipmem.DevBuf(P * 4) for _ in range(2)]
     du, dz = hipmem.DevBuf(P * cap * 4), hipmem.DevBuf(P * cap * 4)
     sp = N.StereoParams(500.0, 60.0, H, 100.0, 50.0, 31.0)
-    ex.stereo_frontend_batch_device(dl.ptr, dr.ptr, P, W, H, W, W * H, dk[0].ptr, dd[0].ptr, dn[0].ptr, dk[1].ptr, dd[1].ptr, dn[1].ptr, cap, sp, du.ptr, dz.ptr, 0)
-    ex.synchronize()
-    nL, nR = dn[0].to_numpy(np.int32, P), dn[1].to_numpy(np.int32, P)
-    kL = dk[0].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap); kR = dk[1].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap)
-    dL = dd[0].to_numpy(np.uint8, P * db).reshape(P, cap, 32); dR = dd[1].to_numpy(np.uint8, P * db).reshape(P, cap, 32)
-    u, z = du.to_numpy(np.float32, P * cap).reshape(P, cap), dz.to_numpy(np.float32, P * cap).reshape(P, cap)
     osp = oracle.stereo_params(fx=500.0, mbf=60.0, n_rows=H)
-    matched = 0
-    for i, (L, R) in enumerate(pairs):
-        okL, odL, okR, odR, ou, oz = oracle.stereo_frontend(p, osp, L, R)
-        assert nL[i] == len(okL) and nR[i] == len(okR), i
-        assert kL[i, :nL[i]].tobytes() == okL.tobytes() and kR[i, :nR[i]].tobytes() == okR.tobytes(), i
-        assert np.array_equal(dL[i, :nL[i]], odL) and np.array_equal(dR[i, :nR[i]], odR), i
-        assert np.array_equal(u[i, :nL[i]], ou) and np.array_equal(z[i, :nL[i]], oz), i
-        matched += int((oz > 0).sum())
-    assert matched > 50 * P
+    ref = [oracle.stereo_frontend(p, osp, L, R) for L, R in pairs]
+    ref_same = oracle.stereo_frontend(p, osp, pairs[0][0], pairs[0][0])
+
+    def run(lp, rp, npairs, expect):
+        ex.stereo_frontend_batch_device(lp, rp, npairs, W, H, W, W * H, dk[0].ptr, dd[0].ptr, dn[0].ptr, dk[1].ptr, dd[1].ptr, dn[1].ptr, cap, sp, du.ptr, dz.ptr, 0)
+        ex.synchronize()
+        nL, nR = dn[0].to_numpy(np.int32, P), dn[1].to_numpy(np.int32, P)
+        kL = dk[0].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap); kR = dk[1].to_numpy(N.KP_DTYPE, P * cap).reshape(P, cap)
+        dL = dd[0].to_numpy(np.uint8, P * db).reshape(P, cap, 32); dR = dd[1].to_numpy(np.uint8, P * db).reshape(P, cap, 32)
+        u, z = du.to_numpy(np.float32, P * cap).reshape(P, cap), dz.to_numpy(np.float32, P * cap).reshape(P, cap)
+        matched = 0
+        for i, (okL, odL, okR, odR, ou, oz) in enumerate(expect):
+            assert nL[i] == len(okL) and nR[i] == len(okR), i
+            assert kL[i, :nL[i]].tobytes() == okL.tobytes() and kR[i, :nR[i]].tobytes() == okR.tobytes(), i
+            assert np.array_equal(dL[i, :nL[i]], odL) and np.array_equal(dR[i, :nR[i]], odR), i
+            assert np.array_equal(u[i, :nL[i]], ou) and np.array_equal(z[i, :nL[i]], oz), i
+            matched += int((oz > 0).sum())
+        return matched
+
+    assert run(dl.ptr, dr.ptr, P, ref) > 50 * P
+    assert run(dl.ptr, dr.ptr, P, ref) > 50 * P                       # again on the same handle
+    assert run(dl.ptr, dr.ptr, 1, ref[:1]) > 50                       # one pair: one left keypoint per wavefront
+    assert run(dl.ptr, dl.ptr, 1, [ref_same]) == 0                    # identical views: median 0, every match rejected (:146-155)
+    assert run(dl.ptr + 3 * W * H, dr.ptr + 3 * W * H, 2, ref[3:5]) > 100
 
 
 def test_reserve_failure_leaves_handle_usable(gpu):

@@ -44,8 +44,34 @@ def stereo(name, seed, w, h, nfeat, fx):
     print(name, len(kL), len(kR), int((depth > 0).sum()))
 
 
+def bench_c2(name, ranks=8, w=1920, h=1080, nfeat=2000):
+    """bench.py's own workload (BASELINE C2): sha256 of the oracle's outputs for pair 0 of every rank 0..7 (`synth_stereo_pair(1000 + 97 * rank,
+    1920, 1080)`, fx = 1050, mbf = fx * 0.12).  bench.py hashes what ITS timed loop left in the output buffers of pair 0 the same way and prints
+    `parity_checksum_ok` — data only: the oracle never travels into the bench's measured path."""
+    import json
+    p = oracle.default_params(nfeat)
+    sp = oracle.stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=h)
+    out = {"workload": "bench.py C2, pair 0 of rank r = synth_stereo_pair(1000 + 97 r, %d, %d), %d features, fx 1050, mbf 126" % (w, h, nfeat),
+           "hash": "sha256 over kL[:nL].tobytes() + dL[:nL] + kR[:nR] + dR[:nR] + uRight[:nL] + depth[:nL] (hs_keypoint records, uint8 descriptors, float32)",
+           "ranks": {}}
+    for r in range(ranks):
+        L, R = synth_stereo_pair(1000 + 97 * r, w, h)
+        kL, dL, kR, dR, uR, depth = oracle.stereo_frontend(p, sp, L, R)
+        hsh = hashlib.sha256()
+        for a in (kL, dL, kR, dR, uR, depth):
+            hsh.update(np.ascontiguousarray(a).tobytes())
+        out["ranks"][str(r)] = {"seed": 1000 + 97 * r, "left_sha256": sha(L), "nL": len(kL), "nR": len(kR), "stereo_matches": int((depth > 0).sum()),
+                                "outputs_sha256": hsh.hexdigest()}
+        print(name, r, len(kL), len(kR), int((depth > 0).sum()))
+    json.dump(out, open(os.path.join(OUT, name + ".json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "bench":
+        bench_c2("bench_c2_seed1000")
+        sys.exit(0)
     mono("c1_mono_640x480_1000", 1, 640, 480, 1000, 1.2)          # BASELINE.json configs[0]
     mono("imaging_800x600_1500_s14", 4, 800, 600, 1500, 1.4)      # "Imaging" profile: scale 1.4 (config/slam_feature_config.yaml:22-29)
     stereo("stereo_640x480_1000", 3, 640, 480, 1000, 500.0)
+    bench_c2("bench_c2_seed1000")
