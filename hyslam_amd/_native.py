@@ -78,7 +78,7 @@ EXPORTS = [
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
     "hs_comm_available", "hs_comm_unavailable_reason", "hs_orb_borrowers", "hs_comm_get_unique_id", "hs_comm_create", "hs_comm_destroy", "hs_comm_world", "hs_comm_rank", "hs_comm_last_error", "hs_comm_allgather_records",
     "hs_orb_stage_launches", "hs_orb_profile_begin", "hs_orb_profile_pause", "hs_orb_profile_end", "hs_debug_stream_copy",
-    "hs_orb_debug_level", "hs_orb_debug_candidates", "hs_orb_debug_selected",
+    "hs_orb_debug_level", "hs_orb_set_debug", "hs_orb_debug_candidates", "hs_orb_debug_selected",
 ]
 
 _lib = None
@@ -207,6 +207,7 @@ def lib():
     L.hs_orb_profile_pause.argtypes = [vp]
     L.hs_orb_profile_end.argtypes = [vp, vp, vp]
     L.hs_orb_debug_level.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, vp]
+    L.hs_orb_set_debug.argtypes = [vp, C.c_int]
     L.hs_orb_debug_candidates.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.hs_orb_debug_selected.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     _lib = L

@@ -53,6 +53,15 @@ struct hs_orb {
     uint8_t* d_pyr = nullptr; size_t pyr_bytes = 0;
     int16_t* d_tables = nullptr;
     uint8_t* d_qt_tabs = nullptr;      // geometric-key tables of the count-domain quadtree (hs_quadtree_build_tables)
+    // round 4: the FAST kernel computes the candidates' geometric keys and leaves their histogram + the best candidate per deepest cell in global
+    // memory (HsFastQt, HsLevel::qt_hist_off): u16 key tables, the per-level records, the two arrays ([batch][stride]; all zero between calls:
+    // the quadtree kernel zeroes what it consumes)
+    uint16_t* d_qkeys = nullptr; HsFastQt* d_fast_qt = nullptr;
+    uint32_t* d_qhist = nullptr; unsigned long long* d_qbest = nullptr; uint32_t qhist_stride = 0, qbest_stride = 0;
+    int fast_keys_levels = HS_MAX_LEVELS;   // HS_FAST_KEYS_LEVELS (read once; tuning): only the levels 0 .. n-1 get keys
+    int fast_keys_max_batch = 16;      // HS_FAST_KEYS_MAX_BATCH (read once): calls of more frames than this run without the keys (see run_extract)
+    bool fast_keys = true;             // HS_FAST_KEYS=0 (read once): the quadtree kernel gathers the candidates and computes the keys itself (the scheme until round 3)
+    bool keep_points = false;          // hs_orb_set_debug(h, 1): the quadtree kernel also gathers the candidates into the dense point arrays (hs_orb_debug_candidates reads them)
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
     std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
     std::vector<HsPyrChain> pyr_chain; // [level]: kernel argument of the chain launch that starts at this level (HsLevel::chain_n levels)
@@ -123,6 +132,8 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_tables); h->d_tables = nullptr;
     hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear();
     hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
+    hipFree(h->d_qkeys); h->d_qkeys = nullptr; hipFree(h->d_fast_qt); h->d_fast_qt = nullptr;
+    hipFree(h->d_qhist); h->d_qhist = nullptr; hipFree(h->d_qbest); h->d_qbest = nullptr; h->qhist_stride = h->qbest_stride = 0;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_items_n); h->d_fast_items_n = nullptr; h->fast_items_n = 0;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
@@ -271,6 +282,41 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         HIP_TRY(h, hipMalloc(&h->d_qt_tabs, std::max<size_t>(qblob.size() + 16, 256)));
         if (!qblob.empty()) HIP_TRY(h, hipMemcpy(h->d_qt_tabs, qblob.data(), qblob.size(), hipMemcpyHostToDevice));
         for (int l = 0; l < L; l++) if (has[l]) { h->lv[l].qt_xtab = h->d_qt_tabs + xo[l]; h->lv[l].qt_ytab = h->d_qt_tabs + yo2[l]; }
+        // the FAST kernel's side of the same keys (HsFastQt): u16 tables  xkey[x] = root(x) << 2 DH | spread(xtab[x]),  ykey[y] = spread(ytab[y]) << 1,
+        // padded by 512 entries, and this level's place in the per-image histogram / best-candidate arrays
+        auto spread = [](uint32_t v) { v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u; return v; };
+        std::vector<uint16_t> keys; std::vector<HsFastQt> fq(L, HsFastQt{});
+        std::vector<size_t> kx(L, 0), ky(L, 0);
+        uint32_t hoff = 0, boff = 0;
+        for (int l = 0; l < L; l++) {
+            HsLevel& V = h->lv[l];
+            V.qt_hist_off = V.qt_best_off = 0xFFFFFFFFu;
+            // (HS_FAST_KEYS_LEVELS: only levels 0 .. n-1.  Measured at one 1080p pair per call, quadtree us for n = 0 / 1 / 2 / 3 / 8: 35.1 / 32.6 /
+            // 31.4 / 30.8 / 24.8 — every level's workgroup is about as long as level 0's, the fixed block-wide steps dominate — so it is all or nothing.)
+            if (!has[l] || !h->fast_keys || l >= h->fast_keys_levels) continue;
+            const int DH = V.n_ini <= 2 ? 6 : 5, ncell = V.n_ini << (2 * DH);
+            kx[l] = keys.size(); keys.resize(keys.size() + (size_t)V.qt_w + 1 + 512, 0);
+            for (int x = 0; x <= V.qt_w; x++) {
+                int r = 0;
+                for (int i = 1; i < V.n_ini; i++) r += x >= V.qt_rbound[i];
+                keys[kx[l] + x] = (uint16_t)(((uint32_t)r << (2 * DH)) | spread(qblob[xo[l] + x]));
+            }
+            ky[l] = keys.size(); keys.resize(keys.size() + (size_t)V.qt_h + 1 + 512, 0);
+            for (int y = 0; y <= V.qt_h; y++) keys[ky[l] + y] = (uint16_t)(spread(qblob[yo2[l] + y]) << 1);
+            V.qt_hist_off = hoff; V.qt_best_off = boff;
+            hoff += (uint32_t)(ncell / 2); boff += (uint32_t)ncell;
+            fq[l].hist_off = V.qt_hist_off; fq[l].best_off = V.qt_best_off; fq[l].enabled = 1;
+        }
+        h->qhist_stride = hoff; h->qbest_stride = boff;
+        HIP_TRY(h, hipMalloc(&h->d_qkeys, std::max<size_t>(keys.size() * 2 + 16, 256)));
+        if (!keys.empty()) HIP_TRY(h, hipMemcpy(h->d_qkeys, keys.data(), keys.size() * 2, hipMemcpyHostToDevice));
+        for (int l = 0; l < L; l++) if (fq[l].enabled) { fq[l].xkey = h->d_qkeys + kx[l]; fq[l].ykey = h->d_qkeys + ky[l]; }
+        HIP_TRY(h, hipMalloc(&h->d_fast_qt, sizeof(HsFastQt) * HS_MAX_LEVELS));
+        HIP_TRY(h, hipMemcpy(h->d_fast_qt, fq.data(), sizeof(HsFastQt) * L, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc(&h->d_qhist, std::max<size_t>((size_t)hoff * batch * 4, 256)));
+        HIP_TRY(h, hipMalloc(&h->d_qbest, std::max<size_t>((size_t)boff * batch * 8, 256)));
+        HIP_TRY(h, hipMemset(h->d_qhist, 0, std::max<size_t>((size_t)hoff * batch * 4, 256)));
+        HIP_TRY(h, hipMemset(h->d_qbest, 0, std::max<size_t>((size_t)boff * batch * 8, 256)));
     }
     {   // which level pairs the fused pyramid kernel can produce (decided on the host copies of the tables)
         std::vector<const int16_t*> xt(L, nullptr), yo(L, nullptr);
@@ -434,6 +480,10 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     // 2: 16 029 / 15 642, 4: 23 004 / 22 660, 8: 32 657 / 33 240, 16: 40 917 / 41 507 — from ~18 k items on the wide ones win (fewer, fuller tiles).  HS_FAST_COLS = 32 / 64 forces one list, HS_FAST_NARROW_MAX moves the threshold.
     const int narrow_max = h->fast_knobs.narrow_max > 0 ? h->fast_knobs.narrow_max : 18000;
     const bool narrow = h->fast_items_n > 0 && (h->fast_knobs.cols == 32 || (h->fast_knobs.cols != 64 && (long long)h->fast_items_n * batch <= narrow_max));
+    // Keys by batch as well: the FAST kernel's two global atomics per candidate cost it 5 % at 16 pairs per call (0.162 -> 0.170 ms) and buy the
+    // quadtree launch 4 us there (its 256 workgroups fill the chip either way); at one pair per call they cost 1 us and buy 10 (35.1 -> 24.8 us: the
+    // level-0 workgroup no longer gathers 5 000 records on one CU).  Both arrays are zero between calls whatever the mode, so the mode may change per call.
+    const bool use_keys = h->fast_keys && h->d_fast_qt != nullptr && batch <= h->fast_keys_max_batch;
     const std::vector<HsLevel>& lvh = narrow ? h->lv_n : h->lv;
     const HsLevel* const d_lv = h->d_lv + (narrow ? L : 0);
     const HsFastItem* const d_items = narrow ? h->d_fast_items_n : h->d_fast_items;
@@ -445,11 +495,13 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
         // enqueued without error; after a failed launch all sets are zeroed again so that the next one starts from a known state
         const bool launched = hs_launch_fast(d_lv, d_items, L, img0, batch, h->total_cells, n_items, h->p.fast_threshold,
                                              h->d_cand, h->d_cell_count, h->cand_img_stride, h->max_wcell, h->max_hcell, h->d_fast_ovf, h->fast_epoch, h->fast_knobs,
-                                             item_first, item_count, spill_slot, lc, st);
+                                             item_first, item_count, spill_slot, lc, use_keys ? h->d_fast_qt : nullptr, h->d_qhist, h->d_qbest, h->qhist_stride, h->qbest_stride, st);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             (void)hipDeviceSynchronize();
             (void)hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4);
+            if (h->d_qhist) (void)hipMemset(h->d_qhist, 0, (size_t)h->qhist_stride * h->batch_cap * 4);      // a launch that died half-way may have left keys behind
+            if (h->d_qbest) (void)hipMemset(h->d_qbest, 0, (size_t)h->qbest_stride * h->batch_cap * 8);
             return fail(h, HS_ERR_HIP, std::string("FAST launch: ") + hipGetErrorString(e));
         }
         if (launched) h->fast_epoch++;
@@ -458,7 +510,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     auto quadtree = [&](int level_first, int level_count, hipStream_t st) {
         hs_launch_quadtree(d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
                            h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0,
-                           level_first, level_count, st);
+                           level_first, level_count, use_keys ? h->d_qhist : nullptr, h->d_qbest, h->qhist_stride, h->qbest_stride, h->keep_points ? 1 : 0, st);
     };
     if (split) {
         if (!h->s_aux) {
@@ -596,6 +648,9 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->fast_knobs = hs_fast_read_knobs();
     { const char* e = getenv("HS_PYRAMID_NO_FUSE"); h->no_fuse = e && atoi(e) != 0; }
     { const char* e = getenv("HS_STEREO_FUSE"); h->stereo_fuse = !(e && atoi(e) == 0); }
+    { const char* e = getenv("HS_FAST_KEYS"); h->fast_keys = !(e && atoi(e) == 0); }
+    { const char* e = getenv("HS_FAST_KEYS_LEVELS"); if (e && atoi(e) > 0) h->fast_keys_levels = atoi(e); }
+    { const char* e = getenv("HS_FAST_KEYS_MAX_BATCH"); if (e && atoi(e) >= 0) h->fast_keys_max_batch = atoi(e); }
     { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
@@ -1590,9 +1645,19 @@ int hs_orb_debug_level(hs_orb* h, int image, int level, uint8_t* out, size_t cap
     return HS_OK;
 }
 
+int hs_orb_set_debug(hs_orb* h, int on)
+{
+    if (!h) return HS_ERR_INVALID;
+    h->keep_points = on != 0;
+    if (h->lane2) h->lane2->keep_points = h->keep_points;
+    return HS_OK;
+}
+
 int hs_orb_debug_candidates(hs_orb* h, int image, int level, int32_t* xys, int cap, int32_t* n)
 {
     if (!h) return HS_ERR_INVALID;
+    if (h->fast_keys && h->last_batch <= h->fast_keys_max_batch && !h->keep_points)
+        return fail(h, HS_ERR_INVALID, "hs_orb_debug_candidates: call hs_orb_set_debug(h, 1) before the extraction (the candidates are only gathered into a dense list in debug mode)");
     if (!xys || !n || image < 0 || image >= h->last_batch || level < 0 || level >= h->p.nlevels) return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());

@@ -39,6 +39,11 @@ struct HsLevel {
     const uint8_t* qt_xtab;        // [qt_w + 1], 16-byte aligned, padded to a multiple of 16
     const uint8_t* qt_ytab;        // [qt_h + 1]
     int32_t qt_rbound[8];
+    // round 4: the FAST kernel computes every candidate's geometric key itself and leaves, per (image, level), the HISTOGRAM of the keys (u16
+    // counters packed in u32) and the BEST candidate of every deepest cell (u64 keys) in global memory: the quadtree kernel starts from them
+    // instead of gathering the candidates.  Offsets of this level inside one image's arrays (entries); 0xFFFFFFFF = the level has no tables.
+    uint32_t qt_hist_off;          // in u32 (= 2 cells)
+    uint32_t qt_best_off;          // in u64 (= 1 cell)
     // candidate / selection storage (entries, per image)
     int32_t cand_cap;
     int32_t sel_cap;
@@ -77,6 +82,13 @@ struct HsFastItem {
     uint32_t _pad;
 };
 static_assert(sizeof(HsFastItem) == 64, "HsFastItem is fetched as one 64-byte record");
+
+// Per-level record of the FAST kernel's key computation (one 32-byte scalar load per work item): u16 tables with the x part of a candidate's
+// geometric key per pixel column — root << 2 DH | the column's cell index at depth DH with its bits spread to the even positions — and the y part
+// per pixel row (bits spread to the odd positions), so that key = xkey[x] | ykey[y] (k_quadtree's geo_key, kernels_quadtree.hip); both padded
+// by 512 entries so that a work item's slice can be fetched without clamping.
+struct HsFastQt { const uint16_t* xkey; const uint16_t* ykey; uint32_t hist_off, best_off; int32_t enabled, _r; };
+static_assert(sizeof(HsFastQt) == 32, "scalar-load record");
 
 // candidate slots per FAST cell: 3x3 NMS leaves at most one survivor per 2x2 block; rounded to 4 so that a cell's records start on
 // a 16-byte boundary (cand_off is a multiple of 4 entries)
@@ -203,7 +215,8 @@ bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels,
                     uint2* cand /*{y<<16|x, score<<24|cell} per slot*/, int32_t* cell_count, uint64_t cand_img_stride,
                     int max_wcell, int max_hcell, uint32_t* overflow /*hs_fast_overflow_bytes(), zero-initialised*/, uint32_t epoch /*launch counter of the handle*/,
                     const HsFastKnobs& knobs, int item_first, int item_count /*the launch covers items [first, first + count) of every image*/,
-                    int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, int lc /*6 / 5: the tile width `d_items` was built for*/, hipStream_t s);
+                    int spill_slot /*0 / 1: which half of the spill areas (two launches may be in flight)*/, int lc /*6 / 5: the tile width `d_items` was built for*/,
+                    const HsFastQt* d_qt /*[nlevels]; nullptr: no keys*/, uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, hipStream_t s);
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs);   // per-wave spill areas of the FAST kernel for launches over <= total_work_max items
 // host side of the geometric-key tables: appends level `V`'s tables to `blob` (16-byte granules) and returns their offsets; false = the level does
 // not use them (more than 8 roots or a level wider than the tables)
@@ -211,7 +224,9 @@ bool hs_quadtree_build_tables(HsLevel& V, std::vector<uint8_t>& blob, size_t& xo
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count, hipStream_t s);
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count,
+                        uint32_t* qhist /*nullptr: the FAST launch left no keys — gather*/, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
+                        int keep_points /*debug: gather the candidates into pts_* even when the keys make it unnecessary*/, hipStream_t s);
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
                         const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps, HsStripFuse strips);

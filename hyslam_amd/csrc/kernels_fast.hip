@@ -121,9 +121,7 @@ struct RowGeom {            // wave-uniform description of one work item in one 
     const uint8_t* rows;    // address of (a0, iniY): first dword of the first tile row
     size_t pitch;
     bool valid, aligned;
-#if defined(HS_FAST_WAVES)
     int level;
-#endif
 };
 
 // How the work units of a launch are spread over the work queues (host: fast_sched()).  The item list of an image is ordered expensive items
@@ -181,9 +179,7 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
     g.th = it.th; g.ih = g.th - 6; g.iw = it.iw;
     g.off = it.off; g.ndw = it.ndw;
     g.valid = it.th != 0;
-#if defined(HS_FAST_WAVES)
     g.level = it.level;
-#endif
     const uint8_t* base;
     if (it.base == nullptr) { base = hs_img0_ptr(img0, g.img); g.pitch = img0.row_stride; }
     else { base = it.base + (size_t)g.img * it.img_stride; g.pitch = (size_t)it.pitch; }
@@ -255,7 +251,9 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
-                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base, FastSched S)
+                                                  uint32_t* __restrict__ overflow, uint32_t overflow_stride, uint32_t epoch, int item_first, uint32_t spill_base, FastSched S,
+                                                  const HsFastQt* __restrict__ qt, uint32_t* __restrict__ qhist, unsigned long long* __restrict__ qbest,
+                                                  uint32_t qhist_img_stride, uint32_t qbest_img_stride)
 {
     constexpr int COLS = 1 << LC;            // dwords per tile row
     constexpr int RS = 64 / COLS;            // half-waves working on different rows in the scans
@@ -398,6 +396,30 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_ACC(1, t1, t2);
         FR_W(2);
 
+        // ---- the quadtree's geometric keys (round 4): a survivor's key is xkey[x] | ykey[y] (HsFastQt).  The item's slices of the two tables are
+        //      fetched NOW into registers — lane j holds the keys of interior columns 2 j, 2 j + 1 (kx0) and 128 + 2 j, 129 + 2 j (kx1; wide tiles
+        //      only) and of interior rows 2 j, 2 j + 1 (ky0; a cell has at most 125 rows) — and read per survivor with ds_bpermute at the very end
+        //      of the item, so their latency is never exposed.  The survivors' key histogram and the best candidate per key go to global memory
+        //      with fire-and-forget atomics: the quadtree kernel starts from them instead of gathering the candidates.
+        uint32_t kx0 = 0, kx1 = 0, ky0 = 0;
+        bool keys_on = false;
+        uint32_t* khist = nullptr; unsigned long long* kbest = nullptr;
+        if (qt != nullptr) {
+            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+            const HsFastQt Q = __builtin_bit_cast(HsFastQt, hs_cload<u32x8>(qt + cur.level));      // one s_load_dwordx8
+            keys_on = Q.enabled != 0;
+            if (keys_on) {
+                struct __attribute__((packed, aligned(2))) U32 { uint32_t v; };
+                typedef const HS_GLOBAL U32* gu32;
+                const uint8_t* xb = hs_uniform_ptr(reinterpret_cast<const uint8_t*>(Q.xkey + (cur.xoff + 3)));
+                const uint8_t* yb = hs_uniform_ptr(reinterpret_cast<const uint8_t*>(Q.ykey + (cur.yoff + 3)));
+                kx0 = ((gu32)((const HS_GLOBAL uint8_t*)(uintptr_t)xb + 4u * (uint32_t)tid))->v;
+                if (COLS > 32) kx1 = ((gu32)((const HS_GLOBAL uint8_t*)(uintptr_t)xb + (256u + 4u * (uint32_t)tid)))->v;
+                ky0 = ((gu32)((const HS_GLOBAL uint8_t*)(uintptr_t)yb + 4u * (uint32_t)tid))->v;
+                khist = qhist + (size_t)cur.img * qhist_img_stride + Q.hist_off;
+                kbest = qbest + (size_t)cur.img * qbest_img_stride + Q.best_off;
+            }
+        }
         const int c_first = cur.off + 3;                         // tile column of the first interior pixel
         uint32_t vmask8 = 0;                                     // this lane's pixels that are interior columns: byte j = pixel j, one bit per row of a scan block
 #pragma unroll
@@ -505,11 +527,26 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int nmax = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
                 const bool keep = act & (s > nmax);
                 const int slot = wave_append(keep, n_emit);     // one running count per ITEM: its records are contiguous from slot0
+                const int gc = ((sc - 1) * inv_w1) >> 16;
+                const int px = sc - 1 - gc;                      // interior column within the item
+                uint32_t gk = 0;
+                if (keys_on) {                                   // (wave-uniform; every lane takes part in the permutes: inactive lanes read lane 0)
+                    const int pxc = act ? px : 0, ryc = act ? r - 1 : 0;
+                    uint32_t vx = (uint32_t)__builtin_amdgcn_ds_bpermute(((pxc & 127) >> 1) << 2, (int)kx0);
+                    if (COLS > 32) { const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((pxc & 127) >> 1) << 2, (int)kx1); if (pxc >= 128) vx = v1; }
+                    const uint32_t vy = (uint32_t)__builtin_amdgcn_ds_bpermute(((ryc & 127) >> 1) << 2, (int)ky0);
+                    gk = ((vx >> (16 * (pxc & 1))) & 0xFFFFu) | ((vy >> (16 * (ryc & 1))) & 0xFFFFu);
+                }
                 if (keep) {
-                    const int gc = ((sc - 1) * inv_w1) >> 16;
-                    const int px = sc - 1 - gc;                  // interior column within the item
-                    cand[slot_base + (size_t)slot] = make_uint2(((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff),
-                                                        ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc));
+                    const uint32_t xy = ((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff), sk = ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc);
+                    cand[slot_base + (size_t)slot] = make_uint2(xy, sk);
+                    if (keys_on) {
+                        // k_quadtree's `offer`: maximum response, first in (cell, y, x) order on ties (ORBExtractor.cpp:381-400)
+                        const unsigned long long order = ((unsigned long long)(sk & 0xFFFFFFu) << 32) | xy;
+                        const unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
+                        __hip_atomic_fetch_add(&khist[gk >> 1], 1u << ((gk & 1) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_max(&kbest[gk], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             npx = 0;
@@ -838,7 +875,8 @@ size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKno
 
 static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                              uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int spill_slot, int items_all, int lc_in, hipStream_t s)
+                             int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int spill_slot, int items_all, int lc_in,
+                             const HsFastQt* d_qt, uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, hipStream_t s)
 {
     (void)max_wcell;
     const FastRowsCfg c = fast_rows_cfg(max_hcell, knobs, lc_in);
@@ -851,7 +889,8 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const FastSched S = fast_sched(batch, items_per_img, knobs, nblk);
     const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
 #define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
-                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, S)
+                                               cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, S, \
+                                               d_qt, qhist, qbest, qhist_img_stride, qbest_img_stride)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
@@ -862,10 +901,11 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
 // so the caller advances its epoch only for launches that happened
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand, int32_t* cell_count, uint64_t cand_img_stride,
-                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int item_count, int spill_slot, int lc, hipStream_t s)
+                    int max_wcell, int max_hcell, uint32_t* overflow, uint32_t epoch, const HsFastKnobs& knobs, int item_first, int item_count, int spill_slot, int lc,
+                    const HsFastQt* d_qt, uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, hipStream_t s)
 {
     (void)d_lv; (void)nlevels;
     if (total_cells <= 0 || item_count <= 0) return false;
     return launch_fast_rows(d_items, img0, batch, total_cells, item_count, fast_th, cand, cell_count, cand_img_stride, max_wcell, max_hcell, overflow, epoch, knobs,
-                            item_first, spill_slot, items_per_img, lc, s);
+                            item_first, spill_slot, items_per_img, lc, d_qt, qhist, qbest, qhist_img_stride, qbest_img_stride, s);
 }

@@ -122,7 +122,9 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    uint32_t* __restrict__ pts_xy_all, uint32_t* __restrict__ pts_sk_all,
                                                    uint16_t* __restrict__ pt_node_all, int32_t* __restrict__ cand_count,
                                                    uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride,
-                                                   uint16_t* __restrict__ sel_perm, int force_point_domain, int level_first)
+                                                   uint16_t* __restrict__ sel_perm, int force_point_domain, int level_first,
+                                                   uint32_t* __restrict__ qhist, unsigned long long* __restrict__ qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
+                                                   int keep_points)
 {
     __shared__ QtRects s_rect[2];                  // point domain: node rectangles; count domain: the histogram pyramid (u16)
     __shared__ uint32_t s_cnt[2][QT_M];            // points per node
@@ -172,14 +174,16 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     static_assert(sizeof(s_idx3) >= 8192 + 4096, "geometric-key tables");
     const bool use_tab = cf_geom && L.qt_xtab != nullptr;              // (qt_w < 8192 - 16 and qt_h < 4096 - 16: the host's condition)
     auto root_of = [&](int x) { return min((int)((float)x / hX), nIni - 1); };      // vpIniNodes[kp.pt.x/hX]
-    if (use_tab) {
-        // the tables depend on the level geometry alone: the host builds them once per configuration (hs_quadtree_build_tables: the same
-        // expressions, IEEE float division and multiplication), the workgroup copies them with 16-byte loads.  Building them here cost the
-        // level-0 workgroup of a 1080p frame 5 k of its 68 k cycles (a float division and six halvings per pixel column and row).
+    // the tables depend on the level geometry alone: the host builds them once per configuration (hs_quadtree_build_tables: the same
+    // expressions, IEEE float division and multiplication), the workgroup copies them with 16-byte loads when it needs them — i.e. when it
+    // gathers the candidates (round 4: normally it does not, see `pre` below).  They live in LDS that is idle then (s_idx3).
+    auto load_key_tables = [&]() {
+        if (!use_tab) return;
         if (tid >= 1 && tid < nIni) s_rbound[tid] = L.qt_rbound[tid];
         for (int i = tid * 16; i <= L.qt_w; i += QT_T * 16) *reinterpret_cast<hs_u32x4*>(xtab + i) = hs_gload<hs_u32x4>(L.qt_xtab + i);
         for (int i = tid * 16; i <= L.qt_h; i += QT_T * 16) *reinterpret_cast<hs_u32x4*>(ytab + i) = hs_gload<hs_u32x4>(L.qt_ytab + i);
-    }
+        __syncthreads();
+    };
     auto spread = [](uint32_t v) { v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u; return v; };   // bit i -> bit 2i
     auto geo_key = [&](int x, int y) {
         if (use_tab) {
@@ -199,9 +203,44 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
         return (r << (2 * DH)) | path;
     };
-    if (cf_geom) {
+    // ---- round 4: the FAST kernel has left this level's key HISTOGRAM (deepest pyramid level) and the best candidate of every key in global
+    //      memory (HsLevel::qt_hist_off; kernels_fast.hip): the count domain starts from them and never touches the candidates — the gather
+    //      below (a third of the level-0 workgroup's time: item scan, run search, record fetch, key computation, LDS atomics) only runs when
+    //      the points themselves are needed: point-domain passes (clustered corners, > 65535 points, HS_QT_POINT_DOMAIN) or the debug taps.
+    //      Whatever happens, the workgroup leaves both global arrays ZERO for the next call.
+    const bool pre = qhist != nullptr && L.qt_hist_off != 0xFFFFFFFFu;          // uniform; the level has key tables (nIni <= 8)
+    const int ncell = nIni << (2 * DH);                                         // deepest cells (pre: nIni <= 8, so <= 8192)
+    uint32_t* const ghist = pre ? qhist + (size_t)img * qhist_img_stride + L.qt_hist_off : nullptr;
+    unsigned long long* const gbest = pre ? qbest + (size_t)img * qbest_img_stride + L.qt_best_off : nullptr;
+    bool best_pending = pre;                                                     // gbest still holds this call's keys
+    auto zero_gbest = [&]() {
+        if (!best_pending) return;
+        for (int i = tid; i < ncell / 2; i += QT_T) *reinterpret_cast<uint4*>(gbest + 2 * i) = make_uint4(0, 0, 0, 0);
+        best_pending = false;
+    };
+    int n_pre = 0;
+    if (cf_geom || pre) {
         uint32_t* const h32 = reinterpret_cast<uint32_t*>(s_rect);
-        for (int i = tid; i < QT_HPYR / 2; i += QT_T) h32[i] = 0;
+        if (pre) {
+            // the deepest level of the pyramid comes from global memory (16 bytes per thread and round: <= 8192 cells are ONE round) and goes back
+            // to zero there; the levels above it are written in full by the pyramid build below, so nothing else needs clearing
+            if (tid < 16) s_wave[tid] = 0;
+            __syncthreads();
+            int local = 0;
+            for (int i = tid * 4; i < ncell / 2; i += QT_T * 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ghist + i);
+                *reinterpret_cast<uint4*>(ghist + i) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(h32 + i) = v;
+                local += (int)(v.x & 0xFFFFu) + (int)(v.x >> 16) + (int)(v.y & 0xFFFFu) + (int)(v.y >> 16) + (int)(v.z & 0xFFFFu) + (int)(v.z >> 16) + (int)(v.w & 0xFFFFu) + (int)(v.w >> 16);
+            }
+            const int wsum = wave_sum(local);
+            if ((tid & 63) == 0 && wsum) atomicAdd(&s_wave[0], wsum);
+            __syncthreads();
+            n_pre = s_wave[0];
+            __syncthreads();                                     // (s_wave is the block scans' scratch from here on)
+        } else {
+            for (int i = tid; i < QT_HPYR / 2; i += QT_T) h32[i] = 0;
+        }
         if (tid < 8) s_dcnt[tid] = 0;
     }
     __syncthreads();
@@ -213,7 +252,10 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     // scan, then a thread per RECORD, which finds its item by binary search over the scan and fetches the record with one 8-byte load.
     // In the count domain the same thread computes the point's geometric key and adds it to the histogram.
     int n = 0;
-    {
+    bool gathered = false;
+    auto gather = [&](const bool add_hist) {
+        load_key_tables();
+        n = 0;
         uint32_t* const s_pre = reinterpret_cast<uint32_t*>(child_index);        // [round items + 1] exclusive offsets of the round's items
         uint32_t* const s_src0 = s_pre + QT_T + 4;                               // [round items] first slot of the item minus its offset: record e sits at s_src0[item] + e
         static_assert(sizeof(child_index) >= (2 * QT_T + 4) * 4, "s_pre / s_src0 scratch");
@@ -229,7 +271,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 const int gk = geo_key(key & 0xFFFF, key >> 16);
                 if (pos < QT_PTS) s_pnode[pos] = (uint16_t)gk;
                 if (keys_to_global) pnode[pos] = (uint16_t)gk;
-                atomicAdd(reinterpret_cast<uint32_t*>(s_rect) + (gk >> 1), 1u << ((gk & 1) * 16));
+                if (add_hist) atomicAdd(reinterpret_cast<uint32_t*>(s_rect) + (gk >> 1), 1u << ((gk & 1) * 16));
             }
         };
         for (int i0 = 0; i0 < nitem; i0 += QT_T) {
@@ -292,6 +334,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             n += tot;
             __syncthreads();                                       // the scratch is reused by the next round
         }
+        gathered = true;
+    };
+    if (!pre) gather(cf_geom);
+    else {
+        n = n_pre;
+        // the points themselves are needed from the start: no count domain at all (HS_QT_POINT_DOMAIN, > 65535 points) or the debug taps
+        if (!cf_geom || n > 65535 || keep_points) { if (n > 0) gather(false); zero_gbest(); }
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
     QT_MARK(1);
@@ -406,7 +455,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             }
         }
         QT_MARK(31);
-        if (S > QT_M) { if (tid == 0) *out_n = 0; return; }                                    // cannot happen for quota + 8 <= QT_M (host checks)
+        if (S > QT_M) { zero_gbest(); if (tid == 0) *out_n = 0; return; }                      // cannot happen for quota + 8 <= QT_M (host checks)
         // ---- the list after pass P: R_P ++ finals(R_{P-1}) ++ ... ++ finals(R_0) by ONE scan over the concatenated cell sequences; R_d walks
         //      the depth-d cells with the root order reversed when d is odd and the digits at even distance from the last one complemented.
         //      Depths >= 2: a thread takes 16 consecutive elements = one aligned block of 16 cells (element k <-> cell k ^ 3 of the block),
@@ -503,6 +552,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         // leave the count domain when a node that may be split has no children in the pyramid: label the points, build the rectangles
         if (cm && (!phase2 || (T_prev > 0 && (int)(s_ekey[cur][0] >> 13) >= DH))) {
             const QtNodes C = view(cur);
+            if (pre && !gathered) { gather(false); zero_gbest(); }      // the point-domain passes need the points after all: fetch them now (keys into s_pnode / pnode)
             relabel_from_keys(C);                       // the pyramid is dead from here on: its LDS becomes the rectangles
             for (int i = tid; i < S; i += QT_T) {
                 const int ek = C.ekey[i], d = ek >> 13, g = ek & 0x1FFF, r = g >> (2 * d);
@@ -726,7 +776,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             }
         }
         __syncthreads();
-        if (T + nsurv > QT_M) { if (tid == 0) *out_n = 0; return; }     // cannot happen for quota+8 <= QT_M (host checks)
+        if (T + nsurv > QT_M) { zero_gbest(); if (tid == 0) *out_n = 0; return; }     // cannot happen for quota+8 <= QT_M (host checks)
 
         QT_MARK(13);
         // -- relabel the points (point domain; in the count domain the points keep their geometric keys until the end)
@@ -782,7 +832,37 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
         atomicMax(&best[node], key);
     };
-    if (in_lds) {
+    if (keyed && pre && !gathered) {
+        // the candidates were never fetched: every occupied deepest cell offers the best candidate the FAST kernel recorded for it (the same
+        // 64-bit key a sweep over the cell's points would end with) to the list node on the cell's root-to-leaf chain; the global slots go back to zero
+        // The eight consecutive cells of a thread share their ancestors down to depth DH - 2 (one mark lookup per depth for all of them) and, in
+        // fours, the one at depth DH - 1: 15 LDS reads per thread instead of 7 per cell.  Exactly one cell of a root-to-leaf chain is a list node.
+        for (int c0 = tid * 8; c0 < ncell; c0 += QT_T * 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(&hist[c0]);                   // eight u16 counts of the deepest level (hoff(DH) == 0)
+            const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+            unsigned long long key[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) key[k] = ((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) ? gbest[c0 + k] : 0ull;                        // loads, all in flight
+            if ((q.x | q.y | q.z | q.w) == 0u) continue;
+            int mc[5], e_common = 0xFFFF;
+#pragma unroll
+            for (int d = 0; d < 5; d++) mc[d] = d <= DH - 2 ? (int)mark[hoff(d) + (c0 >> (2 * (DH - d)))] : 0xFFFF;
+#pragma unroll
+            for (int d = 0; d < 5; d++) if (mc[d] != 0xFFFF) e_common = mc[d];
+            const int m1a = mark[hoff(DH - 1) + (c0 >> 2)], m1b = mark[hoff(DH - 1) + (c0 >> 2) + 1];
+            const uint4 m2 = *reinterpret_cast<const uint4*>(&mark[c0]);                  // marks of the eight cells themselves (hoff(DH) == 0)
+            const uint32_t m2w[4] = { m2.x, m2.y, m2.z, m2.w };
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (!key[k]) continue;
+                const int mk = (int)((m2w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), m1 = k < 4 ? m1a : m1b;
+                const int node = mk != 0xFFFF ? mk : (m1 != 0xFFFF ? m1 : e_common);
+                gbest[c0 + k] = 0ull;
+                atomicMax(&best[node], key[k]);
+            }
+        }
+        best_pending = false;
+    } else if (in_lds) {
         uint32_t sk[QT_PTS / QT_T]; int nd[QT_PTS / QT_T];
 #pragma unroll
         for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; sk[k] = p < n ? psk[p] : 0u; nd[k] = p < n ? (int)s_pnode[p] : 0; }      // global loads, all in flight
@@ -801,6 +881,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             for (int k = 0; k < 8; k++) { const int p = p0 + k * QT_T; if (p < n) offer(xy[k], sk[k], keyed ? node_of_key(nd[k]) : nd[k]); }
         }
     }
+    zero_gbest();                                                        // (a no-op unless a path above left the keys in place)
     __syncthreads();
     QT_MARK(40);
     for (int i = tid; i < S; i += QT_T) {
@@ -865,12 +946,14 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
 void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_cells,
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
-                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, int level_first, int level_count, hipStream_t s)
+                        uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, int level_first, int level_count,
+                        uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, int keep_points, hipStream_t s)
 {
     if (level_count <= 0) return;
     dim3 grid(level_count, batch, 1);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first);
+                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
+                       qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
 }
 
 // Host side of the geometric-key tables (see k_quadtree): the expressions of the kernel's former in-kernel build, evaluated once per

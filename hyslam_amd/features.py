@@ -241,6 +241,10 @@ class ORBExtractor:
         N.check(self._h, self._lib.hs_orb_debug_level(self._h, image, level, buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(lw), C.byref(lh)))
         return buf[:lw.value * lh.value].reshape(lh.value, lw.value).copy()
 
+    def set_debug(self, on=True):
+        """debug mode: the quadtree stage also gathers the FAST candidates into dense per-level lists (debug_candidates reads them)"""
+        N.check(self._h, self._lib.hs_orb_set_debug(self._h, 1 if on else 0))
+
     def debug_candidates(self, image, level, cap=1 << 20):
         out = np.zeros((cap, 3), np.int32)
         n = C.c_int32()

@@ -1,10 +1,16 @@
 // HipFeatureMatcher.h — HYSLAM::FeatureMatcher's search entry points over the C ABI (include/hyslam_amd.h).
 //
-//   HYSLAM::HipFeatureMatcher : HYSLAM::FeatureMatcher     (src/features/FeatureMatcher.h:105-176)
+//   HYSLAM::HipMatcherCore                                 the twelve searches as a plain class (settings + a C-ABI handle)
+//   HYSLAM::HipFeatureMatcher : HYSLAM::FeatureMatcher     (src/features/FeatureMatcher.h:105-176) — overrides that forward to the core
 //
-// Needs the two-line patch of INTEGRATION.md §3 in hySLAM (`virtual` on FeatureFactory::getFeatureMatcher and on the FeatureMatcher search
-// methods): the reference obtains matchers through the NON-virtual FeatureFactory::getFeatureMatcher() (src/features/FeatureFactory.cpp:7-9)
-// and calls non-virtual methods, so without the patch a subclass is never reached.  Every override does three things:
+// Two ways into hySLAM:
+//   (a) the `virtual` patch: `virtual` on FeatureFactory::getFeatureMatcher and on the FeatureMatcher search methods — the reference obtains
+//       matchers through the NON-virtual FeatureFactory::getFeatureMatcher() (src/features/FeatureFactory.cpp:7-9) and calls non-virtual methods, so
+//       without the patch a subclass is never reached — and HipORBFactory hands out HipFeatureMatcher;
+//   (b) NO header edit: host/replace/FeatureMatcher.cc replaces src/features/FeatureMatcher.cc in hySLAM's source list and defines the
+//       reference's own FeatureMatcher member functions as calls into HipMatcherCore (define HYSLAM_AMD_UNPATCHED_MATCHER: HipFeatureMatcher
+//       cannot exist then — nothing to override).
+// Every search does three things:
 //   gather   Frame / KeyFrame / MapPoint fields -> the flat arrays of hs_frame_view / hs_landmark (one pass, no per-landmark map copies);
 //            landmarks are passed SORTED BY ADDRESS, which reproduces the iteration order of the reference's std::map<MapPoint*, ...>
 //            (FeatureMatcher.cc:64,113-118; deviation D6 of DESIGN.md)
@@ -35,21 +41,24 @@
 
 namespace HYSLAM {
 
-class HipFeatureMatcher : public FeatureMatcher {
+class HipMatcherCore {
 public:
     // `handle`: any hs_orb on the device the matcher should run on (e.g. HipORBExtractor::handle()); it only lends its stream and scratch.
     // A handle is thread-compatible: give each thread that matches concurrently (Tracking, Mapping jobs) its own.
-    HipFeatureMatcher(FeatureMatcherSettings settings, hs_orb* handle) : FeatureMatcher(settings), h(handle) {}
+    // The four settings are FeatureMatcher's protected members of the same names (FeatureMatcher.h:158-161).
+    HipMatcherCore(float nnratio, bool checkOri, float th_low, float th_high, hs_orb* handle)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), TH_LOW(th_low), TH_HIGH(th_high), h(handle) {}
+    HipMatcherCore(FeatureMatcherSettings s, hs_orb* handle) : HipMatcherCore(s.nnratio, s.checkOri, s.TH_LOW, s.TH_HIGH, handle) {}
 
     // SearchByProjection(Frame&, vector<MapPoint*>&, th) — TrackLocalMap (FeatureMatcher.cc:123-143)
-    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3) override {
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3) {
         hs_proj_params pp = base_params(th, TH_HIGH, mfNNratio);
         pp.use_distance = 1; pp.use_stereo = 1; pp.check_rotation = 0;
         return project_and_associate(F, vpMapPoints, nullptr, pp);
     }
 
     // SearchByProjection(CurrentFrame, LastFrame, th, bMono) — TrackMotionModel (FeatureMatcher.cc:145-176)
-    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool /*bMono*/) override {
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool /*bMono*/) {
         hs_proj_params pp = base_params(th, TH_HIGH, mfNNratio);
         pp.use_distance = 0; pp.use_stereo = 1; pp.check_rotation = 1;
         return project_and_associate(CurrentFrame, LastFrame.replicatemvpMapPoints(), &LastFrame, pp);
@@ -57,7 +66,7 @@ public:
 
     // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) — relocalisation (FeatureMatcher.cc:180-212).  The reference's
     // RotationConsistencyCriterion is a no-op here (no previous frame is set, MatchCriteria.cpp:368-371).
-    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) override {
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) {
         std::vector<MapPoint*> lms;
         for (const auto& kv : pKF->getLandMarkMatches()) if (kv.second && !sAlreadyFound.count(kv.second)) lms.push_back(kv.second);
         hs_proj_params pp = base_params(th, (float)ORBdist, 1.0f);
@@ -66,7 +75,7 @@ public:
     }
 
     // SearchByBoW(pKF, F, matches) — TrackReferenceKeyFrame / relocalisation (FeatureMatcher.cc:216-278)
-    int SearchByBoW(KeyFrame* pKF, Frame& F, std::map<size_t, MapPoint*>& matches) override {
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::map<size_t, MapPoint*>& matches) {
         const FeatureViews& v1 = pKF->getViews(); const FeatureViews& v2 = F.getViews();
         Views a = gather_views(v1), b = gather_views(v2);
         Csr f1 = gather_featvec(pKF->mFeatVec), f2 = gather_featvec(F.mFeatVec);
@@ -84,7 +93,7 @@ public:
     }
 
     // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) — MonoInitializer (FeatureMatcher.cc:404-462)
-    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) override {
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) {
         Views a = gather_views(F1.getViews());
         FrameArrays fb; hs_frame_view V = gather_frame(F2, fb);
         std::vector<float> prev(2 * std::max<size_t>(a.kps.size(), 1));
@@ -99,7 +108,7 @@ public:
 
     // Fuse(pKF, vpMapPoints, fuse_matches, th, reprojection_err) — LandMarkFuser (FeatureMatcher.cc:464-521)
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, std::map<std::size_t, MapPoint*>& fuse_matches, const float th = 3.0,
-             const float reprojection_err = 5.99) override {
+             const float reprojection_err = 5.99) {
         hs_proj_params pp = base_params(th, TH_LOW, 1.0f);
         pp.use_distance = 1; pp.use_stereo = 0; pp.check_rotation = 0; pp.use_prev_matched = 0;
         pp.use_viewing_angle = 1; pp.max_view_angle = 1.047f; pp.use_reprojection = 1; pp.reproj_threshold = reprojection_err; pp.first_wins = 1;
@@ -117,7 +126,7 @@ public:
 
     // SearchByBoW(pKF1, pKF2, vpMatches12) — the legacy key-frame matcher (FeatureMatcher.cc:938-1077; no call site in hySLAM): a KF2 view is matched at
     // most once (vbMatched2), the orientation histogram takes angle1 - angle2; views take part when they have a landmark that is not bad.
-    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override {
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
         const FeatureViews& v1 = pKF1->getViews(); const FeatureViews& v2 = pKF2->getViews();
         Views a = gather_views(v1), b = gather_views(v2);
         Csr f1 = gather_featvec(pKF1->mFeatVec), f2 = gather_featvec(pKF2->mFeatVec);
@@ -136,7 +145,7 @@ public:
 
     // SearchByBoW2(pKF1, pKF2, vpMatches12) — LoopClosing.cc:275 (FeatureMatcher.cc:346-371): _SearchByBoW_ with PreviouslyMatchedIndexCriterion(true) on
     // BOTH key frames (:306-309), BestMatchBoWCriterion(TH_LOW, mfNNratio), RotationConsistencyBoW; vpMatches12[i] = KF2's landmark at the matched view.
-    int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override {
+    int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) {
         std::vector<int32_t> m12; const int n = bow_between_keyframes(pKF1, pKF2, true, false, nullptr, mfNNratio, m12, "SearchByBoW2");
         const size_t N1 = pKF1->GetMapPointMatches().size();
         vpMatches12 = std::vector<MapPoint*>(N1, static_cast<MapPoint*>(NULL));
@@ -148,7 +157,7 @@ public:
     // PreviouslyMatchedIndexCriterion(false) (+ StereoIndexCriterion when bOnlyStereo) on both key frames, EpipolarConsistencyBoWCriterion(F12)
     // — the epipole (ex, ey) the reference computes is stored by the criterion and never read (MatchCriteria.cpp:637-676) —
     // BestMatchBoWCriterion(TH_LOW, 1.0), RotationConsistencyBoW.  Pairs are appended in ascending idx1 order (std::map iteration, :396-398).
-    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo) override {
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo) {
         float F[9];
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
         std::vector<int32_t> m12; const int n = bow_between_keyframes(pKF1, pKF2, false, bOnlyStereo, F, 1.0f, m12, "SearchForTriangulation");
@@ -158,7 +167,7 @@ public:
 
     // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) — LoopClosing.cc:389 (FeatureMatcher.cc:628-737).  Landmarks stay in vpPoints order (the
     // search is sequential: a keypoint taken by an earlier landmark is invisible to later ones, :713,731).
-    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) override {
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) {
         FrameArrays fa; hs_frame_view V = gather_frame(*pKF, fa);
         float S[16];
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S[4 * r + c] = Scw.at<float>(r, c);
@@ -177,11 +186,11 @@ public:
 
     // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) — LoopClosing.cc:632.  The reference's body is commented out in full (FeatureMatcher.cc:523-624):
     // it computes nothing and falls off the end of an int function.  Nothing to run on the GPU; the override leaves vpReplacePoint untouched and returns 0.
-    int Fuse(KeyFrame* /*pKF*/, cv::Mat /*Scw*/, const std::vector<MapPoint*>& /*vpPoints*/, float /*th*/, std::vector<MapPoint*>& /*vpReplacePoint*/) override { return 0; }
+    int Fuse(KeyFrame* /*pKF*/, cv::Mat /*Scw*/, const std::vector<MapPoint*>& /*vpPoints*/, float /*th*/, std::vector<MapPoint*>& /*vpReplacePoint*/) { return 0; }
 
     // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) — LoopClosing.cc:333 (FeatureMatcher.cc:739-934): both projection directions, then the
     // agreement check; vpMatches12[i1] = KF2's landmark at the agreed view.
-    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) override {
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) {
         FrameArrays fa1, fa2; hs_frame_view V1 = gather_frame(*pKF1, fa1), V2 = gather_frame(*pKF2, fa2);
         const std::vector<MapPoint*> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
         const int N1 = (int)mp1.size(), N2 = (int)mp2.size();
@@ -210,7 +219,7 @@ private:
     struct Csr { std::vector<int32_t> id, ptr, idx; };
 
     void check(int st, const char* what) const {
-        if (st != HS_OK) throw std::runtime_error(std::string("HipFeatureMatcher::") + what + ": " + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        if (st != HS_OK) throw std::runtime_error(std::string("HipMatcherCore::") + what + ": " + hs_status_string(st) + ": " + hs_orb_last_error(h));
     }
     hs_proj_params base_params(float th, float score_threshold, float ratio) const {
         hs_proj_params pp; std::memset(&pp, 0, sizeof(pp));
@@ -338,7 +347,33 @@ private:
         return n;
     }
 
+    float mfNNratio; bool mbCheckOrientation; float TH_LOW, TH_HIGH;
     hs_orb* h;
 };
+
+#ifndef HYSLAM_AMD_UNPATCHED_MATCHER
+// integration (a): FeatureMatcher with virtual search entry points (the patch of INTEGRATION.md §3); every override forwards to the core
+class HipFeatureMatcher : public FeatureMatcher {
+public:
+    HipFeatureMatcher(FeatureMatcherSettings settings, hs_orb* handle) : FeatureMatcher(settings), core(settings, handle), timing(core.timing) {}
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3) override { return core.SearchByProjection(F, vpMapPoints, th); }
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) override { return core.SearchByProjection(CurrentFrame, LastFrame, th, bMono); }
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist) override { return core.SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist); }
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th) override { return core.SearchByProjection(pKF, Scw, vpPoints, vpMatched, th); }
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::map<size_t, MapPoint*>& matches) override { return core.SearchByBoW(pKF, F, matches); }
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override { return core.SearchByBoW(pKF1, pKF2, vpMatches12); }
+    int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12) override { return core.SearchByBoW2(pKF1, pKF2, vpMatches12); }
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo) override { return core.SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo); }
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10) override { return core.SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize); }
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, std::map<std::size_t, MapPoint*>& fuse_matches, const float th = 3.0, const float reprojection_err = 5.99) override { return core.Fuse(pKF, vpMapPoints, fuse_matches, th, reprojection_err); }
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) override { return core.Fuse(pKF, Scw, vpPoints, th, vpReplacePoint); }
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) override { return core.SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th); }
+    hs_orb* handle() const { return core.handle(); }
+private:
+    HipMatcherCore core;
+public:
+    HipCallTiming& timing;            // of the last SearchByProjection(Frame...) / Fuse / key-frame BoW call
+};
+#endif
 
 }  // namespace HYSLAM

@@ -46,6 +46,8 @@ inline hs_orb* thread_handle(int device, const char* who) {
     o.by_device[device] = h;
     return h;
 }
+// the GPU of the per-thread handles that have no factory to ask (HipStereomatcher's reference constructor, replace/FeatureMatcher.cc)
+inline std::atomic<int>& default_device() { static std::atomic<int> d{ 0 }; return d; }
 }  // namespace hip_detail
 
 // ORBDistance (DescriptorDistance.cpp:9-25) kept on the host for the callers that still ask per-pair distances.
@@ -155,18 +157,17 @@ public:
     void computeStereoMatches() {
         const auto t0 = std::chrono::steady_clock::now();
         mvuRight.assign(kL.size(), -1.0f); mvDepth.assign(kL.size(), -1.0f);
-        hs_orb* use = h ? h : hip_detail::thread_handle(default_device().load(), "HipStereomatcher");
+        hs_orb* use = h ? h : hip_detail::thread_handle(hip_detail::default_device().load(), "HipStereomatcher");
         int st = hs_stereo_match(use, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
         if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
         timing.abi_ms = hip_detail::ms_since(t0);
     }
     void getData(std::vector<float>& mvuRight_, std::vector<float>& mvDepth_) { mvuRight_ = mvuRight; mvDepth_ = mvDepth; }
     void getData(FeatureViews& views) { views.setuRs(mvuRight); views.setDepths(mvDepth); }       // Stereomatcher.cpp:31-34
-    static void setDefaultDevice(int device) { default_device().store(device); }
+    static void setDefaultDevice(int device) { hip_detail::default_device().store(device); }
     HipCallTiming timing;             // gather = constructor, abi = computeStereoMatches
 
 private:
-    static std::atomic<int>& default_device() { static std::atomic<int> d{ 0 }; return d; }
     static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) {
         ok.resize(k.size()); od.resize(k.size() * HS_DESC_BYTES);
         for (size_t i = 0; i < k.size(); i++) {

@@ -63,9 +63,16 @@ public:
     // Every call site builds a short-lived matcher through this function (TrackLocalMap.cpp:72-75, TrackMotionModel.cpp:24, ...).  Matchers
     // created on different threads must not share a handle, and a factory must hand out handles of ITS device: the handle is looked up per
     // (calling thread, device) — hip_detail::thread_handle in HipORBExtractor.h.
+#ifndef HYSLAM_AMD_UNPATCHED_MATCHER
     std::unique_ptr<FeatureMatcher> getFeatureMatcher() override {
         return std::make_unique<HipFeatureMatcher>(matcher_settings, hip_detail::thread_handle(device, "HipORBFactory"));
     }
+#else
+    // integration (b), no header edit: the base class's non-virtual getFeatureMatcher() hands out the reference's own FeatureMatcher type, whose
+    // member functions host/replace/FeatureMatcher.cc defines over the C ABI (on the calling thread's handle on hip_detail::default_device());
+    // nothing to override here, the factory only makes that device its own
+    void useDeviceForMatchers() const { hip_detail::default_device().store(device); }
+#endif
     int deviceIndex() const { return device; }
 
 private:

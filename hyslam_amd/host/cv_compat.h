@@ -245,6 +245,46 @@ private:
     LandMarkMatches matches;
 };
 
+#ifdef HYSLAM_AMD_COMPAT_UNPATCHED
+// src/features/FeatureMatcher.h:105-176 AS IT IS in the reference (no patch): non-virtual search entry points, declared only — the bodies come from
+// host/replace/FeatureMatcher.cc, the translation unit that takes the place of src/features/FeatureMatcher.cc (mode b).
+class FeatureMatcher {
+public:
+    FeatureMatcher(float nnratio = 0.6, bool checkOri = true);
+    FeatureMatcher(FeatureMatcherSettings settings);
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::map<size_t, MapPoint*>& matches);
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    int SearchByBoW2(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo);
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, std::map<std::size_t, MapPoint*>& fuse_matches, const float th = 3.0, const float reprojection_err = 5.99);
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th);
+    static const int HISTO_LENGTH;
+protected:
+    float mfNNratio; bool mbCheckOrientation; float TH_LOW; float TH_HIGH;
+};
+
+// src/features/FeatureFactory.h:21-33 as it is in the reference; getFeatureMatcher() with the body of src/features/FeatureFactory.cpp:7-9
+class FeatureFactory {
+public:
+    virtual ~FeatureFactory() {}
+    virtual std::shared_ptr<FeatureExtractor> getExtractor(std::string type) = 0;
+    virtual std::shared_ptr<FeatureExtractor> getExtractor(FeatureExtractorSettings settings) = 0;
+    virtual FeatureVocabulary* getVocabulary(std::string type) = 0;
+    virtual std::shared_ptr<DescriptorDistance> getDistanceFunc() = 0;
+    virtual FeatureExtractorSettings getFeatureExtractorSettings() = 0;
+    std::unique_ptr<FeatureMatcher> getFeatureMatcher() { return std::make_unique<FeatureMatcher>(matcher_settings); }
+    FeatureMatcherSettings getFeatureMatcherSettings() const { return matcher_settings; }
+    void setFeatureMatcherSettings(FeatureMatcherSettings fm_settings) { matcher_settings = fm_settings; }
+protected:
+    FeatureMatcherSettings matcher_settings;
+};
+#else
 // src/features/FeatureMatcher.h:105-176 AFTER the two-line patch of INTEGRATION.md §3 (`virtual` on the search entry points).  The
 // reference's own bodies are not restated: in this shim the base class only defines the interface the adaptor overrides.
 class FeatureMatcher {
@@ -282,4 +322,5 @@ public:
 protected:
     FeatureMatcherSettings matcher_settings;
 };
+#endif
 }  // namespace HYSLAM

@@ -404,6 +404,9 @@ int  hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t byte
 /* ---- stage taps for parity tests (host outputs; synchronous; valid after an extract call) ---- */
 /* pyramid level `level` of image `image` of the last batch: tight w*h bytes; ORBExtractor::ComputePyramid :564-589 */
 int  hs_orb_debug_level(hs_orb* h, int image, int level, uint8_t* out, size_t cap_bytes, int32_t* lw, int32_t* lh);
+/* debug mode: the quadtree stage also gathers the FAST candidates into the dense per-level lists hs_orb_debug_candidates reads (the product path
+ * works from the key histogram the FAST kernel leaves and never builds them).  Set before the extraction. */
+int  hs_orb_set_debug(hs_orb* h, int on);
 /* FAST candidates of that level before DistributeOctTree (unordered): (x,y,score) int32 triplets relative to
  * (16,16); ORBExtractor::ComputeKeyPointsOctTree :430-470 */
 int  hs_orb_debug_candidates(hs_orb* h, int image, int level, int32_t* xys, int cap, int32_t* n);

@@ -9,6 +9,7 @@
 // from array order (deviation D6).  Expected results: an independent gather written here + the CPU oracle (test infrastructure) + a replay of
 // associateLandMark in address order on a copy of the frame's LandMarkMatches.
 // usage: test_matcher_adaptor scene.bin          prints "MATCHER ADAPTOR OK ..." on success, "NO DEVICE" without a GPU
+#include <type_traits>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -107,6 +108,19 @@ int main(int argc, char** argv)
     std::shared_ptr<FeatureExtractor> exS = factory->getExtractor("SLAM"), exI = factory->getExtractor("Imaging");
     if (exS->GetLevels() != 8 || exI->GetScaleFactor() != 1.4f || factory->getFeatureExtractorSettings().nFeatures != 3000) FAIL(5, "factory settings");
     std::unique_ptr<FeatureMatcher> matcher = factory->getFeatureMatcher();
+#ifdef HYSLAM_AMD_COMPAT_UNPATCHED
+    // integration (b): the UNPATCHED reference declarations (non-virtual everywhere) + host/replace/FeatureMatcher.cc in the place of the reference's
+    // FeatureMatcher.cc: `matcher` is a plain FeatureMatcher made by the base class's non-virtual getFeatureMatcher(); every search below goes
+    // through the replaced member functions on the calling thread's handle.  (Nothing to dynamic_cast to: the subclass does not exist in this mode.)
+    static_assert(!std::is_polymorphic<FeatureMatcher>::value, "the unpatched FeatureMatcher has no virtual function");
+    {
+        hs_orb* mine = hip_detail::thread_handle(hip_detail::default_device().load(), "test");
+        hs_orb* theirs = nullptr;
+        std::thread t([&] { theirs = hip_detail::thread_handle(hip_detail::default_device().load(), "test"); });
+        t.join();
+        if (!theirs || theirs == mine) FAIL(9, "two threads share one matcher handle");
+    }
+#else
     if (!dynamic_cast<HipFeatureMatcher*>(matcher.get())) FAIL(6, "getFeatureMatcher() did not dispatch to the HIP matcher");
     {   // matcher handles are per (calling thread, device): the same handle again on this thread, the factory's device, another handle on another thread
         hs_orb* mine = static_cast<HipFeatureMatcher*>(matcher.get())->handle();
@@ -118,6 +132,7 @@ int main(int argc, char** argv)
         t.join();
         if (!theirs || theirs == mine) FAIL(9, "two threads share one matcher handle");
     }
+#endif
 
     // ---- the scene as hySLAM objects; MapPoints allocated in shuffled order
     std::shared_ptr<DescriptorDistance> dist = factory->getDistanceFunc();

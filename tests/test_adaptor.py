@@ -13,6 +13,19 @@ BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
 EXE = os.path.join(BUILD, "test_adaptor")
 EXE_M = os.path.join(BUILD, "test_matcher_adaptor")
 EXE_B = os.path.join(BUILD, "bench_adaptor")
+EXE_R = os.path.join(BUILD, "test_matcher_replacement")
+
+
+def build_replacement():
+    """integration (b) of INTEGRATION.md §3: tests/cpp/test_matcher_adaptor.cpp compiled against the UNPATCHED declarations of the reference's FeatureMatcher /
+    FeatureFactory (cv_compat.h with HYSLAM_AMD_COMPAT_UNPATCHED: no virtual anywhere) together with hyslam_amd/host/replace/FeatureMatcher.cc, the
+    translation unit that takes the place of src/features/FeatureMatcher.cc"""
+    os.makedirs(BUILD, exist_ok=True)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pthread", "-DHYSLAM_AMD_COMPAT_UNPATCHED", "-DHYSLAM_AMD_UNPATCHED_MATCHER",
+                           os.path.join(ROOT, "tests", "cpp", "test_matcher_adaptor.cpp"), os.path.join(ROOT, "hyslam_amd", "host", "replace", "FeatureMatcher.cc"), "-o", EXE_R,
+                           "-L" + os.path.join(ROOT, "hyslam_amd"), "-lhyslam_amd", "-Wl,-rpath," + os.path.join(ROOT, "hyslam_amd"),
+                           "-L" + os.path.join(ROOT, "oracle", "_build"), "-lhs_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle", "_build")])
 
 
 def build(src="test_adaptor.cpp", exe=EXE):
@@ -49,10 +62,10 @@ def write_scene(path):
         np.ascontiguousarray(lms).tofile(f)
 
 
-def run_matcher():
+def run_matcher(exe=EXE_M):
     scene = os.path.join(BUILD, "scene.bin")
     write_scene(scene)
-    return subprocess.run([EXE_M, scene], capture_output=True, timeout=600)
+    return subprocess.run([exe, scene], capture_output=True, timeout=600)
 
 
 def run_bench(w=640, h=480, reps=6, n_lm=5000):
@@ -74,6 +87,13 @@ def test_adaptor_compiles_and_fails_loudly_without_gpu():
 def test_matcher_adaptor_and_factory_compile_and_fail_loudly_without_gpu():
     build("test_matcher_adaptor.cpp", EXE_M)
     r = run_matcher()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert b"NO DEVICE" in r.stdout or b"MATCHER ADAPTOR OK" in r.stdout
+
+
+def test_matcher_replacement_unit_compiles_against_the_unpatched_declarations():
+    build_replacement()
+    r = run_matcher(EXE_R)
     assert r.returncode == 0, r.stdout + r.stderr
     assert b"NO DEVICE" in r.stdout or b"MATCHER ADAPTOR OK" in r.stdout
 
@@ -113,4 +133,13 @@ def test_matcher_adaptor_replays_associations_in_address_order_on_gpu(gpu):
     points SearchByProjection(pKF, Scw, ...), SearchBySim3, SearchForTriangulation (all views / stereo only), SearchByBoW2 and the empty Fuse(Scw)"""
     build("test_matcher_adaptor.cpp", EXE_M)
     r = run_matcher()
+    assert r.returncode == 0 and b"MATCHER ADAPTOR OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_matcher_replacement_unit_on_gpu(gpu):
+    """integration (b): the same ten searches through a PLAIN FeatureMatcher object of the reference's unpatched declarations (no virtual function, made by the
+    base class's non-virtual FeatureFactory::getFeatureMatcher()), whose member functions hyslam_amd/host/replace/FeatureMatcher.cc defines over the C ABI"""
+    build_replacement()
+    r = run_matcher(EXE_R)
     assert r.returncode == 0 and b"MATCHER ADAPTOR OK" in r.stdout, r.stdout + r.stderr

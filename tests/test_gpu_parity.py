@@ -37,6 +37,11 @@ def stage_parity(img, nfeat, scale=1.2):
     p = oracle.default_params(nfeat, scale)
     ok, od, dbg = oracle.extract(p, img, debug=True)
     ex = HS.ORBExtractor(settings(nfeat, scale))
+    # the product path first (the quadtree stage works from the key histogram the FAST kernel leaves and never lists the candidates), then the same
+    # frame in debug mode (hs_orb_set_debug: the candidates are gathered into dense lists as well): same features, and the candidate sets per level
+    gk0, gd0 = ex(img)
+    assert_same_features(gk0, gd0, ok, od)
+    ex.set_debug(True)
     gk, gd = ex(img)
     sc = oracle.scale_tables(p)[0]
     for l in range(p.nlevels):
@@ -53,6 +58,7 @@ def stage_parity(img, nfeat, scale=1.2):
         assert np.array_equal(gs[:, 0].astype(np.float32) * mul, ok["x"][m]) and np.array_equal(gs[:, 1].astype(np.float32) * mul, ok["y"][m])
         assert np.array_equal(gs[:, 2].astype(np.float32), ok["response"][m])
     assert_same_features(gk, gd, ok, od)
+    ex.set_debug(False)
     return ex, gk, gd
 
 
@@ -218,7 +224,12 @@ def test_blur_saturation_white_blocks(gpu):
                                  {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64", "HS_FAST_NQ": "16"}, {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64", "HS_FAST_ORDER": "0"},
                                  {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "32"}, {"HS_FAST_NO_FOLD": "1"},
                                  # the folded static schedule on wide items; narrow items never (threshold 1 item)
-                                 {"HS_FAST_COLS": "64"}, {"HS_FAST_COLS": "64", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_NARROW_MAX": "1"}])
+                                 {"HS_FAST_COLS": "64"}, {"HS_FAST_COLS": "64", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_NARROW_MAX": "1"},
+                                 # the quadtree stage gathering the candidates and computing their keys itself (the scheme until round 3)
+                                 {"HS_FAST_KEYS": "0"}, {"HS_FAST_KEYS": "0", "HS_QT_POINT_DOMAIN": "1"},
+                                 # ... the keys for every batch size / for the first two levels only / with the point-domain passes forced (the candidates are fetched after all)
+                                 {"HS_FAST_KEYS_MAX_BATCH": "100000"}, {"HS_FAST_KEYS_LEVELS": "2"}, {"HS_FAST_KEYS_MAX_BATCH": "100000", "HS_QT_POINT_DOMAIN": "1"},
+                                 {"HS_FAST_KEYS_MAX_BATCH": "100000", "HS_FAST_COLS": "64", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_KEYS_MAX_BATCH": "100000", "HS_FAST_TEST_SCAN_B": "1"}])
 def test_fast_kernel_variants_in_subprocess(gpu, env):
     """the FAST kernel's tile-width variants (narrow / wide work items forced whatever the batch), its two schedules (folded static for small
     launches, work queues) forced on both widths, its list-overflow (flush) paths forced by a tiny LDS list, NMS driven from the score

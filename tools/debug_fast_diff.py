@@ -10,7 +10,7 @@ w, h, seed = (int(a) for a in (sys.argv[1:4] + ["640", "480", "1"][len(sys.argv)
 img = synth_image(seed, w, h)
 p = oracle.default_params(1000, 1.2)
 ok, od, dbg = oracle.extract(p, img, debug=True)
-ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=1000, fScaleFactor=1.2, nLevels=8))
+ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=1000, fScaleFactor=1.2, nLevels=8)); ex.set_debug(True)
 ex(img)
 for l in range(p.nlevels):
     gc = ex.debug_candidates(0, l); oc = dbg["candidates"][l].astype(np.int32)

@@ -12,7 +12,7 @@ from hyslam_amd.synth import synth_image, synth_stereo_pair
 def check_image(img, nfeat, tag):
     p = oracle.default_params(nfeat)
     ok, od, dbg = oracle.extract(p, img, debug=True)
-    ex = H.ORBExtractor(H.FeatureExtractorSettings(nFeatures=nfeat))
+    ex = H.ORBExtractor(H.FeatureExtractorSettings(nFeatures=nfeat)); ex.set_debug(True)
     t = time.time(); gk, gd = ex(img); dt = time.time() - t
     print(f"[{tag}] {img.shape} nfeat={nfeat}: oracle {len(ok)} kps, gpu {len(gk)} kps ({dt*1e3:.1f} ms incl. alloc)")
     allok = True
