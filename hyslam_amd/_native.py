@@ -70,10 +70,10 @@ EXPORTS = [
     "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_device", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
-    "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait",
+    "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait", "hs_orb_cancel", "hs_ticket_frames_copied",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_set_split", "hs_orb_synchronize",
     "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
-    "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
+    "hs_vocab_last_error", "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",
     "hs_comm_available", "hs_comm_unavailable_reason", "hs_orb_borrowers", "hs_comm_get_unique_id", "hs_comm_create", "hs_comm_destroy", "hs_comm_world", "hs_comm_rank", "hs_comm_last_error", "hs_comm_allgather_records",
@@ -188,7 +188,11 @@ def lib():
     L.hs_host_free.restype = None
     L.hs_orb_submit_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(i32)]
     L.hs_orb_wait.argtypes = [vp, i32, vp, vp, vp, C.c_int, vp, vp]
+    L.hs_orb_cancel.argtypes = [vp, i32]
+    L.hs_ticket_frames_copied.argtypes = [vp, i32]
     L.hs_comm_get_unique_id.argtypes = [vp]
+    L.hs_vocab_last_error.argtypes = []
+    L.hs_vocab_last_error.restype = C.c_char_p
     L.hs_comm_available.argtypes = []
     L.hs_comm_unavailable_reason.argtypes = []
     L.hs_comm_unavailable_reason.restype = C.c_char_p

@@ -64,6 +64,8 @@ struct hs_orb {
     bool keep_points = false;          // hs_orb_set_debug(h, 1): the quadtree kernel also gathers the candidates into the dense point arrays (hs_orb_debug_candidates reads them)
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
     std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
+    std::vector<HsPyrChain> pyr_deep;  // [level]: the small-batch plan — chains as long as the LDS allows (8 levels: all seven in ONE launch); valid = 0 where none starts
+    int deep_max_batch = 2;            // HS_PYRAMID_DEEP_MAX (read once): calls of at most this many frames use the small-batch plan (0 = never)
     std::vector<HsPyrChain> pyr_chain; // [level]: kernel argument of the chain launch that starts at this level (HsLevel::chain_n levels)
     int chain_mode = -1;               // HS_PYRAMID_CHAIN (read once): -1 = a three-level chain for the tail of an odd number of levels, 0 = never, 2 = chains for every fused pair too (parity tests)
     uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
@@ -130,7 +132,7 @@ void free_geometry(hs_orb* h)
 {
     hipFree(h->d_pyr); h->d_pyr = nullptr;
     hipFree(h->d_tables); h->d_tables = nullptr;
-    hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear();
+    hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear(); h->pyr_deep.clear();
     hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
     hipFree(h->d_qkeys); h->d_qkeys = nullptr; hipFree(h->d_fast_qt); h->d_fast_qt = nullptr;
     hipFree(h->d_qhist); h->d_qhist = nullptr; hipFree(h->d_qbest); h->d_qbest = nullptr; h->qhist_stride = h->qbest_stride = 0;
@@ -344,9 +346,23 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
                 if (h->pyr_chain[l].valid) h->lv[l].chain_n = 3;
             }
         }
+        // the small-batch plan: a launch of few frames lasts as long as one workgroup lives and costs ~5 us whatever it does, so the dependent
+        // launches are what counts — greedy: from level 1, the longest chain that fits HS_PYR_DEEP_LDS, then the next (1080p: ONE launch for levels 1-7)
+        h->pyr_deep.assign(L, HsPyrChain{});
+        if (!h->no_fuse && h->deep_max_batch > 0) {
+            for (int l = 1; l + 1 < L;) {
+                int took = 0;
+                for (int n = std::min(HS_PYR_CHAIN_MAX, L - l); n >= 2 && !took; n--) {
+                    hs_pyramid_plan_chain(h->lv.data(), l, n, xt.data(), yo.data(), ib.data(), blob, h->pyr_deep[l], HS_PYR_DEEP_LDS);
+                    if (h->pyr_deep[l].valid) took = n;
+                }
+                l += took ? took : 1;
+            }
+        }
         HIP_TRY(h, hipMalloc(&h->d_pyr_tabs, std::max<size_t>(blob.size() * 8, 256)));
         if (!blob.empty()) HIP_TRY(h, hipMemcpy(h->d_pyr_tabs, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
-        for (HsPyrChain& C : h->pyr_chain) {                  // blob offsets -> device pointers
+        for (int which = 0; which < 2; which++)
+        for (HsPyrChain& C : (which ? h->pyr_deep : h->pyr_chain)) {                  // blob offsets -> device pointers
             if (!C.valid) continue;
             for (int i = 0; i < C.nstage; i++) {
                 HsPyrStage& S = C.st[i];
@@ -472,9 +488,11 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     // Level 0 needs no pyramid.  For one or two LARGE frames the chain of launches is latency-bound (dependent pyramid launches, a FAST launch
     // whose duration is its slowest work item, the level-0 quadtree workgroup — 0.11 ms for a 4000 x 3000 frame): level 0's FAST + quadtree run
     // on a second stream BESIDE the pyramid and the other levels' FAST + quadtree, joined before the describe stage.  Same kernels, same
-    // results.  Measured: the 4000 x 3000 "Imaging" extraction 0.245 -> 0.16 ms (config C4: 2 350 -> 3 550 steps/s); a 1080p pair gets SLOWER
-    // (0.132 -> 0.160 ms: the fork / join between the streams costs more than the overlap saves), 16 pairs too (0.468 -> 0.519 ms), hence the
-    // size rule.  Not with stage events (they would serialise the two sequences).
+    // results.  Measured (profiles/README.md row "C4", profiles/r03_bench_lines.json -> c4; the same figures as include/hyslam_amd.h quotes for
+    // hs_orb_set_split): the 4000 x 3000 "Imaging" extraction 0.413 ms unsplit -> 0.207 ms split (config C4: 2 592 -> 4 068 steps/s with both cameras
+    // split); a 1080p pair gets SLOWER (0.132 -> 0.160 ms: the fork / join between the streams costs more than the overlap saves), 16 pairs too
+    // (-7 %), hence the size rule.  Not with stage events (they would serialise the two sequences).  The two concurrent FAST launches rely on every
+    // earlier launch of the handle having completed: a handle is driven from ONE stream at a time (include/hyslam_amd.h).
     // Item width by batch (round 4): a launch of few frames lasts as long as its slowest wave (one stereo pair: 1 904 wide items for 2 816
     // resident single-wave workgroups), so it gets the NARROW items — twice as many, half as long; measured at 1080p (pairs per call: narrow / wide pairs/s): 1: 9 949 / 8 403,
     // 2: 16 029 / 15 642, 4: 23 004 / 22 660, 8: 32 657 / 33 240, 16: 40 917 / 41 507 — from ~18 k items on the wide ones win (fewer, fuller tiles).  HS_FAST_COLS = 32 / 64 forces one list, HS_FAST_NARROW_MAX moves the threshold.
@@ -483,6 +501,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     // Keys by batch as well: the FAST kernel's two global atomics per candidate cost it 5 % at 16 pairs per call (0.162 -> 0.170 ms) and buy the
     // quadtree launch 4 us there (its 256 workgroups fill the chip either way); at one pair per call they cost 1 us and buy 10 (35.1 -> 24.8 us: the
     // level-0 workgroup no longer gathers 5 000 records on one CU).  Both arrays are zero between calls whatever the mode, so the mode may change per call.
+    const HsPyrChain* const deep = (batch <= h->deep_max_batch && !h->pyr_deep.empty()) ? h->pyr_deep.data() : nullptr;      // the pyramid's small-batch plan
     const bool use_keys = h->fast_keys && h->d_fast_qt != nullptr && batch <= h->fast_keys_max_batch;
     const std::vector<HsLevel>& lvh = narrow ? h->lv_n : h->lv;
     const HsLevel* const d_lv = h->d_lv + (narrow ? L : 0);
@@ -524,14 +543,14 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
         if (rc != HS_OK) return rc;
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
         rc = fast(0, n_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
     } else {
         mark(h, 0, s);
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s);
+        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
         mark(h, 1, s);
         const int rc = fast(0, n_items, 0, s);
         if (rc != HS_OK) return rc;
@@ -593,6 +612,30 @@ void run_stereo_fused(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const
 
 } // namespace
 
+// host-side facts of the current configuration (tests: tests/cpp/host_sanitize, tools): launches of the pyramid's standard / small-batch plan,
+// FAST work items per image (wide / narrow), levels with quadtree keys, longest deep chain, its LDS bytes
+void hs_debug_plan_summary(const hs_orb* h, int32_t* out /*[8]*/)
+{
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!h || h->lv.empty()) return;
+    const int L = h->p.nlevels;
+    out[0] = hs_pyramid_launch_count(h->lv.data(), L);
+    int deep_launches = 0, longest = 0, lds = 0;
+    for (int l = 1; l < L; l++) {
+        deep_launches++;
+        if (l < (int)h->pyr_deep.size() && h->pyr_deep[l].valid) {
+            const HsPyrChain& C = h->pyr_deep[l];
+            if (C.nstage > longest) { longest = C.nstage; lds = C.x_bytes + C.h_rows * 512; }
+            l += C.nstage - 1;
+        } else if (h->lv[l].chain_n > 0 && l + h->lv[l].chain_n <= L) l += h->lv[l].chain_n - 1;
+        else if (h->lv[l].fuse_tbx > 0 && l + 1 < L) l++;
+    }
+    out[1] = L > 1 ? deep_launches : 0; out[2] = h->fast_items; out[3] = h->fast_items_n;
+    for (int l = 0; l < L; l++) out[4] += h->lv[l].qt_hist_off != 0xFFFFFFFFu;
+    out[5] = longest; out[6] = lds;
+    if (L > 1 && !h->pyr_deep.empty() && h->pyr_deep[1].valid) out[7] = h->pyr_deep[1].grid_x * h->pyr_deep[1].grid_y;
+}
+
 // accessors for the other translation units of the library (kernels_bow.hip)
 void hs_set_error(hs_orb* h, const char* msg) { if (h) h->err = msg ? msg : ""; }
 int hs_orb_device_of(const hs_orb* h) { return h ? h->device : 0; }
@@ -653,6 +696,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     { const char* e = getenv("HS_FAST_KEYS_MAX_BATCH"); if (e && atoi(e) >= 0) h->fast_keys_max_batch = atoi(e); }
     { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
+    { const char* e = getenv("HS_PYRAMID_DEEP_MAX"); if (e) h->deep_max_batch = atoi(e); }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
     { const char* e = getenv("HS_EXTRACT_SPLIT"); h->split_mode = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;
@@ -779,6 +823,8 @@ int hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, int
     if (!h) return HS_ERR_INVALID;
     if (!d_imgs || !d_kps || !d_desc || !d_n || batch < 1 || row_stride < (size_t)w || cap < 1 || cap > 65535)
         return fail(h, HS_ERR_INVALID, "bad argument");
+    if (((uintptr_t)d_desc & 15) != 0 || (((uintptr_t)d_kps | (uintptr_t)d_n) & 3) != 0)
+        return fail(h, HS_ERR_INVALID, "output alignment: descriptors 16 bytes (they are written with 16-byte vector stores; hs_record_offsets pads for it), keypoints and counts 4");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->lane2 && batch >= 2) {      // two lanes: the second half runs on the child handle's stream, fenced by fork / join events
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -949,6 +995,8 @@ int hs_stereo_frontend_batch_device(hs_orb* h, const uint8_t* d_left, const uint
     if (!d_left || !d_right || !d_kpsL || !d_descL || !d_nL || !d_kpsR || !d_descR || !d_nR || !sp || !d_uRight || !d_depth ||
         pairs < 1 || 2 * pairs > 65535 || row_stride < (size_t)w || cap < 1 || cap > 65535)
         return fail(h, HS_ERR_INVALID, "bad argument");
+    if ((((uintptr_t)d_descL | (uintptr_t)d_descR) & 15) != 0 || (((uintptr_t)d_kpsL | (uintptr_t)d_kpsR | (uintptr_t)d_nL | (uintptr_t)d_nR | (uintptr_t)d_uRight | (uintptr_t)d_depth) & 3) != 0)
+        return fail(h, HS_ERR_INVALID, "output alignment: descriptors 16 bytes (they are written with 16-byte vector stores), everything else 4");
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->lane2 && pairs >= 2) {      // two lanes: each handles half of the pairs end to end (extract L+R, match) on its own stream
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -1061,6 +1109,9 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
         if (rc == HS_OK) rc = ensure_stereo_strips(h, pairs, cap, sp->n_rows);
         if (rc != HS_OK) return rc;
     }
+    // From here on work is ENQUEUED that targets the slot's buffers: whatever fails below, the three streams are drained before the call returns,
+    // so that a slot handed out again (it stays !busy) is never written by a copy or a kernel of the failed attempt.
+    auto enqueue = [&]() -> int {
     // copy-in stream: page-locked frames (hs_host_alloc) go by DMA at link speed and the call returns at once; pageable frames go through the
     // runtime's staging path (the call returns when they are staged) — either way the compute stream keeps running the previous batch
     for (int i = 0; i < batch; i++)
@@ -1097,6 +1148,15 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
     HIP_TRY(h, hipStreamWaitEvent(h->s_out, sl->ev_done, 0));
     HIP_TRY(h, hipMemcpyAsync(sl->h_out, sl->d_out, sl->used, hipMemcpyDeviceToHost, h->s_out));
     HIP_TRY(h, hipEventRecord(sl->ev_out, h->s_out));
+    return HS_OK;
+    };
+    rc = enqueue();
+    if (rc != HS_OK) {
+        const std::string why = h->err;
+        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_out); (void)hipGetLastError();
+        h->err = why;
+        return rc;
+    }
     sl->busy = true; sl->batch = batch; sl->pairs = pairs; sl->cap = cap;
     sl->ticket = h->next_ticket++;
     if (h->next_ticket <= 0) h->next_ticket = 1;
@@ -1113,7 +1173,15 @@ int hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int3
     if (!kps || !desc || !n || (sl->pairs && (!uRight || !depth))) return fail(h, HS_ERR_INVALID, "bad argument");
     if (cap < sl->cap) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipEventSynchronize(sl->ev_out));
+    {
+        const hipError_t e = hipEventSynchronize(sl->ev_out);
+        if (e != hipSuccess) {      // the results will never arrive: drain what can be drained and give the slot back (a ticket that fails must not block its slot for ever)
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_out); (void)hipGetLastError();
+            sl->busy = false;
+            return fail(h, HS_ERR_HIP, std::string("hipEventSynchronize(ticket): ") + hipGetErrorString(e));
+        }
+    }
     const int B = sl->batch, c0 = sl->cap;
     memcpy(n, sl->h_out, (size_t)B * 4);
     for (int i = 0; i < B; i++) {            // only the keypoints that exist are copied, into the caller's [batch][cap] layout
@@ -1128,6 +1196,28 @@ int hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int3
     }
     sl->busy = false;
     return HS_OK;
+}
+
+int hs_orb_cancel(hs_orb* h, int32_t ticket)
+{
+    if (!h) return HS_ERR_INVALID;
+    hs_orb::IngestSlot* sl = nullptr;
+    for (auto& c : h->slot) if (c.busy && c.ticket == ticket) sl = &c;
+    if (!sl || ticket <= 0) return fail(h, HS_ERR_INVALID, "unknown ticket");
+    (void)hipSetDevice(h->device);
+    if (hipEventSynchronize(sl->ev_out) != hipSuccess) {      // let the batch finish (its frames may be read until then), then drop the results
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_out); (void)hipGetLastError();
+    }
+    sl->busy = false;
+    return HS_OK;
+}
+
+int hs_ticket_frames_copied(hs_orb* h, int32_t ticket)
+{
+    if (!h) return HS_ERR_INVALID;
+    for (auto& c : h->slot) if (c.busy && c.ticket == ticket) { const hipError_t e = hipEventQuery(c.ev_in); (void)hipGetLastError(); return e == hipSuccess ? 1 : 0; }
+    return -1;
 }
 
 int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
@@ -1517,13 +1607,16 @@ int hs_hamming_knn2(hs_orb* h, const uint8_t* q, int nq, const uint8_t* t, int n
     return HS_OK;
 }
 
-size_t hs_record_bytes(int cap) { return cap < 0 ? 0 : (size_t)HS_RECORD_HEADER + (size_t)cap * (sizeof(hs_keypoint) + HS_DESC_BYTES); }
+// [ count | pad to 16 | keypoints[cap] | pad to 16 | descriptors[cap][32] ]: the descriptor block starts on a 16-byte boundary whatever the parity of
+// cap (24-byte keypoints), because the describe kernel writes a descriptor as two 16-byte vector stores
+static size_t record_off_desc(int cap) { return ((size_t)HS_RECORD_HEADER + (size_t)std::max(cap, 0) * sizeof(hs_keypoint) + 15) & ~(size_t)15; }
+size_t hs_record_bytes(int cap) { return cap < 0 ? 0 : record_off_desc(cap) + (size_t)cap * HS_DESC_BYTES; }
 
 void hs_record_offsets(int cap, size_t* off_count, size_t* off_kps, size_t* off_desc)
 {
     if (off_count) *off_count = 0;
     if (off_kps) *off_kps = HS_RECORD_HEADER;
-    if (off_desc) *off_desc = (size_t)HS_RECORD_HEADER + (size_t)std::max(cap, 0) * sizeof(hs_keypoint);
+    if (off_desc) *off_desc = record_off_desc(cap);
 }
 
 int hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_stride, int world, int rank, int cap,

@@ -172,9 +172,11 @@ struct HsPyrStage {
     const HsXTab* xt; const HsPyrRow* rows;                                    // its x table and row records [grid.y][slot]: rows y0.. of the tile's region (padded with copies of the last row)
     const HsPyrStageX* tx; const HsPyrStageY* ty;                              // [grid.x], [grid.y]
 };
+#define HS_PYR_DEEP_LDS (120 * 1024)  // LDS a deep chain may plan with (hs_pyramid_plan_chain's lds_max for the small-batch plan)
+#define HS_PYR_CHAIN_MAX 7            // levels one k_resize_chain launch can produce (small batches: the whole pyramid of 8 levels in ONE launch)
 struct HsPyrChain {
     const uint8_t* sbase; uint64_t s_img_stride; int32_t spitch, nstage;       // the source level (sbase == nullptr: the caller's frames)
-    HsPyrStage st[3];
+    HsPyrStage st[HS_PYR_CHAIN_MAX];
     int32_t tbx, lds_pitch, x_bytes, h_rows;                                   // tile width of the last level; LDS: pitch of the source rectangle, bytes of the level buffer, rows of the sums buffer
     int32_t grid_x, grid_y, valid, _r;
 };
@@ -194,10 +196,12 @@ struct HsStripFuse { int32_t enabled, n_rows, n_strips, _r; float size_ref; int3
 inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
 
 // kernels_*.hip launchers (all asynchronous on `s`)
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s);
-// plans a chain over levels [first, first + n) (n = 2 or 3): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the geometry does not fit
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s,
+                       const HsPyrChain* deep = nullptr /*[nlevels], host: the small-batch plan (long chains); used where deep[l].valid*/);
+// plans a chain over levels [first, first + n) (2 <= n <= HS_PYR_CHAIN_MAX): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the
+// geometry does not fit `lds_max` bytes of LDS
 void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
-                           std::vector<uint64_t>& blob, HsPyrChain& C);
+                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max = 60 * 1024);
 // host side of HsPyrFuse for every fused pair: records appended to `blob` (device pointers are blob offsets until hs_api.hip relocates them)
 void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
                              std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse);

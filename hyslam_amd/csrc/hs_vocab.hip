@@ -151,7 +151,12 @@ int load_binary(hs_vocab* v, const char* path)
 
 } // namespace
 
+// why the last hs_vocab_load / hs_vocab_from_tree / hs_vocab_save of THIS thread failed (there is no handle to hang the text on when a load fails)
+static std::string& vocab_error() { static thread_local std::string e; return e; }
+
 extern "C" {
+
+const char* hs_vocab_last_error(void) { return vocab_error().c_str(); }
 
 int hs_vocab_load(const char* path, hs_vocab** out)
 {
@@ -159,7 +164,8 @@ int hs_vocab_load(const char* path, hs_vocab** out)
     *out = nullptr;
     hs_vocab* v = new hs_vocab();
     const int rc = has_suffix(path, ".txt") ? load_text(v, path) : load_binary(v, path);      // ORBVocabulary.cpp:17-21
-    if (rc != HS_OK) { fprintf(stderr, "hs_vocab_load(%s): %s\n", path, v->err.c_str()); delete v; return rc; }
+    if (rc != HS_OK) { vocab_error() = std::string("hs_vocab_load(") + path + "): " + v->err; delete v; return rc; }      // (no diagnostics on stderr from inside a library)
+    vocab_error().clear();
     *out = v;
     return HS_OK;
 }

@@ -441,10 +441,10 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
 // Host side of k_resize_chain for the levels [first, first + n): walks the tiles of the LAST level from the largest tile width downwards until every
 // stage's region fits 256 columns and the LDS buffers, with the expressions of hs_pyramid_build_tables / the two-level kernel.
 void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
-                           std::vector<uint64_t>& blob, HsPyrChain& C)
+                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max)
 {
     C = HsPyrChain{};
-    if (n < 2 || n > 3 || first < 1) return;
+    if (n < 2 || n > HS_PYR_CHAIN_MAX || first < 1) return;
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     for (int i = 0; i < n; i++) {
         const HsLevel& D = h_lv[first + i]; const HsLevel& S = h_lv[first + i - 1];
@@ -546,7 +546,7 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
         pitch = (pitch + 15) & ~15;
         const size_t x_bytes = std::max((size_t)pitch * x_rows0, (size_t)FZ_APITCH * x_rows);
         const size_t lds = ((x_bytes + 15) & ~(size_t)15) + (size_t)h_rows * 256 * 2;
-        if (lds > 60 * 1024) continue;
+        if (lds > lds_max || h_rows > 127 || x_rows > 127) continue;               // (row records address the sums buffer with 16-bit byte offsets: 512 B per row)
         // ---- commit
         if (blob.empty()) blob.push_back(0);
         C.sbase = first == 1 ? nullptr : h_lv[first - 1].base; C.s_img_stride = h_lv[first - 1].img_stride; C.spitch = h_lv[first - 1].pitch; C.nstage = n;
@@ -708,10 +708,29 @@ static int pyr_nw8_wg_per_cu()
     static int v = [] { const char* e = getenv("HS_PYRAMID_NW8"); return e ? atoi(e) : 3; }();
     return v;
 }
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s)
+void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s, const HsPyrChain* deep)
 {
+    static const bool big_lds = [] {      // the deep chains of small batches may want more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess;
+    }();
     for (int l = 1; l < nlevels; l++) {
         const HsLevel& D = h_lv[l];
+        if (deep && deep[l].valid && l + deep[l].nstage <= nlevels) {
+            bool vec16 = true;
+            if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((h_lv[0].w + 15) & ~15) <= (int)img0.row_stride;
+            const HsPyrChain& C = deep[l];
+            const size_t lds = (size_t)C.x_bytes + (size_t)C.h_rows * 256 * 2;
+            if (vec16 && (lds <= 64 * 1024 || big_lds)) {
+                dim3 grid(C.grid_x, C.grid_y, batch);
+                // (measured at one 1080p pair per call, levels 1-7 in one launch of 304 workgroups: 27.6 us with 8 waves per workgroup, 28.8 us with 16 — the
+                //  stages are a dependent sequence inside the workgroup, more waves per stage do not shorten it; three launches of the standard plan: 28.6 us)
+                if ((size_t)grid.x * grid.y * grid.z <= (size_t)256 * pyr_nw8_wg_per_cu()) hipLaunchKernelGGL(k_resize_chain<8>, grid, dim3(512), lds, s, C, img0);
+                else hipLaunchKernelGGL(k_resize_chain<4>, grid, dim3(256), lds, s, C, img0);
+                l += C.nstage - 1;
+                continue;
+            }
+        }
         if (chain && D.chain_n > 0 && chain[l].valid && l + D.chain_n <= nlevels) {
             bool vec16 = true;
             if (l == 1) vec16 = (((uintptr_t)img0.base | (uintptr_t)img0.base2 | img0.row_stride | img0.img_stride) & 15) == 0 && ((h_lv[0].w + 15) & ~15) <= (int)img0.row_stride;

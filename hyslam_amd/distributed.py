@@ -3,7 +3,7 @@
 Frames are independent, so extraction and stereo matching shard across ranks with no data-path collective.  Only
 cross-camera matching needs an exchange: an all-gather of one fixed-size record per rank,
 
-    [ int32 count | 12 B pad | hs_keypoint[cap] (24 B each) | uint8 desc[cap][32] ]      (~113 KB for cap = 2012)
+    [ int32 count | 12 B pad | hs_keypoint[cap] (24 B each) | pad to 16 B | uint8 desc[cap][32] ]      (~113 KB for cap = 2012)
 
 The extractor writes its outputs straight into that layout (the C ABI takes separate pointers, so `d_n`, `d_kps`, `d_desc`
 simply point into one buffer): packing costs nothing and the exchange is ONE collective per step.  On the 8-GPU xGMI mesh
@@ -19,14 +19,18 @@ KP_BYTES = KP_DTYPE.itemsize      # 24
 DESC_BYTES = 32
 
 
+def _off_desc(cap):
+    return (HEADER + cap * KP_BYTES + 15) & ~15       # the descriptors start on a 16-byte boundary whatever the parity of cap (they are written with 16-byte vector stores)
+
+
 def record_bytes(cap):
     """== hs_record_bytes(cap) of the C ABI (tests/test_abi.py checks the two agree)"""
-    return HEADER + cap * (KP_BYTES + DESC_BYTES)
+    return _off_desc(cap) + cap * DESC_BYTES
 
 
 def record_offsets(cap):
     """byte offsets of (count, keypoints, descriptors) inside one record"""
-    return 0, HEADER, HEADER + cap * KP_BYTES
+    return 0, HEADER, _off_desc(cap)
 
 
 def pack_record(kps, desc, cap):

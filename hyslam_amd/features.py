@@ -157,21 +157,39 @@ class ORBExtractor:
         t = C.c_int32()
         N.check(self._h, self._lib.hs_orb_submit_batch(self._h, ptrs, b, w, h, images[0].strides[0], C.byref(sp) if sp is not None else None, C.byref(t)))
         self._tickets = getattr(self, "_tickets", {})
-        self._tickets[t.value] = (b, sp is not None, images)
+        # the ticket remembers ITS output capacity (the geometry may change with a later submit) and keeps the frames alive: the C side reads
+        # them asynchronously until wait() / cancel() returns (include/hyslam_amd.h: lifetime of the frames)
+        self._tickets[t.value] = (b, sp is not None, images, self.max_keypoints())
         return t.value
 
     def wait(self, ticket, out=None):
         """-> (n[b], kps[b, cap], desc[b, cap, 32], uRight[b/2, cap] | None, depth[b/2, cap] | None); entries beyond n[i] are undefined.
         `out` = a tuple of arrays from a previous call to reuse."""
-        b, stereo, _ = self._tickets.pop(ticket)
-        cap = self.max_keypoints()
+        b, stereo, _, cap = self._tickets[ticket]          # looked up, NOT removed: a wait that fails (capacity, arguments) can be repeated
         if out is None:
             out = (np.zeros(b, np.int32), np.zeros((b, cap), KP_DTYPE), np.zeros((b, cap, 32), np.uint8),
                    np.zeros((b // 2, cap), np.float32) if stereo else None, np.zeros((b // 2, cap), np.float32) if stereo else None)
         n, kps, desc, uR, depth = out
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-        N.check(self._h, self._lib.hs_orb_wait(self._h, ticket, p(kps), p(desc), p(n), cap, p(uR), p(depth)))
+        if kps.shape[1] < cap:
+            raise ValueError("wait(): the reused output arrays hold %d keypoints per frame, the ticket needs %d" % (kps.shape[1], cap))
+        try:
+            N.check(self._h, self._lib.hs_orb_wait(self._h, ticket, p(kps), p(desc), p(n), kps.shape[1], p(uR), p(depth)))
+        except HsError as e:
+            if e.status == N.HS_ERR_HIP:                    # the C side has released the slot: the ticket is gone
+                self._tickets.pop(ticket, None)
+            raise
+        del self._tickets[ticket]                           # only now: the results are out and the frames may go
         return out
+
+    def cancel(self, ticket):
+        """give up a ticket: waits until its batch has drained, drops the results"""
+        N.check(self._h, self._lib.hs_orb_cancel(self._h, ticket))
+        self._tickets.pop(ticket, None)
+
+    def frames_copied(self, ticket):
+        """True once the copy-in of `ticket` is complete (its frame buffers may be recycled)"""
+        return self._lib.hs_ticket_frames_copied(self._h, ticket) == 1
 
     def pinned_frames(self, count, h, w):
         """`count` h x w uint8 frames in page-locked host memory (hs_host_alloc): H2D copies from them are plain DMA, no staging.

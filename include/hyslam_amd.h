@@ -101,7 +101,10 @@ int  hs_orb_extract(hs_orb* h, const uint8_t* img, int w, int h_px, int stride,
 int  hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride,
                           hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n);
 /* Device-resident batch: image i starts at d_imgs + i*image_stride, rows `row_stride` bytes apart.
- * d_kps [batch][cap], d_desc [batch][cap][32], d_n [batch]; all device memory.  Asynchronous. */
+ * d_kps [batch][cap], d_desc [batch][cap][32] (16-byte aligned), d_n [batch]; all device memory.  Asynchronous.
+ * ONE STREAM AT A TIME PER HANDLE: the *_device entry points take a caller stream, but a handle's workspace, the FAST kernel's work-queue counter
+ * rotation and its spill halves assume that every call on the handle is ordered after the previous one — drive a handle from one stream (or order the
+ * streams yourself); use separate handles for concurrent streams. */
 int  hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, int w, int h_px,
                                  size_t row_stride, size_t image_stride,
                                  hs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_n, int cap, void* stream);
@@ -115,11 +118,20 @@ int  hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, in
  * uRight / depth [batch/2][cap] (stereo tickets only; NULL otherwise); cap >= hs_orb_max_keypoints().
  * At most TWO tickets may be in flight (two staging slots): a third submit returns HS_ERR_INVALID until the oldest was waited for.
  * Frames in page-locked memory (hs_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) are DMA'd at link speed; pageable frames
- * work too and go through the runtime's staging path. */
+ * work too and go through the runtime's staging path.
+ * LIFETIME OF THE FRAMES: hs_orb_submit_batch returns BEFORE the frames have been read (page-locked frames are DMA'd asynchronously) — they must stay
+ * valid and UNCHANGED until hs_orb_wait (or hs_orb_cancel) for that ticket returns, or until hs_ticket_frames_copied(h, ticket) returns 1 (the
+ * copy-in of that ticket is complete: a capture buffer may be recycled from then on; 0 = not yet, -1 = unknown ticket).  A capture loop that reuses
+ * its buffer right after submit gets silently corrupted features.
+ * hs_orb_cancel(h, ticket): give up a ticket — waits until its batch has drained, drops the results, frees the slot.
+ * A failed hs_orb_submit_batch leaves no ticket and no work behind (the streams are drained before it returns); a hs_orb_wait that fails with
+ * HS_ERR_CAPACITY / HS_ERR_INVALID keeps the ticket (call again with valid arguments), one that fails with HS_ERR_HIP releases it. */
 int  hs_host_alloc(size_t bytes, void** out);
 void hs_host_free(void* p);
 int  hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride, const hs_stereo_params* sp, int32_t* ticket);
 int  hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int32_t* n, int cap, float* uRight, float* depth);
+int  hs_orb_cancel(hs_orb* h, int32_t ticket);
+int  hs_ticket_frames_copied(hs_orb* h, int32_t ticket);
 
 /* ---- stereo: replaces Stereomatcher::computeStereoMatches + getData, src/features/Stereomatcher.cpp:26-156 ---- */
 /* uRight[nL], depth[nL]: -1 where there is no stereo match (Stereomatcher.h:44-47). */
@@ -150,9 +162,12 @@ int  hs_orb_set_lanes(hs_orb* h, int lanes);
 
 /* The launch sequence of an extraction can be SPLIT: level 0 needs no pyramid, so its FAST + quadtree can run on a second stream of the handle
  * beside the pyramid and the other levels' FAST + quadtree (joined before the describe stage; same kernels, same results).  mode -1 (default): split
- * one or two large frames (>= 6 Mpx per call: a 4000 x 3000 "Imaging" frame: 0.24 -> 0.22 ms); 0: never; 1: always.  For an isolated 1080p pair the
- * fork / join between the streams costs more than the overlap saves (0.132 -> 0.160 ms), but when several handles share the GPU (hySLAM's SLAM stereo
- * camera + Imaging camera, BASELINE config 4) splitting BOTH lets their kernels interleave: 2 400 -> 3 500 steps/s.  Ignored while stage events are on. */
+ * one or two large frames (>= 6 Mpx per call); 0: never; 1: always.  Measured (profiles/README.md, row "C4"; profiles/r03_bench_lines.json -> c4): the
+ * 4000 x 3000 "Imaging" extraction 0.413 ms unsplit (round 2) -> 0.207 ms split; for an isolated 1080p pair the fork / join between the streams costs
+ * more than the overlap saves (0.132 -> 0.160 ms in round 3), but when several handles share the GPU (hySLAM's SLAM stereo camera + Imaging camera,
+ * BASELINE config 4) splitting BOTH lets their kernels interleave: 2 592 -> 4 068 steps/s.  Ignored while stage events are on.
+ * The two concurrent FAST launches of a split call rely on every earlier launch of the handle having completed — one more reason for the
+ * one-stream-at-a-time rule of the *_device entry points (see hs_orb_extract_batch_device). */
 int  hs_orb_set_split(hs_orb* h, int mode);
 
 /* block until everything enqueued on the handle's own stream (or `stream`) has finished */
@@ -306,6 +321,8 @@ typedef struct hs_vocab_tree {
  * tools/bin_vocabulary.cc).  DBoW2 and the vocabulary file are external to the reference; the formats are restated from the published ORB-SLAM2
  * DBoW2 sources (hs_vocab.hip).  Host only, no device needed.  hs_vocab_get_tree's arrays stay valid until hs_vocab_destroy. */
 typedef struct hs_vocab hs_vocab;
+/* text of the last failed hs_vocab_load on the calling thread ("" after a success): the loaders print nothing */
+const char* hs_vocab_last_error(void);
 int  hs_vocab_load(const char* path, hs_vocab** out);
 int  hs_vocab_from_tree(const hs_vocab_tree* tree, int k, hs_vocab** out);      /* deep copy of a caller-built flat tree (synthetic vocabularies) */
 int  hs_vocab_save(const hs_vocab* v, const char* path);                        /* ".txt" -> text, else binary: tools/bin_vocabulary.cc's conversion */
@@ -346,8 +363,10 @@ int  hs_hamming_knn2_device(hs_orb* h, const uint8_t* d_q, int nq, const uint8_t
                             int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
 
 /* ---- frame records: the fixed-size unit of the cross-camera exchange (BASELINE config 5; new — the reference has no
- * multi-camera exchange).  record = { int32 count; 12 bytes pad; hs_keypoint kps[cap]; uint8 desc[cap][32] }: the extractor's three
- * outputs laid out in one buffer, so hs_orb_extract_batch_device writes a frame straight into the all-gather message. */
+ * multi-camera exchange).  record = { int32 count; 12 bytes pad; hs_keypoint kps[cap]; pad to a 16-byte boundary; uint8 desc[cap][32] }: the
+ * extractor's three outputs laid out in one buffer, so hs_orb_extract_batch_device writes a frame straight into the all-gather message (the
+ * device entry points want the descriptor block 16-byte aligned — it is written with 16-byte vector stores — hence the padding for odd cap;
+ * put the records themselves at 16-byte aligned addresses with a stride that is a multiple of 16: hs_record_bytes is). */
 #define HS_RECORD_HEADER 16
 size_t hs_record_bytes(int cap);
 void   hs_record_offsets(int cap, size_t* off_count, size_t* off_kps, size_t* off_desc);

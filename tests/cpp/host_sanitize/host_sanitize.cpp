@@ -1,0 +1,173 @@
+// host_sanitize.cpp — drives the PRODUCT's host code (everything in hyslam_amd/csrc that does not run on the GPU) under AddressSanitizer +
+// UndefinedBehaviorSanitizer, CPU only: the library's translation units compiled host-only and linked against hip_stub.cpp (device memory =
+// host memory, launches = no-ops).  Covered: hs_orb_create's tables, configure_impl's geometry for a random sweep of frame sizes / scale factors /
+// level counts / cell sizes / feature counts (the sweep of tests/test_gpu_parity.py plus extremes): pyramid fusion, chain and deep-chain planners,
+// FAST work items (wide and narrow), quadtree key tables, workspace sizing and uploads; the host-pointer entry points' staging (extract, batch,
+// stereo, the matchers' CSR / scratch handling), the ingest ticket state machine (submit / wait, errors, both slots busy), and the vocabulary
+// loaders on valid, truncated and randomly corrupted text / binary files (hs_vocab_last_error instead of stderr).
+// usage: host_sanitize [seed] [geometries] [vocab_cases]      prints "HOST SANITIZE OK ..." (any sanitizer report aborts with a non-zero status)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include <unistd.h>
+#include "../../../include/hyslam_amd.h"
+
+extern "C" long hip_stub_launches();
+void hs_debug_plan_summary(const hs_orb* h, int32_t* out /*[8]*/);        // hs_api.hip: launches of the pyramid's two plans, item counts (host-side facts of the last configuration)
+
+#define CHECK(c) do { if (!(c)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static std::mt19937_64 rng;
+static int rnd(int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); }
+
+static int geometry_case(int w, int h, int nfeat, float scale, int levels, int cell, int batch, bool exercise)
+{
+    hs_orb_params p; hs_orb_default_params(&p);
+    p.nfeatures = nfeat; p.scale_factor = scale; p.nlevels = levels; p.cell_px = cell;
+    hs_orb* ex = nullptr;
+    int st = hs_orb_create(&p, 0, &ex);
+    if (st != HS_OK) return 0;                                   // rejected parameter combinations (quota > LDS list, ...) are fine: no crash is the point
+    st = hs_orb_reserve(ex, w, h, batch);
+    int ok = 0;
+    if (st == HS_OK) {
+        ok = 1;
+        int32_t plan[8]; hs_debug_plan_summary(ex, plan);
+        if (plan[0] <= 0 && levels > 1) { printf("no pyramid launches for %dx%d levels %d\n", w, h, levels); return -1; }
+        const int cap = hs_orb_max_keypoints(ex);
+        if (exercise && cap > 0) {
+            std::vector<uint8_t> img((size_t)w * h);
+            for (auto& v : img) v = (uint8_t)rng();
+            std::vector<hs_keypoint> k((size_t)batch * cap); std::vector<uint8_t> d((size_t)batch * cap * 32); std::vector<int32_t> n(batch, -1);
+            std::vector<const uint8_t*> ptrs(batch, img.data());
+            st = hs_orb_extract_batch(ex, ptrs.data(), batch, w, h, w, k.data(), d.data(), cap, n.data());
+            if (st != HS_OK) { printf("extract_batch %dx%d: %s\n", w, h, hs_orb_last_error(ex)); return -1; }
+            // the ingest tickets: two in flight, a third is refused, waits in both orders, a wait with too small a capacity keeps the ticket
+            hs_stereo_params sp{ 500.f, 60.f, h, 100.f, 50.f, 31.f };
+            if (batch % 2 == 0) {
+                int32_t t1 = 0, t2 = 0, t3 = 0;
+                if (hs_orb_submit_batch(ex, ptrs.data(), batch, w, h, w, &sp, &t1) != HS_OK) { printf("submit: %s\n", hs_orb_last_error(ex)); return -1; }
+                if (hs_orb_submit_batch(ex, ptrs.data(), batch, w, h, w, &sp, &t2) != HS_OK) return -1;
+                if (hs_orb_submit_batch(ex, ptrs.data(), batch, w, h, w, &sp, &t3) == HS_OK) { printf("a third ticket was accepted\n"); return -1; }
+                std::vector<float> ur((size_t)batch / 2 * cap), dz((size_t)batch / 2 * cap);
+                if (hs_orb_wait(ex, t2, k.data(), d.data(), n.data(), 1, ur.data(), dz.data()) == HS_OK) { printf("a wait with cap 1 passed\n"); return -1; }      // (the ticket stays valid)
+                if (hs_orb_wait(ex, t2, k.data(), d.data(), n.data(), cap, ur.data(), dz.data()) != HS_OK) { printf("wait t2: %s\n", hs_orb_last_error(ex)); return -1; }
+                if (hs_orb_wait(ex, t1, k.data(), d.data(), n.data(), cap, ur.data(), dz.data()) != HS_OK) return -1;
+                if (hs_orb_wait(ex, t1, k.data(), d.data(), n.data(), cap, ur.data(), dz.data()) == HS_OK) { printf("a ticket was waited for twice\n"); return -1; }
+            }
+            // stereo matcher + 2-NN on host arrays (staging sizes follow nL / nR)
+            const int nL = rnd(0, 300), nR = rnd(0, 300);
+            std::vector<hs_keypoint> kl(std::max(nL, 1)), kr(std::max(nR, 1)); std::vector<uint8_t> dl((size_t)std::max(nL, 1) * 32), dr((size_t)std::max(nR, 1) * 32);
+            for (auto& q : kl) { q.x = (float)rnd(0, w); q.y = (float)rnd(-5, h + 5); q.size = 31.f; q.octave = rnd(0, 7); }
+            for (auto& q : kr) { q.x = (float)rnd(0, w); q.y = (float)rnd(-5, h + 5); q.size = 31.f; q.octave = rnd(0, 7); }
+            std::vector<float> ur(std::max(nL, 1)), dz(std::max(nL, 1));
+            if (hs_stereo_match(ex, kl.data(), dl.data(), nL, kr.data(), dr.data(), nR, &sp, ur.data(), dz.data()) != HS_OK) { printf("stereo: %s\n", hs_orb_last_error(ex)); return -1; }
+            std::vector<int32_t> bi(std::max(nL, 1)), bd(std::max(nL, 1)), sd(std::max(nL, 1));
+            if (nL > 0 && nR > 0 && hs_hamming_knn2(ex, dl.data(), nL, dr.data(), nR, bi.data(), bd.data(), sd.data()) != HS_OK) return -1;
+        }
+    }
+    hs_orb_destroy(ex);
+    return ok;
+}
+
+// a small valid vocabulary (k-ary tree of `levels` levels), saved as text and binary through the library's own writer
+static hs_vocab* make_vocab(int k, int levels, std::vector<int32_t>& cb, std::vector<int32_t>& cc, std::vector<uint8_t>& desc, std::vector<int32_t>& word, std::vector<float>& weight)
+{
+    int n = 1, width = 1;
+    for (int l = 1; l <= levels; l++) { width *= k; n += width; }
+    cb.assign(n, 0); cc.assign(n, 0); desc.resize((size_t)n * 32); word.assign(n, -1); weight.assign(n, 0.f);
+    for (auto& v : desc) v = (uint8_t)rng();
+    int next = 1, words = 0;
+    std::vector<int> level(n, 0);
+    for (int i = 0; i < n; i++) {
+        if (level[i] < levels && next + k <= n) { cb[i] = next; cc[i] = k; for (int c = 0; c < k; c++) level[next + c] = level[i] + 1; next += k; }
+        else { word[i] = words++; weight[i] = 0.5f + (float)(rng() % 100) / 100.f; }
+    }
+    hs_vocab_tree T{ n, levels, cb.data(), cc.data(), desc.data(), word.data(), weight.data(), nullptr };
+    hs_vocab* v = nullptr;
+    return hs_vocab_from_tree(&T, k, &v) == HS_OK ? v : nullptr;
+}
+
+static std::vector<uint8_t> slurp(const std::string& p) { std::vector<uint8_t> b; FILE* f = fopen(p.c_str(), "rb"); if (!f) return b; int c; while ((c = fgetc(f)) != EOF) b.push_back((uint8_t)c); fclose(f); return b; }
+static void spit(const std::string& p, const std::vector<uint8_t>& b) { FILE* f = fopen(p.c_str(), "wb"); if (f) { if (!b.empty()) fwrite(b.data(), 1, b.size(), f); fclose(f); } }
+
+int main(int argc, char** argv)
+{
+    if (argc > 3 && !strcmp(argv[1], "plan")) {                 // host_sanitize plan W H [nfeat scale levels]: the host-side plan of a geometry
+        hs_orb_params p; hs_orb_default_params(&p);
+        p.nfeatures = argc > 4 ? atoi(argv[4]) : 2000; if (argc > 5) p.scale_factor = (float)atof(argv[5]); if (argc > 6) p.nlevels = atoi(argv[6]);
+        hs_orb* ex = nullptr;
+        CHECK(hs_orb_create(&p, 0, &ex) == HS_OK && hs_orb_reserve(ex, atoi(argv[2]), atoi(argv[3]), 2) == HS_OK);
+        int32_t s[8]; hs_debug_plan_summary(ex, s);
+        printf("pyramid launches: standard plan %d, small-batch plan %d (longest chain %d levels, %d B of LDS, %d workgroups per frame); FAST items per frame: %d wide, %d narrow; levels with quadtree keys: %d\n",
+               s[0], s[1], s[5], s[6], s[7], s[2], s[3], s[4]);
+        hs_orb_destroy(ex);
+        return 0;
+    }
+    const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+    const int n_geo = argc > 2 ? atoi(argv[2]) : 120, n_voc = argc > 3 ? atoi(argv[3]) : 400;
+    rng.seed(seed);
+    int ndev = 0;
+    CHECK(hs_device_count(&ndev) == HS_OK && ndev == 1);
+
+    // ---- geometry: the fixed shapes of the GPU suites, then the random sweep
+    int accepted = 0, tried = 0;
+    const int fixed[][7] = { {640, 480, 1000, 120, 8, 30, 2}, {1920, 1080, 2000, 120, 8, 30, 2}, {1920, 1080, 2000, 120, 8, 30, 32}, {4000, 3000, 3000, 140, 8, 30, 1},
+                             {643, 481, 700, 120, 8, 30, 1}, {3840, 2160, 2000, 120, 8, 30, 1}, {2560, 40, 500, 120, 3, 30, 1}, {64, 64, 100, 120, 8, 30, 1}, {33, 33, 50, 200, 12, 12, 4},
+                             {1200, 300, 1500, 120, 6, 30, 1}, {1900, 200, 1200, 120, 3, 30, 1}, {16384, 64, 100, 110, 2, 62, 1}, {1920, 1080, 9000, 120, 8, 30, 1}, {800, 600, 1500, 140, 8, 62, 2} };
+    for (const auto& f : fixed) {
+        const int r = geometry_case(f[0], f[1], f[2], f[3] / 100.f, f[4], f[5], f[6], (size_t)f[0] * f[1] * f[6] < 6000000);
+        CHECK(r >= 0); accepted += r; tried++;
+    }
+    for (int i = 0; i < n_geo; i++) {
+        const int w = rnd(1, 10) == 1 ? rnd(20, 120) : rnd(64, 2600), h = rnd(1, 10) == 1 ? rnd(20, 120) : rnd(64, 1600);
+        const int r = geometry_case(w, h, rnd(20, 4000), 1.1f + 0.01f * (float)rnd(0, 90), rnd(1, 12), rnd(1, 8) == 1 ? rnd(8, 70) : 30, rnd(1, 5), (size_t)w * h < 1500000);
+        CHECK(r >= 0); accepted += r; tried++;
+    }
+    CHECK(accepted > tried / 2);
+
+    // ---- vocabulary files: valid round trips, then truncations and random corruptions of both formats
+    char dir[] = "/tmp/hs_host_sanitize_XXXXXX";
+    CHECK(mkdtemp(dir) != nullptr);
+    const std::string ptxt = std::string(dir) + "/v.txt", pbin = std::string(dir) + "/v.bin", pbad_t = std::string(dir) + "/bad.txt", pbad_b = std::string(dir) + "/bad.bin";
+    std::vector<int32_t> cb, cc, word; std::vector<uint8_t> desc; std::vector<float> weight;
+    hs_vocab* v = make_vocab(4, 3, cb, cc, desc, word, weight);
+    CHECK(v != nullptr);
+    CHECK(hs_vocab_save(v, ptxt.c_str()) == HS_OK && hs_vocab_save(v, pbin.c_str()) == HS_OK);
+    hs_vocab_destroy(v);
+    int loaded = 0, refused = 0;
+    for (const std::string& p : { ptxt, pbin }) {
+        hs_vocab* a = nullptr;
+        CHECK(hs_vocab_load(p.c_str(), &a) == HS_OK && a && hs_vocab_last_error()[0] == 0);
+        int32_t k, L, nn, nw, sc, wt;
+        CHECK(hs_vocab_info(a, &k, &L, &nn, &nw, &sc, &wt) == HS_OK && k == 4 && L == 3 && nw == 64);
+        hs_vocab_destroy(a);
+    }
+    CHECK(hs_vocab_load((std::string(dir) + "/missing.txt").c_str(), &v) != HS_OK && hs_vocab_last_error()[0] != 0);
+    const std::vector<uint8_t> good_t = slurp(ptxt), good_b = slurp(pbin);
+    CHECK(!good_t.empty() && !good_b.empty());
+    for (int i = 0; i < n_voc; i++) {
+        const bool text = i & 1;
+        std::vector<uint8_t> b = text ? good_t : good_b;
+        const int kind = rnd(0, 3);
+        if (kind == 0) b.resize((size_t)rnd(0, (int)b.size()));                                                      // truncated
+        else if (kind == 1) for (int j = 0, m = rnd(1, 8); j < m; j++) b[(size_t)rnd(0, (int)b.size() - 1)] = (uint8_t)rng();         // a few bytes
+        else if (kind == 2) { const size_t at = (size_t)rnd(0, (int)b.size() - 1); for (size_t j = at; j < b.size() && j < at + 16; j++) b[j] = text ? (uint8_t)"9-.e 7"[rng() % 6] : (uint8_t)0xFF; }   // a run (huge numbers / counts)
+        else { const size_t at = (size_t)rnd(0, (int)b.size()); b.insert(b.begin() + at, (size_t)rnd(1, 64), text ? (uint8_t)' ' : (uint8_t)rng()); }               // inserted bytes
+        const std::string& p = text ? pbad_t : pbad_b;
+        spit(p, b);
+        hs_vocab* a = nullptr;
+        const int st = hs_vocab_load(p.c_str(), &a);
+        if (st == HS_OK) {                                                                                            // still well-formed: it must be usable
+            CHECK(a != nullptr);
+            hs_vocab_tree T; CHECK(hs_vocab_get_tree(a, &T) == HS_OK && T.n_nodes >= 2);
+            hs_vocab_destroy(a); loaded++;
+        } else { CHECK(a == nullptr && hs_vocab_last_error()[0] != 0); refused++; }
+    }
+    unlink(ptxt.c_str()); unlink(pbin.c_str()); unlink(pbad_t.c_str()); unlink(pbad_b.c_str()); rmdir(dir);
+    printf("HOST SANITIZE OK seed %llu: %d of %d geometries configured, %ld kernel launches issued into the stub, %d corrupted vocabularies refused, %d still well-formed\n",
+           (unsigned long long)seed, accepted, tried, hip_stub_launches(), refused, loaded);
+    return 0;
+}

@@ -75,7 +75,8 @@ def test_two_rank_allgather_and_identical_match_lists():
 def test_record_layout_and_sharding():
     from hyslam_amd import distributed as D
     cap = 50
-    assert D.record_bytes(cap) == 16 + cap * 56 and D.record_offsets(cap) == (0, 16, 16 + cap * 24)
+    assert D.record_bytes(cap) == 16 + cap * 56 and D.record_offsets(cap) == (0, 16, 16 + cap * 24)           # an even cap needs no padding
+    assert D.record_offsets(51) == (0, 16, (16 + 51 * 24 + 15) & ~15) and D.record_offsets(51)[2] % 16 == 0 and D.record_bytes(51) == D.record_offsets(51)[2] + 51 * 32
     rng = np.random.default_rng(0)
     from hyslam_amd._native import KP_DTYPE
     k = np.zeros(7, KP_DTYPE); k["x"] = rng.random(7); k["octave"] = np.arange(7)

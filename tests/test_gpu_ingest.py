@@ -75,3 +75,40 @@ def test_mono_tickets_change_of_geometry_and_capacity_check(gpu):
     assert st == N.HS_ERR_CAPACITY
     r3 = ex.wait(t3)
     assert np.array_equal(r3[0], r1[0])
+
+
+def test_ticket_survives_a_failed_wait_and_can_be_cancelled(gpu):
+    """the Python binding keeps a ticket (and the frames it reads from) until hs_orb_wait has SUCCEEDED: a wait with too small reused arrays
+    raises and can be repeated; a ticket waited for after a later submit of ANOTHER geometry still gets arrays of its own capacity;
+    cancel() frees the slot; frames_copied() turns true"""
+    import time
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=800))
+    p = oracle.default_params(800)
+    a = [synth_image(60 + i, 512, 384) for i in range(2)]
+    wide = [synth_image(90, 1500, 220)]                                   # 7 root nodes per level: a larger max_keypoints() than the first geometry's
+    t1 = ex.submit_batch(a)
+    cap1 = ex._tickets[t1][3]
+    t2 = ex.submit_batch(wide)
+    assert ex._tickets[t2][3] >= cap1
+    small = (np.zeros(2, np.int32), np.zeros((2, 10), N.KP_DTYPE), np.zeros((2, 10, 32), np.uint8), None, None)
+    with pytest.raises(ValueError):
+        ex.wait(t1, small)
+    assert t1 in ex._tickets
+    r1 = ex.wait(t1)                                                       # sized by the ticket's own capacity, not by the current geometry's
+    assert r1[1].shape[1] == cap1
+    for i, f in enumerate(a):
+        ok, od = oracle.extract(p, f)
+        assert r1[0][i] == len(ok) and r1[1][i, :r1[0][i]].tobytes() == ok.tobytes() and np.array_equal(r1[2][i, :r1[0][i]], od)
+    assert t1 not in ex._tickets
+    with pytest.raises(KeyError):
+        ex.wait(t1)
+    for _ in range(2000):
+        if ex.frames_copied(t2):
+            break
+        time.sleep(0.001)
+    assert ex.frames_copied(t2)
+    ex.cancel(t2)
+    assert t2 not in ex._tickets and ex._lib.hs_ticket_frames_copied(ex._h, t2) == -1
+    t3, t4 = ex.submit_batch(a), ex.submit_batch(a)                        # both slots are free again
+    r3, r4 = ex.wait(t3), ex.wait(t4)
+    assert np.array_equal(r3[0], r1[0]) and r3[1][0, :r3[0][0]].tobytes() == r4[1][0, :r4[0][0]].tobytes()

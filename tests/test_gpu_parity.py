@@ -217,7 +217,7 @@ def test_blur_saturation_white_blocks(gpu):
 
 @pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_EXTRACT_SPLIT": "1"}, {"HS_EXTRACT_SPLIT": "0"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"},
-                                 {"HS_PYRAMID_CHAIN": "2"}, {"HS_PYRAMID_CHAIN": "0"}, {"HS_PYRAMID_NW8": "100000"}, {"HS_PYRAMID_NW8": "0"},
+                                 {"HS_PYRAMID_CHAIN": "2"}, {"HS_PYRAMID_CHAIN": "0"}, {"HS_PYRAMID_DEEP_MAX": "0"}, {"HS_PYRAMID_DEEP_MAX": "100000"}, {"HS_PYRAMID_DEEP_MAX": "100000", "HS_PYRAMID_NW8": "0"}, {"HS_PYRAMID_NW8": "100000"}, {"HS_PYRAMID_NW8": "0"},
                                  {"HS_FAST_ORDER": "0"}, {"HS_FAST_ORDER": "2"}, {"HS_FAST_IMAGE_MAJOR": "1"},
                                  # the work queues (what every launch used until round 3; now the launches of > 2 units per workgroup) on wide and on narrow items
                                  {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64"}, {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64", "HS_FAST_NQ": "8"},
@@ -233,7 +233,8 @@ def test_blur_saturation_white_blocks(gpu):
 def test_fast_kernel_variants_in_subprocess(gpu, env):
     """the FAST kernel's tile-width variants (narrow / wide work items forced whatever the batch), its two schedules (folded static for small
     launches, work queues) forced on both widths, its list-overflow (flush) paths forced by a tiny LDS list, NMS driven from the score
-    tile instead of the corner list, the quadtree's point-domain passes, the pyramid's chain kernel for every fused group / for none and its
+    tile instead of the corner list, the quadtree's point-domain passes, the pyramid's chain kernel for every fused group / for none, its deep
+    chains (small batches: as many levels per launch as the LDS holds — all seven at 1080p) never / for every batch, and its
     8-wave / 4-wave workgroups forced, and the split launch sequence (level 0's FAST + quadtree on a second
     stream beside the pyramid) forced on / off: same bits as the oracle"""
     e = dict(os.environ)

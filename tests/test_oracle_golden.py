@@ -39,3 +39,24 @@ def test_stereo_golden():
     # depth is mbf/disparity wherever a match survived
     m = depth > 0
     assert np.array_equal(depth[m], np.float32(float(g["fx"]) * 0.12) / (kL["x"][m] - uR[m]))
+
+
+def test_committed_boundary_dump_is_what_the_oracle_computes():
+    """tests/golden/oracle_boundaries.npz (inputs + the oracle's outputs at the four cv:: call sites, for tools/check_with_opencv.py on a machine that
+    has OpenCV 3.4) must stay in step with the oracle: every array's sha256 is committed beside it and recomputed here"""
+    import hashlib
+    import json
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(g, "oracle_boundaries.sha256.json")))
+    d = np.load(os.path.join(g, "oracle_boundaries.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert set(d.files) == set(meta["arrays_sha256"])
+    for k in d.files:
+        assert sha(d[k]) == meta["arrays_sha256"][k], k
+    img, cell = d["image"], d["cell"]
+    assert np.array_equal(oracle.fast(img, 20, True), d["fast_image"]) and np.array_equal(oracle.fast(cell, 20, True), d["fast_cell"])
+    assert np.array_equal(oracle.resize_linear(img, 533, 400), d["resize_533x400"]) and np.array_equal(oracle.resize_linear(img, 457, 343), d["resize_457x343"])
+    assert np.array_equal(oracle.gaussian_blur7(img), d["blur_default_taps"])
+    assert np.array_equal(oracle.gaussian_blur7(img, [16, 34, 50, 56, 50, 34, 16]), d["blur_256sum_taps"])
+    at = np.array([oracle.lib().hso_fast_atan2(float(a), float(b)) for a, b in zip(d["atan_y"][:2000], d["atan_x"][:2000])], np.float32)
+    assert np.array_equal(at, d["atan_deg"][:2000])

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4: the pyramid's small-batch plan (deep chains: levels 1-7 of a 1080p frame in one launch)
+OUT=gpurun_out/${1:-r4h}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_fuzz.py tests/test_adaptor.py -m gpu -q -x > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+tail -8 $OUT/pytest.log
+for b in 1 2 4 8; do
+  for k in 0 100000; do
+    HS_PYRAMID_DEEP_MAX=$k timeout 300 python3 bench.py --cpu-seconds 0 --pcie-seconds 0 --call-site 0 --pairs $b --steps 100 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pairs $b deep $k:', d['value'], round(d['ms_per_step']/d['inner_repeats']*1000/$b,1), 'us/pair', d['parity_checksum_ok'], d['stage_ms_per_step'])"
+  done
+done 2>&1 | tee $OUT/sweep.txt
+for b in 8 16; do
+  for k in 0 100000; do
+    HS_FAST_KEYS_MAX_BATCH=$k timeout 300 python3 bench.py --cpu-seconds 0 --pcie-seconds 0 --call-site 0 --pairs $b --steps 100 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pairs $b keys max batch $k:', d['value'], d['parity_checksum_ok'], d['stage_ms_per_step'])"
+  done
+done 2>&1 | tee -a $OUT/sweep.txt
+bash tools/kernel_timeline.sh --pairs 1 --min-timed-ms 0 > $OUT/kt1.txt 2>&1; cat $OUT/kt1.txt
