@@ -65,6 +65,8 @@ struct hs_orb {
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
     std::vector<HsPyrFuse> pyr_fuse;   // [level]: kernel argument of the pair (level, level + 1) when it is fused
     std::vector<HsPyrChain> pyr_deep;  // [level]: the small-batch plan — chains as long as the LDS allows (8 levels: all seven in ONE launch); valid = 0 where none starts
+    int deep_rows = 8;                 // HS_PYRAMID_DEEP_ROWS (read once): rows of the LAST level per tile in the small-batch plan (a workgroup's stages are a dependent
+                                       // sequence whose length goes with the rows per wave: more, flatter tiles shorten the launch although their halo rows cost more work)
     int deep_max_batch = 2;            // HS_PYRAMID_DEEP_MAX (read once): calls of at most this many frames use the small-batch plan (0 = never)
     std::vector<HsPyrChain> pyr_chain; // [level]: kernel argument of the chain launch that starts at this level (HsLevel::chain_n levels)
     int chain_mode = -1;               // HS_PYRAMID_CHAIN (read once): -1 = a three-level chain for the tail of an odd number of levels, 0 = never, 2 = chains for every fused pair too (parity tests)
@@ -353,7 +355,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
             for (int l = 1; l + 1 < L;) {
                 int took = 0;
                 for (int n = std::min(HS_PYR_CHAIN_MAX, L - l); n >= 2 && !took; n--) {
-                    hs_pyramid_plan_chain(h->lv.data(), l, n, xt.data(), yo.data(), ib.data(), blob, h->pyr_deep[l], HS_PYR_DEEP_LDS);
+                    hs_pyramid_plan_chain(h->lv.data(), l, n, xt.data(), yo.data(), ib.data(), blob, h->pyr_deep[l], HS_PYR_DEEP_LDS, h->deep_rows);
                     if (h->pyr_deep[l].valid) took = n;
                 }
                 l += took ? took : 1;
@@ -697,6 +699,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
     { const char* e = getenv("HS_PYRAMID_DEEP_MAX"); if (e) h->deep_max_batch = atoi(e); }
+    { const char* e = getenv("HS_PYRAMID_DEEP_ROWS"); if (e && atoi(e) >= 2) h->deep_rows = atoi(e); }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }
     { const char* e = getenv("HS_EXTRACT_SPLIT"); h->split_mode = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     bool zero = true; for (int k = 0; k < 7; k++) zero = zero && p->blur_taps[k] == 0;

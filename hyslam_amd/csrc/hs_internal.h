@@ -201,7 +201,7 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse
 // plans a chain over levels [first, first + n) (2 <= n <= HS_PYR_CHAIN_MAX): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the
 // geometry does not fit `lds_max` bytes of LDS
 void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
-                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max = 60 * 1024);
+                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max = 60 * 1024, int tile_rows = 0 /*rows of the last level per tile; 0 = the two-level kernel's 16*/);
 // host side of HsPyrFuse for every fused pair: records appended to `blob` (device pointers are blob offsets until hs_api.hip relocates them)
 void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
                              std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse);

@@ -355,9 +355,20 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
 // columns, combines them vertically into its region, stores the part of the region the workgroup OWNS and keeps the region in LDS for the next
 // stage.  Everything wave-uniform comes from two 32-byte records per stage (HsPyrStageX / HsPyrStageY, hs_pyramid_plan_chain).  Used for
 // the last THREE levels of a pyramid with an odd number of levels to make (levels 5, 6, 7 of 8: one launch instead of two).
+#ifdef HS_PYR_PROFILE      // make EXTRA=-DHS_PYR_PROFILE: clock stamps of workgroup (0, 0, 0) of every k_resize_chain launch (tools/pyramid_phase_profile.py)
+__device__ unsigned long long g_pyr_prof[64];
+extern "C" void hs_debug_pyr_profile(unsigned long long* out64) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_pyr_prof), sizeof(unsigned long long) * 64); }
+#define PYR_MARK() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && pk < 62) g_pyr_prof[pk++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PYR_MARK()
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 img0)
 {
+#ifdef HS_PYR_PROFILE
+    int pk = 0;
+#endif
+    PYR_MARK();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const s_x = smem;                                                           // source rectangle (stage 0) / region of the previous stage
     uint16_t* const s_h = reinterpret_cast<uint16_t*>(smem + F.x_bytes);                 // [h_rows][256] (H >> 4)
@@ -368,10 +379,22 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
     if (F.sbase == nullptr) { sbase = hs_img0_ptr(img0, img); spitch = (uint32_t)img0.row_stride; }
     else { sbase = F.sbase + (size_t)img * F.s_img_stride; spitch = (uint32_t)F.spitch; }
     int src_pitch = F.lds_pitch;
+    // The stages are a dependent sequence inside the workgroup, and every stage starts with two dependent fetches: its tile records (scalar loads) and,
+    // addressed by them, the four x-table entries of every lane.  At one workgroup per CU (small batches: the deep chains) nothing hides them, so
+    // they are software-pipelined: the records of stage st + 1 are requested at the top of stage st, its x-table entries between the two passes.
+    auto ld_x = [&](int st) { return __builtin_bit_cast(HsPyrStageX, hs_cload<hs_u32x8>(&F.st[st].tx[blockIdx.x])); };
+    auto ld_y = [&](int st) { return __builtin_bit_cast(HsPyrStageY, hs_cload<hs_u32x8>(&F.st[st].ty[blockIdx.y])); };
+    auto ld_t = [&](int st, const HsPyrStageX& X, uint64_t (&t)[4]) {
+        const HsPyrStage& S = F.st[st];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = hs_gload<uint64_t>(&S.xt[min(X.x0 + 4 * tx + i, S.w - 1)]);
+    };
+    HsPyrStageX X = ld_x(0); HsPyrStageY Y = ld_y(0);
+    uint64_t traw[4]; ld_t(0, X, traw);
     for (int st = 0; st < F.nstage; st++) {
         const HsPyrStage& S = F.st[st];
-        const HsPyrStageX X = __builtin_bit_cast(HsPyrStageX, hs_cload<hs_u32x8>(&S.tx[blockIdx.x]));
-        const HsPyrStageY Y = __builtin_bit_cast(HsPyrStageY, hs_cload<hs_u32x8>(&S.ty[blockIdx.y]));
+        const int stn = min(st + 1, F.nstage - 1);                   // (the last stage re-requests its own records: harmless, keeps the loads unconditional)
+        const HsPyrStageX Xn = ld_x(stn); const HsPyrStageY Yn = ld_y(stn);
         if (st == 0) {                                               // the source rectangle: a wave takes whole rows, floor(64 / nvec) at a time
             const uint8_t* const src0 = hs_uniform_ptr(sbase + (size_t)Y.src_y0 * spitch + X.src_x0);
             const int nvec = X.nvec;
@@ -389,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
         {
             HsXTab t[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, hs_gload<uint64_t>(&S.xt[min(X.x0 + 4 * tx + i, S.w - 1)]));
+            for (int i = 0; i < 4; i++) t[i] = __builtin_bit_cast(HsXTab, traw[i]);
             const int o0 = t[0].sx - X.src_x0;
             wbase = o0 & ~3; wshift = o0 & 3;
 #pragma unroll
@@ -400,50 +423,69 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
             }
         }
         __syncthreads();                                             // the source is in LDS (staged, or written by the previous stage)
+        PYR_MARK();
         if (4 * tx < X.ncols) {
-            for (int r = wave; r < Y.n_src; r += NW) {
-                const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_x[r * src_pitch + wbase]);
-                const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-                const uint32_t wlo = __builtin_amdgcn_alignbyte(d1, d0, wshift), whi = __builtin_amdgcn_alignbyte(d2, d1, wshift);
-                *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(whi, wlo, sel[0], sel[1], coef[0], coef[1]), pyr_hpair(whi, wlo, sel[2], sel[3], coef[2], coef[3]));
+            // two source rows per iteration, all six LDS reads issued before the first use: with one or two waves per SIMD (small batches) the LDS
+            // round trip of every row was exposed
+            for (int r = wave; r < Y.n_src; r += 2 * NW) {
+                const bool two = r + NW < Y.n_src;                    // uniform
+                const uint32_t* wa = reinterpret_cast<const uint32_t*>(&s_x[r * src_pitch + wbase]);
+                const uint32_t* wb = reinterpret_cast<const uint32_t*>(&s_x[(two ? r + NW : r) * src_pitch + wbase]);
+                const uint32_t a0 = wa[0], a1 = wa[1], a2 = wa[2], b0 = wb[0], b1 = wb[1], b2 = wb[2];
+                const uint32_t alo = __builtin_amdgcn_alignbyte(a1, a0, wshift), ahi = __builtin_amdgcn_alignbyte(a2, a1, wshift);
+                const uint32_t blo = __builtin_amdgcn_alignbyte(b1, b0, wshift), bhi = __builtin_amdgcn_alignbyte(b2, b1, wshift);
+                *reinterpret_cast<uint2*>(&s_h[r * 256 + 4 * tx]) = make_uint2(pyr_hpair(ahi, alo, sel[0], sel[1], coef[0], coef[1]), pyr_hpair(ahi, alo, sel[2], sel[3], coef[2], coef[3]));
+                if (two) *reinterpret_cast<uint2*>(&s_h[(r + NW) * 256 + 4 * tx]) = make_uint2(pyr_hpair(bhi, blo, sel[0], sel[1], coef[0], coef[1]), pyr_hpair(bhi, blo, sel[2], sel[3], coef[2], coef[3]));
             }
         }
+        ld_t(stn, Xn, traw);                                         // in flight during the vertical pass
         __syncthreads();                                             // the sums are complete, the source is dead: the region overlays it
+        PYR_MARK();
         {
             uint8_t* const dimg = S.base + (size_t)img * S.img_stride;
             const uint32_t col = (uint32_t)(X.x0 + 4 * tx);
             const bool lane_on = 4 * tx < X.ncols, own_col = (int)col < X.own_x1;
             const bool keep = st + 1 < F.nstage;                     // uniform: a later stage reads the region from LDS
             const HsPyrRow* recp = S.rows + ((size_t)blockIdx.y * (uint32_t)S.slot + (uint32_t)wave);      // the tile's padded row table: `pointer += NW`, no clamp
-            HsPyrRow nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
+            HsPyrRow nxt0 = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp)), nxt1 = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp + NW));
             const uint8_t* const h_lane = reinterpret_cast<const uint8_t*>(s_h) + 8 * tx;
             uint8_t* rowp = dimg + (size_t)(Y.y0 + wave) * (uint32_t)S.pitch;
             const uint32_t rstep = (uint32_t)NW * (uint32_t)S.pitch;
             uint32_t* xrow = reinterpret_cast<uint32_t*>(&s_x[wave * FZ_APITCH + 4 * tx]);
-            for (int y = Y.y0 + wave; y <= Y.y_last; y += NW) {
-                const HsPyrRow rec = nxt;
-                recp += NW;
-                nxt = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp));
+            // two destination rows per iteration (their four LDS reads in flight together); the row table is padded with copies of the tile's last row,
+            // so the second row of the last iteration reads valid sums and is simply not stored
+            for (int y = Y.y0 + wave; y <= Y.y_last; y += 2 * NW) {
+                const HsPyrRow rec0 = nxt0, rec1 = nxt1;
+                recp += 2 * NW;
+                nxt0 = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp)); nxt1 = __builtin_bit_cast(HsPyrRow, hs_cload<hs_u32x2>(recp + NW));
+                const bool two = y + NW <= Y.y_last;                  // uniform
                 if (lane_on) {
-                    const uint2 H0 = *reinterpret_cast<const uint2*>(h_lane + rec.off0);
-                    const uint2 H1 = *reinterpret_cast<const uint2*>(h_lane + rec.off1);
-                    const uint32_t px = pyr_vquad(H0, H1, rec.b0, rec.b1);
-                    if (keep) *xrow = px;
-                    if (own_col && y < Y.own_y1) hs_gstore_off<uint32_t>(rowp, col, px);
+                    const uint2 A0 = *reinterpret_cast<const uint2*>(h_lane + rec0.off0), A1 = *reinterpret_cast<const uint2*>(h_lane + rec0.off1);
+                    const uint2 B0 = *reinterpret_cast<const uint2*>(h_lane + rec1.off0), B1 = *reinterpret_cast<const uint2*>(h_lane + rec1.off1);
+                    const uint32_t pa = pyr_vquad(A0, A1, rec0.b0, rec0.b1), pb = pyr_vquad(B0, B1, rec1.b0, rec1.b1);
+                    if (keep) { *xrow = pa; if (two) xrow[NW * (FZ_APITCH / 4)] = pb; }
+                    if (own_col && y < Y.own_y1) hs_gstore_off<uint32_t>(rowp, col, pa);
+                    if (own_col && two && y + NW < Y.own_y1) hs_gstore_off<uint32_t>(rowp + rstep, col, pb);
                 }
-                xrow += NW * (FZ_APITCH / 4); rowp += rstep;
+                xrow += 2 * NW * (FZ_APITCH / 4); rowp += 2 * rstep;
             }
         }
         src_pitch = FZ_APITCH;
+        X = Xn; Y = Yn;
+        PYR_MARK();
     }
+#ifdef HS_PYR_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) g_pyr_prof[63] = pk;
+#endif
 }
 
 // Host side of k_resize_chain for the levels [first, first + n): walks the tiles of the LAST level from the largest tile width downwards until every
 // stage's region fits 256 columns and the LDS buffers, with the expressions of hs_pyramid_build_tables / the two-level kernel.
 void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
-                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max)
+                           std::vector<uint64_t>& blob, HsPyrChain& C, size_t lds_max, int tile_rows)
 {
     C = HsPyrChain{};
+    if (tile_rows <= 0) tile_rows = FZ_ROWS;
     if (n < 2 || n > HS_PYR_CHAIN_MAX || first < 1) return;
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     for (int i = 0; i < n; i++) {
@@ -451,12 +493,12 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
         if ((double)S.w / D.w > 2.0 || (double)S.h / D.h > 2.0 || D.w < 8 || D.h < 1) return;
     }
     const HsLevel& LAST = h_lv[first + n - 1];
-    const int nby = (LAST.h + FZ_ROWS - 1) / FZ_ROWS;
+    const int nby = (LAST.h + tile_rows - 1) / tile_rows;
     // ---- rows (independent of the tile width): part starts, owned ends, regions and source spans — the same three steps as for the columns below
     std::vector<std::vector<HsPyrStageY>> ty(n, std::vector<HsPyrStageY>(nby));
     int h_rows = 0, x_rows0 = 0, x_rows = 0;
     for (int by = 0; by < nby; by++) {
-        int y0 = by * FZ_ROWS;
+        int y0 = by * tile_rows;
         for (int i = n - 1; i >= 0; i--) {
             ty[i][by] = HsPyrStageY{};
             ty[i][by].y0 = y0;
@@ -470,7 +512,7 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
             if (t.own_y1 < t.y0) return;
         }
     for (int by = 0; by < nby; by++) {
-        int need_last = std::min(by * FZ_ROWS + FZ_ROWS, LAST.h) - 1;              // last row of the stage's level that is really read
+        int need_last = std::min(by * tile_rows + tile_rows, LAST.h) - 1;          // last row of the stage's level that is really read
         for (int i = n - 1; i >= 0; i--) {
             const HsLevel& S = h_lv[first + i - 1];
             const int16_t* yo = yofs[first + i];
@@ -559,7 +601,7 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
             // every slot is padded with copies of its last row (the kernel prefetches one step of <= 8 rows past the end)
             int slot = 0;
             for (int by = 0; by < nby; by++) slot = std::max(slot, ty[i][by].y_last - ty[i][by].y0 + 1);
-            slot += 8;
+            slot += 4 * 8;                                                           // (the vertical pass walks 2 NW rows per step and prefetches one step ahead: 4 NW rows past the end at most)
             const size_t orow = blob.size(); blob.resize(orow + (size_t)slot * nby);
             const int sh = h_lv[first + i - 1].h;
             for (int by = 0; by < nby; by++) {

@@ -11,7 +11,7 @@ for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
         n=r["Kernel_Name"].split("(")[0].replace("void ","")
         if n.startswith("k_"): rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:24]))
 rows.sort()
-first=[i for i,r in enumerate(rows) if r[2].startswith("k_resize_two")]
+first=[i for i,r in enumerate(rows) if r[2].startswith("k_resize")]          # a step starts with the first pyramid launch (k_resize_two_levels, or k_resize_chain alone in the small-batch plan)
 starts=[i for i in first if i==0 or not rows[i-1][2].startswith("k_resize")]
 a,b=starts[-3],starts[-2]
 t0=rows[a][0]; prev=None; busy=0
