@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md); issue-rate fractions are quoted against it
 W, H, NFEAT = 1920, 1080, 2000
-PROFILE_TAG = "r03"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
+PROFILE_TAG = "r04"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
 
 
 def parse_args():

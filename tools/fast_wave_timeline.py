@@ -16,9 +16,9 @@ imgs = [L, R] * ((int(sys.argv[1]) if len(sys.argv) > 1 else 32) // 2)
 ex.extract_batch(imgs)
 ex.extract_batch(imgs)
 lib = ex._lib
-out = (C.c_ulonglong * (4096 * 8))()
+out = (C.c_ulonglong * (4096 * 16))()       # 16 slots per workgroup since round 4 (the first item's phase stamps follow the six summary slots)
 lib.hs_debug_fast_waves(out)
-raw = np.array(list(out), dtype=np.uint64).reshape(4096, 8)
+raw = np.array(list(out), dtype=np.uint64).reshape(4096, 16)[:, :8]
 v = raw[:, :5].astype(np.float64)
 long_w = raw[:, 5]
 blk = np.arange(4096)

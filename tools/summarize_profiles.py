@@ -76,6 +76,8 @@ for r in csv.DictReader(open(first("sq/**/*counter_collection.csv"))):
     if k.startswith("k_"):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for d in agg.values() for c in d})
+# launch sequences of the counter run = launches of the FAST kernel (one per sequence); bench.py runs two warm-ups since round 4, so the count is read, not assumed
+n_seq = max([len(next(iter(d.values()))) for k, d in agg.items() if k.startswith("k_fast_rows")] or [5 * HANDLES])
 sq = {}
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
@@ -84,13 +86,12 @@ with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     for k, d in agg.items():
         n = len(next(iter(d.values())))
         o.write(k.replace(",", ";") + "," + str(n) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names) + "\n")
-        # 5 steps (1 warm-up + 4) x HANDLES launch sequences
-        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / (5.0 * HANDLES),
+        sq[k.split("<")[0]] = dict({c: round(sum(d[c]) / len(d[c])) for c in names}, frames_per_launch=2 * PAIRS // HANDLES, launches=n, launches_per_sequence=n / float(n_seq),
                                   source_sha16=stamp(k))
 json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
-for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs4", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof",
+for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs2", "bench_pairs4", "bench_pairs8", "bench_pairs32", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof",
              "bench_density3", "adaptor"):
     p = os.path.join(src, name + ".json")
     try:
@@ -141,6 +142,15 @@ for name in ("qt_phase_1080p", "qt_phase_4000x3000"):
             "# tools/quadtree_phase_profile.py: shader-clock stamps of the level-0 quadtree workgroup of image 0 (HS_QT_PROFILE build); tags: 20 set-up, 22 item scan, 23/25 record run\n"
             "# (search / fetch+key+histogram), 1 gather done, 30 pyramid, 31 closed form, 5 list built, 110 order, 11 child counts, 12 cut+children, 13 survivors, 14 relabel (point domain),\n"
             "# 3 geometric keys -> nodes, 40 best point per node, 41 emitted, 4 tile order\n" + body)
+    except OSError:
+        pass
+for name, head in (("fast_b1_timeline", "# tools/fast_b1_timeline.py 2 (HS_FAST_WAVES build): one stereo pair per call — phases of every persistent workgroup's first work item, by pyramid level\n"),
+                   ("fast_wave_timeline", "# tools/fast_wave_timeline.py 32 (HS_FAST_WAVES build): 32 frames per launch\n"),
+                   ("pyr_phase_b1", "# tools/pyramid_phase_profile.py 2 (HS_PYR_PROFILE build): the middle workgroup of the single k_resize_chain launch of a single-pair call (levels 1-7)\n"),
+                   ("pyr_phase_b16", "# tools/pyramid_phase_profile.py 32 (HS_PYR_PROFILE build): the middle workgroup of the three-level k_resize_chain launch (levels 5-7) at 16 pairs per call\n")):
+    try:
+        body = open(os.path.join(src, name + ".txt")).read()
+        open("profiles/%s_%s.txt" % (rnd, name), "w").write(head + body)
     except OSError:
         pass
 b = summary["bench"]
