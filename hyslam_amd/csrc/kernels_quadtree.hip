@@ -404,23 +404,41 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         //          nodes_d = nz_d - one_{d-1},   single-point nodes_d = one_d - one_{d-1}
         //      (a parent with one point has exactly one occupied child, with one point)
         auto stat = [](uint32_t c) { return (c > 0 ? 1u : 0u) + (c == 1 ? 0x10000u : 0u); };
-        for (int d = DH - 1; d >= 0; d--) {
-            const int nbp = nIni << (2 * d), od = hoff(d), oc = hoff(d + 1);
-            const int per = nbp > QT_T ? 2 : 1;                                               // nbp <= 2048
-            uint32_t acc = 0;
-            if (tid * per < nbp) {
-                for (int j = 0; j < per; j++) {
-                    const int b = tid * per + j;
-                    const uint2 q = *reinterpret_cast<const uint2*>(&hist[oc + 4 * b]);      // four u16 children, 8-byte aligned
-                    const uint32_t c0 = q.x & 0xFFFF, c1 = q.x >> 16, c2 = q.y & 0xFFFF, c3 = q.y >> 16;
-                    hist[od + b] = (uint16_t)(c0 + c1 + c2 + c3);
-                    acc += stat(c0) + stat(c1) + stat(c2) + stat(c3);
+        // Two depths per block-wide step (round 4: every step costs a barrier + two wave sums whatever its work, and there were DH of them): a thread takes
+        // eight consecutive cells of depth d + 1 — two parents at depth d, half a grandparent at depth d - 1 —, writes both parents' sums with one store and
+        // completes the grandparent with its neighbour lane's half.  Statistics of the child and of the parent depth; the grandparents' follow in the next step.
+        int d = DH - 1;
+        for (; d >= 1; d -= 2) {
+            const int nhalf = nIni << (2 * d - 1), oc = hoff(d + 1), od = hoff(d), og = hoff(d - 1);      // half grandparents = pairs of parents (<= 1024)
+            uint32_t accC = 0, accP = 0;
+            if ((tid & ~63) < nhalf) {                                                        // waves with work (uniform per wave)
+                const bool on = tid < nhalf;
+                uint32_t half = 0;
+                if (on) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(&hist[oc + 8 * tid]);     // eight u16 children, 16-byte aligned
+                    const uint32_t c0 = q.x & 0xFFFF, c1 = q.x >> 16, c2 = q.y & 0xFFFF, c3 = q.y >> 16, c4 = q.z & 0xFFFF, c5 = q.z >> 16, c6 = q.w & 0xFFFF, c7 = q.w >> 16;
+                    const uint32_t p0 = c0 + c1 + c2 + c3, p1 = c4 + c5 + c6 + c7;
+                    *reinterpret_cast<uint32_t*>(&hist[od + 2 * tid]) = p0 | (p1 << 16);
+                    accC = stat(c0) + stat(c1) + stat(c2) + stat(c3) + stat(c4) + stat(c5) + stat(c6) + stat(c7);
+                    accP = stat(p0) + stat(p1);
+                    half = p0 + p1;
                 }
+                const uint32_t other = (uint32_t)__shfl_xor((int)half, 1, 64);                // (nhalf is even: a lane's partner is on exactly when the lane is)
+                if (on && !(tid & 1)) hist[og + (tid >> 1)] = (uint16_t)(half + other);
+                const uint32_t totC = (uint32_t)wave_sum((int)accC), totP = (uint32_t)wave_sum((int)accP);
+                if ((tid & 63) == 0) { if (totC) atomicAdd(&s_dcnt[d + 1], totC); if (totP) atomicAdd(&s_dcnt[d], totP); }
             }
-            if ((tid & ~63) * per < nbp) {                                                    // waves with work (uniform per wave)
-                const uint32_t tot = (uint32_t)wave_sum((int)acc);
-                if ((tid & 63) == 0 && tot) atomicAdd(&s_dcnt[d + 1], tot);
+            __syncthreads();
+        }
+        if (d == 0) {                                                                         // an odd number of depths: the roots from depth 1
+            uint32_t acc = 0;
+            if (tid < nIni) {
+                const uint2 q = *reinterpret_cast<const uint2*>(&hist[hoff(1) + 4 * tid]);
+                const uint32_t c0 = q.x & 0xFFFF, c1 = q.x >> 16, c2 = q.y & 0xFFFF, c3 = q.y >> 16;
+                hist[hoff(0) + tid] = (uint16_t)(c0 + c1 + c2 + c3);
+                acc = stat(c0) + stat(c1) + stat(c2) + stat(c3);
             }
+            if (tid < 64) { const uint32_t tot = (uint32_t)wave_sum((int)acc); if (tid == 0 && tot) atomicAdd(&s_dcnt[1], tot); }
             __syncthreads();
         }
         if (tid < 64) {
