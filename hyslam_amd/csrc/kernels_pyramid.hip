@@ -357,7 +357,9 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
 // the last THREE levels of a pyramid with an odd number of levels to make (levels 5, 6, 7 of 8: one launch instead of two).
 #ifdef HS_PYR_PROFILE      // make EXTRA=-DHS_PYR_PROFILE: clock stamps of workgroup (0, 0, 0) of every k_resize_chain launch (tools/pyramid_phase_profile.py)
 __device__ unsigned long long g_pyr_prof[64];
+__device__ unsigned long long g_pyr_wg[4096 * 2];            // real-time (100 MHz) start / end stamp of every workgroup of the last k_resize_chain launch
 extern "C" void hs_debug_pyr_profile(unsigned long long* out64) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_pyr_prof), sizeof(unsigned long long) * 64); }
+extern "C" void hs_debug_pyr_workgroups(unsigned long long* out8192) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_pyr_wg), sizeof(unsigned long long) * 8192); }
 #define PYR_MARK() do { if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0 && pk < 62) g_pyr_prof[pk++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PYR_MARK()
@@ -367,6 +369,8 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
 {
 #ifdef HS_PYR_PROFILE
     int pk = 0;
+    const unsigned pyr_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && pyr_wg < 4096) g_pyr_wg[2 * pyr_wg] = __builtin_amdgcn_s_memrealtime();
 #endif
     PYR_MARK();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -476,6 +480,8 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
     }
 #ifdef HS_PYR_PROFILE
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) g_pyr_prof[63] = pk;
+    __syncthreads();
+    if (threadIdx.x == 0 && pyr_wg < 4096) g_pyr_wg[2 * pyr_wg + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

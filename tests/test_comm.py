@@ -93,3 +93,45 @@ def test_comm_world1_extract_gather_match_on_one_stream(gpu):
     ok, od = oracle.extract(oracle.default_params(NF), img)
     assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
     xc.close()
+
+
+def test_comm_probe_and_borrowers_symbols():
+    """hs_comm_available is a non-collective probe (an answer, not a hang or a crash, with or without librccl / a GPU); a null handle borrows nothing"""
+    from hyslam_amd import _native as N
+    from hyslam_amd import distributed as D
+    lib = N.lib()
+    ok, why = D.comm_available()
+    assert isinstance(ok, bool) and (ok or why)
+    assert lib.hs_orb_borrowers(None) == 0
+
+
+@pytest.mark.gpu
+def test_handle_destroyed_before_its_communicator_is_deferred(gpu):
+    """a communicator borrows its handle: hs_orb_destroy on a borrowed handle only marks it, the last hs_comm_destroy frees it — the order the header
+    used to forbid (use-after-free in the first multi-rank teardown that got it wrong) is safe now, and the communicator still works in between"""
+    import ctypes as C
+    import hipmem
+    from hyslam_amd import _native as N
+    from hyslam_amd import distributed as D
+    lib = N.lib()
+    h = C.c_void_p()
+    params = N.OrbParams()
+    lib.hs_orb_default_params(C.byref(params))
+    assert lib.hs_orb_create(C.byref(params), 0, C.byref(h)) == N.HS_OK
+    assert lib.hs_orb_borrowers(h) == 0
+    ident = (C.c_uint8 * 128)()
+    assert lib.hs_comm_get_unique_id(ident) == N.HS_OK
+    c1, c2 = C.c_void_p(), C.c_void_p()
+    assert lib.hs_comm_create(h, ident, 1, 0, C.byref(c1)) == N.HS_OK and lib.hs_orb_borrowers(h) == 1
+    assert lib.hs_comm_get_unique_id(ident) == N.HS_OK
+    assert lib.hs_comm_create(h, ident, 1, 0, C.byref(c2)) == N.HS_OK and lib.hs_orb_borrowers(h) == 2
+    lib.hs_orb_destroy(h)                                     # deferred: two communicators still use the handle's device and stream
+    assert lib.hs_orb_borrowers(h) == 2
+    rb = 4096
+    src, dst = hipmem.DevBuf.from_numpy(np.arange(rb, dtype=np.uint8)), hipmem.DevBuf(rb)
+    assert lib.hs_comm_allgather_records(c1, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), rb, None) == N.HS_OK
+    hipmem.sync()
+    assert np.array_equal(dst.to_numpy(np.uint8, rb), np.arange(rb, dtype=np.uint8))
+    lib.hs_comm_destroy(c1)
+    assert lib.hs_orb_borrowers(h) == 1
+    lib.hs_comm_destroy(c2)                                   # the last borrower: the handle is freed here (nothing to assert on a freed handle)

@@ -20,3 +20,15 @@ print("stamps %d; total %d cycles" % (k, out[k - 1] - t0))
 for i in range(1, k):
     st, ph = (i - 1) // 3, (i - 1) % 3
     print("stage %d %-16s +%6d  (total %7d)" % (st, names[ph], out[i] - out[i - 1], out[i] - t0))
+
+import numpy as np
+wg = (C.c_ulonglong * 8192)()
+ex._lib.hs_debug_pyr_workgroups(wg)
+a = np.array(list(wg), dtype=np.float64).reshape(4096, 2)
+a = a[a[:, 1] > 0]
+t0 = a[:, 0].min()
+st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
+print("workgroups %d: start median %.2f us, 90 %% %.2f, max %.2f; life median %.2f us, 90 %% %.2f, max %.2f; end median %.2f us, 90 %% %.2f, max %.2f (= the launch's span from the first workgroup's start)"
+      % (len(a), np.median(st), np.percentile(st, 90), st.max(), np.median(en - st), np.percentile(en - st, 90), (en - st).max(), np.median(en), np.percentile(en, 90), en.max()))
+late = np.argsort(-en)[:8]
+print("latest finishers (index, start, life):", [(int(i), round(float(st[i]), 1), round(float(en[i] - st[i]), 1)) for i in late])
