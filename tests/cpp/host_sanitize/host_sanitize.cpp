@@ -12,8 +12,11 @@
 #include <random>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include <unistd.h>
 #include "../../../include/hyslam_amd.h"
+void hs_orb_borrow(hs_orb* h, int delta);      // hs_api.hip (internal: what hs_comm_create / hs_comm_destroy call)
 
 extern "C" long hip_stub_launches();
 void hs_debug_plan_summary(const hs_orb* h, int32_t* out /*[8]*/);        // hs_api.hip: launches of the pyramid's two plans, item counts (host-side facts of the last configuration)
@@ -127,6 +130,22 @@ int main(int argc, char** argv)
         CHECK(r >= 0); accepted += r; tried++;
     }
     CHECK(accepted > tried / 2);
+
+    // ---- a handle outliving its communicators: hs_orb_destroy and the last borrower's release race on two threads; exactly one of them frees
+    // the handle (ASan: a double free or a leak fails the run), in either order and with several borrowers
+    for (int i = 0; i < 200; i++) {
+        hs_orb_params p; hs_orb_default_params(&p);
+        hs_orb* ex = nullptr;
+        CHECK(hs_orb_create(&p, 0, &ex) == HS_OK);
+        const int nb = 1 + i % 3;
+        for (int b = 0; b < nb; b++) hs_orb_borrow(ex, +1);
+        CHECK(hs_orb_borrowers(ex) == nb);
+        std::atomic<int> go{0};
+        std::thread td([&] { while (!go.load()) {} hs_orb_destroy(ex); });
+        std::thread tb([&] { while (!go.load()) {} for (int b = 0; b < nb; b++) hs_orb_borrow(ex, -1); });
+        go.store(1);
+        td.join(); tb.join();
+    }
 
     // ---- vocabulary files: valid round trips, then truncations and random corruptions of both formats
     char dir[] = "/tmp/hs_host_sanitize_XXXXXX";
