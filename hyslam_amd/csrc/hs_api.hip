@@ -341,6 +341,20 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
                     if (!h->pyr_chain[l].valid && n == 3) hs_pyramid_plan_chain(h->lv.data(), l, 2, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l]);
                     if (h->pyr_chain[l].valid) { h->lv[l].chain_n = h->pyr_chain[l].nstage; if (h->pyr_chain[l].nstage == 3) l++; }
                 }
+            } else if (const char* plan = getenv("HS_PYRAMID_PLAN")) {      // tuning knob: explicit chain lengths from level 1, e.g. "2,3,2" (1 = a single level, 2 = the two-level kernel unless HS_PYRAMID_CHAIN2=1)
+                const bool chain2 = getenv("HS_PYRAMID_CHAIN2") && atoi(getenv("HS_PYRAMID_CHAIN2")) != 0;
+                int l = 1;
+                for (const char* q = plan; *q && l < L; ) {
+                    const int n = std::min(atoi(q), L - l);
+                    if (n >= 3 || (n == 2 && (chain2 || !(l & 1)))) {       // (the two-level kernel is planned for pairs that start on an odd level)
+                        hs_pyramid_plan_chain(h->lv.data(), l, n, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l], HS_PYR_DEEP_LDS, 0);
+                        if (h->pyr_chain[l].valid) h->lv[l].chain_n = n;
+                    }
+                    if (n == 1) h->lv[l].fuse_tbx = 0;
+                    l += std::max(n, 1);
+                    while (*q && *q != ',') q++;
+                    if (*q == ',') q++;
+                }
             } else if (L >= 4 && ((L - 1) & 1)) {
                 const int l = L - 3;
                 hs_pyramid_plan_chain(h->lv.data(), l, 3, xt.data(), yo.data(), ib.data(), blob, h->pyr_chain[l]);

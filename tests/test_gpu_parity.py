@@ -218,6 +218,8 @@ def test_blur_saturation_white_blocks(gpu):
 @pytest.mark.parametrize("env", [{}, {"HS_QT_POINT_DOMAIN": "1"}, {"HS_EXTRACT_SPLIT": "1"}, {"HS_EXTRACT_SPLIT": "0"}, {"HS_PYRAMID_NO_FUSE": "1"}, {"HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_TEST_SCAN_B": "1"}, {"HS_FAST_COLS": "32"},
                                  {"HS_FAST_COLS": "32", "HS_FAST_TEST_SMALL_LISTS": "1"}, {"HS_FAST_COLS": "32", "HS_FAST_TEST_SCAN_B": "1"},
                                  {"HS_PYRAMID_CHAIN": "2"}, {"HS_PYRAMID_CHAIN": "0"}, {"HS_PYRAMID_DEEP_MAX": "0"}, {"HS_PYRAMID_DEEP_MAX": "100000"}, {"HS_PYRAMID_DEEP_MAX": "100000", "HS_PYRAMID_NW8": "0"}, {"HS_PYRAMID_NW8": "100000"}, {"HS_PYRAMID_NW8": "0"},
+                                 # explicit launch plans (chain lengths from level 1): four- and five-level chains, a chain that starts on an even level, single levels
+                                 {"HS_PYRAMID_PLAN": "3,4", "HS_PYRAMID_DEEP_MAX": "0"}, {"HS_PYRAMID_PLAN": "2,5", "HS_PYRAMID_DEEP_MAX": "0"}, {"HS_PYRAMID_PLAN": "1,2,3,1", "HS_PYRAMID_DEEP_MAX": "0"},
                                  {"HS_FAST_ORDER": "0"}, {"HS_FAST_ORDER": "2"}, {"HS_FAST_IMAGE_MAJOR": "1"},
                                  # the work queues (what every launch used until round 3; now the launches of > 2 units per workgroup) on wide and on narrow items
                                  {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64"}, {"HS_FAST_NO_FOLD": "1", "HS_FAST_COLS": "64", "HS_FAST_NQ": "8"},
