@@ -120,6 +120,30 @@ __device__ __forceinline__ uint32_t pyr_vquad(uint2 H0, uint2 H1, uint32_t b0, u
     return __builtin_amdgcn_perm(c2, a2, 0x06040200u);                                                  // bytes 0 and 2 of both
 }
 
+// Source rectangle -> LDS with 16-byte vectors: a wave takes whole source rows, floor(64 / nvec) at a time (no per-lane division by the runtime nvec).
+// FOUR rows per lane are in flight before the first LDS write (round 4): written as `load; store` per row the loop waited for every load on the spot —
+// three dependent HBM round trips at the head of every workgroup (7 k of the 22 k cycles a workgroup of the levels 5-7 launch lives).  Rows past the
+// end are clamped to the last row: a duplicate load and an identical write instead of a branch.
+template <int NW>
+__device__ __forceinline__ void pyr_stage_source(const uint8_t* src0 /*wave-uniform*/, uint32_t spitch, uint8_t* s_dst, uint32_t dpitch, int nvec, int nrows, int tx, int wave)
+{
+    const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));          // rows per wave step
+    const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
+    if (tx >= rpw * nvec) return;
+    const int step = NW * rpw, last = nrows - 1;
+    for (int r = wave * rpw + rl; r < nrows; r += 4 * step) {
+        const int r1 = min(r + step, last), r2 = min(r + 2 * step, last), r3 = min(r + 3 * step, last);
+        const hs_u32x4 v0 = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
+        const hs_u32x4 v1 = hs_gload_off<hs_u32x4>(src0, (uint32_t)r1 * spitch + 16u * (uint32_t)q);
+        const hs_u32x4 v2 = hs_gload_off<hs_u32x4>(src0, (uint32_t)r2 * spitch + 16u * (uint32_t)q);
+        const hs_u32x4 v3 = hs_gload_off<hs_u32x4>(src0, (uint32_t)r3 * spitch + 16u * (uint32_t)q);
+        *reinterpret_cast<hs_u32x4*>(&s_dst[(uint32_t)r * dpitch + 16 * q]) = v0;
+        *reinterpret_cast<hs_u32x4*>(&s_dst[(uint32_t)r1 * dpitch + 16 * q]) = v1;
+        *reinterpret_cast<hs_u32x4*>(&s_dst[(uint32_t)r2 * dpitch + 16 * q]) = v2;
+        *reinterpret_cast<hs_u32x4*>(&s_dst[(uint32_t)r3 * dpitch + 16 * q]) = v3;
+    }
+}
+
 // LDS-staged variant (the fast path): a workgroup produces a 256 x LT_ROWS destination tile in three steps.
 //   A  the source rectangle it needs is fetched once with 16-byte coalesced loads into LDS (each source row is read from HBM/L2 once
 //      per tile instead of once per destination row)
@@ -155,17 +179,7 @@ __global__ __launch_bounds__(256) void k_resize_level_lds(const HsLevel* __restr
     const int col_last = min((int)(int16_t)hs_cload<uint32_t>(&xt[dx_last]) + 1, sw - 1);
     const int nvec = ((col_last - col0) >> 4) + 1, nrow = sy_last - sy_first + 1;      // host guarantees nvec*16 <= lds_pitch - 16, nrow <= lds_rows
     // ---- A: a wave takes whole source rows, floor(64 / nvec) at a time (no per-lane division by the runtime nvec)
-    {
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));          // rows per wave step
-        const int rl = (lane >= nvec) + (lane >= 2 * nvec) + (lane >= 3 * nvec), q = lane - rl * nvec;
-        if (lane < rpw * nvec) {
-            for (int r = wave * rpw + rl; r < nrow; r += 4 * rpw) {
-                const hs_u32x4 v = hs_gload<hs_u32x4>(sbase + (size_t)(sy_first + r) * spitch + col0 + 16 * q);
-                *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
-            }
-        }
-    }
+    pyr_stage_source<4>(hs_uniform_ptr(sbase + (size_t)sy_first * spitch + col0), (uint32_t)spitch, s_src, (uint32_t)lds_pitch, nvec, nrow, threadIdx.x & 63, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     // per-lane column data (independent of the row): 8-byte window position, byte-pair selectors, coefficient pairs
     const int dx0 = dx_tile + 4 * tx;
     HsXTab t[4];
@@ -254,17 +268,7 @@ __global__ __launch_bounds__(64 * NW) void k_resize_two_levels(HsPyrFuse F, HsIm
     const int ax0 = X.ax0, ay0 = Y.ay0, nAr = Y.ay_last - Y.ay0 + 1, nSr = Y.n_sr, nvec = X.nvec;
 
     // ---- 1: the source rectangle (a wave takes whole source rows, floor(64 / nvec) at a time)
-    {
-        const uint8_t* const src0 = hs_uniform_ptr(sbase + (size_t)Y.sy_first * spitch + X.col0);
-        const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
-        const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
-        if (tx < rpw * nvec) {
-            for (int r = wave * rpw + rl; r < nSr; r += NW * rpw) {
-                const hs_u32x4 v = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
-                *reinterpret_cast<hs_u32x4*>(&s_src[r * lds_pitch + 16 * q]) = v;
-            }
-        }
-    }
+    pyr_stage_source<NW>(hs_uniform_ptr(sbase + (size_t)Y.sy_first * spitch + X.col0), spitch, s_src, (uint32_t)lds_pitch, nvec, nSr, tx, wave);
     // per-lane column data of one horizontal pass: window position, byte-pair selectors, coefficient pairs
     struct ColData { int wbase, wshift; uint32_t sel[4], coef[4]; };
     auto col_data = [&](const HsXTab* xt, int dx0, int wmax, int origin) {
@@ -399,18 +403,7 @@ __global__ __launch_bounds__(64 * NW) void k_resize_chain(HsPyrChain F, HsImg0 i
         const HsPyrStage& S = F.st[st];
         const int stn = min(st + 1, F.nstage - 1);                   // (the last stage re-requests its own records: harmless, keeps the loads unconditional)
         const HsPyrStageX Xn = ld_x(stn); const HsPyrStageY Yn = ld_y(stn);
-        if (st == 0) {                                               // the source rectangle: a wave takes whole rows, floor(64 / nvec) at a time
-            const uint8_t* const src0 = hs_uniform_ptr(sbase + (size_t)Y.src_y0 * spitch + X.src_x0);
-            const int nvec = X.nvec;
-            const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));
-            const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
-            if (tx < rpw * nvec) {
-                for (int r = wave * rpw + rl; r < Y.n_src; r += NW * rpw) {
-                    const hs_u32x4 v = hs_gload_off<hs_u32x4>(src0, (uint32_t)r * spitch + 16u * (uint32_t)q);
-                    *reinterpret_cast<hs_u32x4*>(&s_x[r * src_pitch + 16 * q]) = v;
-                }
-            }
-        }
+        if (st == 0) pyr_stage_source<NW>(hs_uniform_ptr(sbase + (size_t)Y.src_y0 * spitch + X.src_x0), spitch, s_x, (uint32_t)src_pitch, X.nvec, Y.n_src, tx, wave);
         // per-lane column data of the stage's horizontal pass: window position, byte-pair selectors, coefficient pairs
         int wbase, wshift; uint32_t sel[4], coef[4];
         {
@@ -542,6 +535,7 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
         }
     }
     // ---- columns: the largest tile width whose regions fit
+    std::vector<std::vector<HsPyrStageX>> best_txs; int best_tbx = 0, best_pitch = 0; size_t best_xbytes = 0;
     for (int tbx = 256; tbx >= 64; tbx -= 4) {
         const int nbx = (LAST.w + tbx - 1) / tbx;
         std::vector<std::vector<HsPyrStageX>> txs(n, std::vector<HsPyrStageX>(nbx));
@@ -595,6 +589,14 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
         const size_t x_bytes = std::max((size_t)pitch * x_rows0, (size_t)FZ_APITCH * x_rows);
         const size_t lds = ((x_bytes + 15) & ~(size_t)15) + (size_t)h_rows * 256 * 2;
         if (lds > lds_max || h_rows > 127 || x_rows > 127) continue;               // (row records address the sums buffer with 16-bit byte offsets: 512 B per row)
+        best_tbx = tbx; best_pitch = pitch; best_xbytes = x_bytes; best_txs = txs;
+        break;
+    }
+    if (best_tbx == 0) return;
+    {
+        const int tbx = best_tbx, pitch = best_pitch, nbx = (LAST.w + tbx - 1) / tbx;
+        const size_t x_bytes = best_xbytes;
+        const std::vector<std::vector<HsPyrStageX>>& txs = best_txs;
         // ---- commit
         if (blob.empty()) blob.push_back(0);
         C.sbase = first == 1 ? nullptr : h_lv[first - 1].base; C.s_img_stride = h_lv[first - 1].img_stride; C.spitch = h_lv[first - 1].pitch; C.nstage = n;
@@ -629,7 +631,6 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
             S.tx = reinterpret_cast<const HsPyrStageX*>(ox * 8); S.ty = reinterpret_cast<const HsPyrStageY*>(oy * 8);
         }
         C.tbx = tbx; C.lds_pitch = pitch; C.x_bytes = (int32_t)((x_bytes + 15) & ~(size_t)15); C.h_rows = h_rows; C.grid_x = nbx; C.grid_y = nby; C.valid = 1;
-        return;
     }
 }
 
