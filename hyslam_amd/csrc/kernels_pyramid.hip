@@ -130,6 +130,9 @@ __device__ __forceinline__ void pyr_stage_source(const uint8_t* src0 /*wave-unif
     const int rpw = nvec <= 16 ? 4 : (nvec <= 21 ? 3 : (nvec <= 32 ? 2 : 1));          // rows per wave step
     const int rl = (tx >= nvec) + (tx >= 2 * nvec) + (tx >= 3 * nvec), q = tx - rl * nvec;
     if (tx >= rpw * nvec) return;
+#ifdef HS_PYR_NOLOAD          // diagnostic build (results are garbage): how much of a launch is the wait for its source rows?
+    return;
+#endif
     const int step = NW * rpw, last = nrows - 1;
     for (int r = wave * rpw + rl; r < nrows; r += 4 * step) {
         const int r1 = min(r + step, last), r2 = min(r + 2 * step, last), r3 = min(r + 3 * step, last);
