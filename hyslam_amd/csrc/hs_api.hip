@@ -18,6 +18,7 @@ struct hs_orb {
     int device = 0;
     // communicators created on this handle (hs_comm_create) BORROW it — its device and its stream: while one is alive hs_orb_destroy only drops
     // the owner's reference and the last hs_comm_destroy frees the handle, so the two destroy calls are safe in either order and on two threads
+    std::atomic<bool> owned{true};            // hs_orb_destroy has not been called yet (hs_orb_borrowers = refs minus the owner's reference)
     std::atomic<int> refs{1};                 // the owner's reference (dropped by hs_orb_destroy) + one per communicator created on the handle; whoever drops the last one frees it
     hipStream_t stream = nullptr;
     std::string err;
@@ -751,9 +752,10 @@ static void orb_destroy_now(hs_orb* h);
 void hs_orb_destroy(hs_orb* h)
 {
     if (!h) return;
+    h->owned.store(false);
     if (h->refs.fetch_sub(1) == 1) orb_destroy_now(h);                   // else a communicator still uses the handle: the last hs_comm_destroy frees it
 }
-int hs_orb_borrowers(const hs_orb* h) { return h ? std::max(0, h->refs.load() - 1) : 0; }
+int hs_orb_borrowers(const hs_orb* h) { return h ? std::max(0, h->refs.load() - (h->owned.load() ? 1 : 0)) : 0; }
 } // extern "C"
 // hs_comm.hip: +1 when a communicator is created on the handle, -1 when it is destroyed (which also completes a deferred hs_orb_destroy)
 void hs_orb_borrow(hs_orb* h, int delta)
