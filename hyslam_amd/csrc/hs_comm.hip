@@ -40,7 +40,10 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.so) break; }
+        // RTLD_LOCAL: a process may hold ANOTHER copy of RCCL (PyTorch ships its own and loads it by path; a copy that is already resident under the
+        // same soname is simply reused).  With RTLD_GLOBAL this copy's symbols interposed on a PyTorch imported later and the process died in the static
+        // destructors at exit ("double free or corruption")
+        for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.so) break; }
         if (!r.so) { const char* e = dlerror(); r.why = std::string("librccl not found: ") + (e ? e : ""); return; }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));

@@ -105,6 +105,21 @@ def test_comm_probe_and_borrowers_symbols():
     assert lib.hs_orb_borrowers(None) == 0
 
 
+def test_probe_before_torch_does_not_kill_the_process_at_exit():
+    """librccl is loaded RTLD_LOCAL: a process that asks the C library for RCCL BEFORE it imports PyTorch ends up with two copies of RCCL (PyTorch ships
+    its own); with RTLD_GLOBAL the first copy interposed on the second and the interpreter died in the static destructors at exit ('double free or
+    corruption', exit code 134 — which is how a green test run turned into a failed one)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from hyslam_amd import _native as N\n"
+            "rc = N.lib().hs_comm_available()\n"
+            "import torch\n"
+            "print('probe', rc, 'torch', torch.__version__)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "probe" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_handle_destroyed_before_its_communicator_is_deferred(gpu):
     """a communicator borrows its handle: hs_orb_destroy on a borrowed handle only marks it, the last hs_comm_destroy frees it — the order the header
