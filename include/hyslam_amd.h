@@ -386,9 +386,11 @@ int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_s
  * librccl is loaded on first use (dlopen): HS_ERR_NO_DEVICE when it or a GPU is missing.  Asynchronous.
  * hs_comm_available(): non-collective probe (HS_OK / HS_ERR_NO_DEVICE, reason in hs_comm_unavailable_reason()) — ask it on every rank before
  * the first hs_comm_create, which blocks until all ranks arrive, and fall back together when any rank cannot.
- * Lifetime: a communicator BORROWS its handle (device, stream).  hs_orb_destroy on a handle that still has communicators is deferred: the
- * handle is only marked and the last hs_comm_destroy frees it, so the two destroy calls are safe in either order; the handle must not be
- * used for anything else after its hs_orb_destroy.  hs_orb_borrowers() = communicators alive on the handle. */
+ * Lifetime: a communicator BORROWS its handle (device, stream).  The handle is reference-counted (the owner + one per communicator):
+ * hs_orb_destroy on a handle that still has communicators only drops the owner's reference and the last hs_comm_destroy frees it, so the two
+ * destroy calls are safe in either order and from two threads; the handle must not be used for anything else after its hs_orb_destroy.
+ * hs_orb_borrowers() = communicators alive on the handle.  librccl is loaded RTLD_LOCAL: a host process that carries its own copy of RCCL
+ * (PyTorch does) keeps using that one; a copy already resident under the soname librccl.so.1 is reused. */
 #define HS_COMM_ID_BYTES 128
 typedef struct hs_comm hs_comm;
 int  hs_comm_available(void);

@@ -122,7 +122,7 @@ def test_probe_before_torch_does_not_kill_the_process_at_exit():
 
 @pytest.mark.gpu
 def test_handle_destroyed_before_its_communicator_is_deferred(gpu):
-    """a communicator borrows its handle: hs_orb_destroy on a borrowed handle only marks it, the last hs_comm_destroy frees it — the order the header
+    """a communicator borrows its handle: hs_orb_destroy on a borrowed handle only drops the owner's reference, the last hs_comm_destroy frees it — the order the header
     used to forbid (use-after-free in the first multi-rank teardown that got it wrong) is safe now, and the communicator still works in between"""
     import ctypes as C
     import hipmem
