@@ -306,7 +306,7 @@ def timed(step, args, fence, torch, dist, world, dev, begin=None, end=None, paus
     # the K steps cover >= --min-timed-ms of GPU time.  `steps` stays the caller's unit; every rank uses the same factor.
     inner = 1
     if args.min_timed_ms > 0 and t_pass > 0:
-        inner = max(1, int(np.ceil(args.min_timed_ms * 1e-3 / (args.steps * t_pass))))
+        inner = max(1, int(np.ceil(1.15 * args.min_timed_ms * 1e-3 / (args.steps * t_pass))))      # 15 % margin: the few warm-up passes carry the final synchronisation, so t_pass overestimates a pass
     if world > 1:
         t = torch.tensor([inner], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
