@@ -1,14 +1,14 @@
 #!/bin/bash
 # diagnostic: pyramid launches without their source fetch (garbage results) vs the real ones
 set -e
-mkdir -p gpurun_out/r4v && cd /tmp && export TMPDIR=/tmp
+mkdir -p gpurun_out/pyr_noload && cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for v in real noload; do
   if [ $v = noload ]; then export HYSLAM_AMD_LIB=$R/hyslam_amd/libhyslam_amd_pnoload.so; fi
-  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r4v/$v -o t -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-seconds 0 --call-site 0 --pcie-seconds 0 --min-timed-ms 0 --profile-steps 0 > $R/gpurun_out/r4v/$v.out 2>&1 || true
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/pyr_noload/$v -o t -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-seconds 0 --call-site 0 --pcie-seconds 0 --min-timed-ms 0 --profile-steps 0 > $R/gpurun_out/pyr_noload/$v.out 2>&1 || true
   python3 - <<PY
 import csv,glob,collections
-f=glob.glob("$R/gpurun_out/r4v/$v/**/*kernel_trace.csv",recursive=True)[0]
+f=glob.glob("$R/gpurun_out/pyr_noload/$v/**/*kernel_trace.csv",recursive=True)[0]
 d=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n=r["Kernel_Name"]
