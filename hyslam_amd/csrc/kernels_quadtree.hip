@@ -617,46 +617,59 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             // that go first.  All 1024 threads: candidate i = t % W is compared against the G-th part of the list by thread t, the partial
             // ranks meet in LDS (the child-index array is free here).
             uint32_t* const rank_acc = reinterpret_cast<uint32_t*>(child_index);      // [T_prev]
-            uint32_t* const okey = ccount;                                             // [T_prev + 3] count << 16 | ~index: j goes before i <=> okey[j] > okey[i]
+            // Sort key: count << 16 | ~index — j goes before i <=> key[j] > key[i].  32-bit keys (four per LDS read) while no node can hold more than
+            // 65 535 points (n <= 65 535: always in the count domain); a level with more candidates than that (saturated frames: a 4 Mpx checkerboard has
+            // 260 000 on one level) ranks with 64-bit keys — the counts used to be CLAMPED to 16 bits there, so two nodes above 65 535 points tied and
+            // went by list index instead of by size (found by the long fuzz campaign of round 4: 5 of 59 keypoints differed)
             for (int i = tid; i < S; i += QT_T) proc_rank[i] = -1;
-            for (int i = tid; i < T_prev + 3; i += QT_T) {
-                if (i < T_prev) { rank_acc[i] = 0; okey[i] = (min(C.cnt[i], 0xFFFFu) << 16) | (0xFFFFu - (uint32_t)i); }
-                else okey[i] = 0;                                                      // padding of the last group of four
-            }
-            if (tid == 0) s_misc[2] = 0;
-            __syncthreads();
-            const int W = T_prev, G = (W > 0 && W <= QT_T / 2) ? QT_T / W : 1;        // G threads per candidate
-            const int part = (((W + G - 1) / G) + 3) & ~3;                             // list entries per thread, a multiple of 4
-            int mine = 0;
-            for (int i0 = 0; i0 < W; i0 += QT_T) {
-                const int i = G > 1 ? tid % W : i0 + tid, g = G > 1 ? tid / W : 0;
-                if (i < W && g < G) {
-                    const uint32_t ki = okey[i];
-                    if (ki >= (2u << 16)) {                                            // a multi-point node
-                        const int j0 = g * part, j1 = min((W + 3) & ~3, j0 + part);
-                        int r = 0;
-                        const uint4* k4 = reinterpret_cast<const uint4*>(okey);       // four keys per LDS read
-                        for (int j = j0; j < j1; j += 4) {
-                            const uint4 q = k4[j >> 2];
-                            r += (q.x > ki) + (q.y > ki) + (q.z > ki) + (q.w > ki);
-                        }
-                        if (G > 1) { if (r) atomicAdd(&rank_acc[i], (uint32_t)r); } else rank_acc[i] = (uint32_t)r;
-                        mine += g == 0;
-                    }
+            auto rank_candidates = [&](auto key_zero) {
+                using K = decltype(key_zero);
+                K* const okey = reinterpret_cast<K*>(ccount);                          // [T_prev + 3]
+                static_assert(sizeof(ccount) >= (QT_M + 3) * sizeof(unsigned long long), "sort keys");
+                for (int i = tid; i < T_prev + 3; i += QT_T) {
+                    if (i < T_prev) { rank_acc[i] = 0; okey[i] = ((K)C.cnt[i] << 16) | (K)(0xFFFFu - (uint32_t)i); }
+                    else okey[i] = 0;                                                  // padding of the last group of four
                 }
-                if (G > 1) break;
-            }
-            {   // number of candidates
-                const unsigned long long bal = __ballot(mine > 0);
-                int cntw = mine;
-                if (W > QT_T) {
+                if (tid == 0) s_misc[2] = 0;
+                __syncthreads();
+                const int W = T_prev, G = (W > 0 && W <= QT_T / 2) ? QT_T / W : 1;    // G threads per candidate
+                const int part = (((W + G - 1) / G) + 3) & ~3;                         // list entries per thread, a multiple of 4
+                int mine = 0;
+                for (int i0 = 0; i0 < W; i0 += QT_T) {
+                    const int i = G > 1 ? tid % W : i0 + tid, g = G > 1 ? tid / W : 0;
+                    if (i < W && g < G) {
+                        const K ki = okey[i];
+                        if (ki >= ((K)2 << 16)) {                                      // a multi-point node
+                            const int j0 = g * part, j1 = min((W + 3) & ~3, j0 + part);
+                            int r = 0;
+                            if constexpr (sizeof(K) == 4) {
+                                const uint4* k4 = reinterpret_cast<const uint4*>(okey);   // four keys per LDS read
+                                for (int j = j0; j < j1; j += 4) {
+                                    const uint4 q = k4[j >> 2];
+                                    r += (q.x > ki) + (q.y > ki) + (q.z > ki) + (q.w > ki);
+                                }
+                            } else {
+                                for (int j = j0; j < j1; j++) r += okey[j] > ki;
+                            }
+                            if (G > 1) { if (r) atomicAdd(&rank_acc[i], (uint32_t)r); } else rank_acc[i] = (uint32_t)r;
+                            mine += g == 0;
+                        }
+                    }
+                    if (G > 1) break;
+                }
+                {   // number of candidates
+                    const unsigned long long bal = __ballot(mine > 0);
+                    int cntw = mine;
+                    if (W > QT_T) {
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) cntw += __shfl_xor(cntw, o, 64);
-                } else cntw = (int)__popcll(bal);
-                if ((tid & 63) == 0 && cntw) atomicAdd(&s_misc[2], cntw);
-            }
-            __syncthreads();
-            for (int i = tid; i < W; i += QT_T)
+                        for (int o = 32; o > 0; o >>= 1) cntw += __shfl_xor(cntw, o, 64);
+                    } else cntw = (int)__popcll(bal);
+                    if ((tid & 63) == 0 && cntw) atomicAdd(&s_misc[2], cntw);
+                }
+                __syncthreads();
+            };
+            if (n <= 65535) rank_candidates((uint32_t)0); else rank_candidates((unsigned long long)0);
+            for (int i = tid; i < T_prev; i += QT_T)
                 if (C.cnt[i] > 1) { const int r = (int)rank_acc[i]; proc_rank[i] = (int16_t)r; order_node[r] = (int16_t)i; }
             E = s_misc[2];
         }

@@ -246,6 +246,26 @@ def test_fast_kernel_variants_in_subprocess(gpu, env):
     assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_quadtree_nodes_above_65535_points_rank_by_size(gpu):
+    """a saturated 4 Mpx frame (checkerboard of pitch 4 + noise) with a small quota: level 1 holds 264 572 candidates in ONE root, whose four children
+    hold more than 65 535 points each when the size-ordered passes start.  Their sort keys carried the count in 16 bits (clamped), so they tied and
+    went by list index instead of by size: 5 of 59 keypoints differed from the oracle (seed 2019 of the long fuzz campaign of round 4).  The
+    reference sorts by the real size (`ORBExtractor.cpp:321-325`)."""
+    h, w = 1679, 2421
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (((yy // 4) + (xx // 4)) % 2 * 121).astype(np.int32)
+    p = oracle.default_params(50, 1.2, 8)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=50, fScaleFactor=1.2, nLevels=8))
+    for seed in (5, 9, 14, 7):                                    # noise seeds 5, 9, 14 differed with the clamped keys (7 happened to agree)
+        img = np.clip(base + np.random.default_rng(seed).integers(0, 30, (h, w)), 0, 255).astype(np.uint8)
+        ok, od, dbg = oracle.extract(p, img, cap=4 * 50 + 64 * 8 + 1024, debug=True, cand_cap=1 << 21)
+        assert int(dbg["n_candidates"].max()) > 4 * 65535, "the frame must put more than 65 535 points into each child of one root"
+        buf = np.zeros((h, w + 16), np.uint8)                     # the row stride of the fuzz case (odd: the unaligned load path)
+        buf[:, :w] = img
+        gk, gd = ex(buf[:, :w])
+        assert_same_features(gk, gd, ok, od)
+
+
 def test_quadtree_count_domain_and_its_fallbacks(gpu):
     """DistributeOctTree in the count domain (histogram pyramid of the points' geometric keys, phase 1 in closed form) and every way out of it:
     clustered corners that need nodes deeper than the pyramid (switch to the point-domain passes in the middle of the distribution), 3..8 root

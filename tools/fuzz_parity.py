@@ -46,6 +46,36 @@ def make_image(rng, kind, w, h, seed):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def diagnose(ex, view, img, p, ok, od, gk, gd, big):
+    """a mismatch: is it repeatable, which stage differs first (pyramid bytes / candidate sets / selection per level, through the debug taps), which records"""
+    out = []
+    try:
+        reps = [ex(view) for _ in range(3)]
+        out.append("repeat runs equal to the first: %s" % [bool(k.tobytes() == gk.tobytes() and np.array_equal(d, gd)) for k, d in reps])
+        out.append("repeat runs equal to the oracle: %s" % [bool(len(k) == len(ok) and k.tobytes() == ok.tobytes() and np.array_equal(d, od)) for k, d in reps])
+        _, _, dbg = oracle.extract(p, np.ascontiguousarray(img), cap=big, debug=True, cand_cap=1 << 21)
+        ex.set_debug(True)
+        gk2, gd2 = ex(view)
+        out.append("debug-mode run equal to the oracle: %s" % bool(len(gk2) == len(ok) and gk2.tobytes() == ok.tobytes() and np.array_equal(gd2, od)))
+        for l in range(p.nlevels):
+            pyr_ok = np.array_equal(ex.debug_level(0, l), dbg["pyramid"][l])
+            gc = ex.debug_candidates(0, l); oc = dbg["candidates"][l].astype(np.int32)
+            cand_ok = len(gc) == len(oc) and (len(gc) == 0 or np.array_equal(gc[np.lexsort((gc[:, 0], gc[:, 1]))], oc[np.lexsort((oc[:, 0], oc[:, 1]))]))
+            gs = ex.debug_selected(0, l)
+            out.append("level %d: pyramid %s, candidates %s (gpu %d, oracle %d), selected gpu %d oracle %d" % (l, pyr_ok, cand_ok, len(gc), len(oc), len(gs), int(dbg["n_selected"][l])))
+        ex.set_debug(False)
+        n = min(len(gk), len(ok))
+        bad = [i for i in range(n) if gk[i].tobytes() != ok[i].tobytes() or not np.array_equal(gd[i], od[i])]
+        out.append("records that differ (product run): %d of %d, first %s" % (len(bad), n, bad[:8]))
+        for i in bad[:4]:
+            out.append("  [%d] gpu %s | oracle %s | descriptor equal %s" % (i, gk[i], ok[i], bool(np.array_equal(gd[i], od[i]))))
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed("gpurun_out/fuzz_mismatch.npz", img=img, stride=np.int64(view.strides[0]), nfeat=p.nfeatures, scale=p.scale_factor, levels=p.nlevels, gk=gk, gd=gd, ok=ok, od=od)
+    except Exception as e:                      # the diagnosis must never hide the mismatch itself
+        out.append("diagnosis failed: %r" % (e,))
+    return "\n    " + "\n    ".join(out)
+
+
 def one_case(rng, i):
     kind = ["scene", "scene", "noise", "checker", "flat", "texture", "cluster"][int(rng.integers(0, 7))]
     w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
@@ -80,6 +110,8 @@ def one_case(rng, i):
     ok, od = oracle.extract(p, np.ascontiguousarray(img), cap=big)
     good = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
     msg = desc + " pad %d -> %d keypoints %s" % (pad, len(ok), "ok" if good else "MISMATCH (gpu %d)" % len(gk))
+    if not good:
+        msg += diagnose(ex, view, img, p, ok, od, gk, gd, big)
     if good and len(ok) > 20 and rng.random() < 0.3:      # stereo: shifted copy with noise as the right frame
         sh = int(rng.integers(1, 40))
         right = np.roll(img, -sh, axis=1).copy()
