@@ -40,6 +40,13 @@ def make_image(rng, kind, w, h, seed):
             x, y = int(rng.integers(0, max(1, w - pw))), int(rng.integers(0, max(1, h - ph)))
             img[y:y + ph, x:x + pw] = rng.integers(0, 256, img[y:y + ph, x:x + pw].shape)
         return np.clip(img, 0, 255).astype(np.uint8)
+    if kind == "band":                         # all the texture in one or two narrow horizontal bands: the keypoints of a frame crowd into a few of the stereo matcher's 32-row strips
+        img = np.full((h, w), int(rng.integers(40, 200)), np.int32) + rng.integers(0, 4, (h, w))
+        for _ in range(int(rng.integers(1, 3))):
+            bh = int(rng.integers(40, max(41, min(160, h // 2))))
+            y = int(rng.integers(0, max(1, h - bh)))
+            img[y:y + bh] = synth_image(seed, w, bh).astype(np.int32) if rng.random() < 0.5 else rng.integers(0, 256, (bh, w))
+        return np.clip(img, 0, 255).astype(np.uint8)
     # gradient + mid-frequency texture
     yy, xx = np.mgrid[0:h, 0:w]
     img = 128 + 60 * np.sin(xx / float(rng.integers(3, 40))) * np.cos(yy / float(rng.integers(3, 40))) + (xx * 40.0 / w) + rng.normal(0, float(rng.uniform(0, 12)), (h, w))
@@ -76,13 +83,25 @@ def diagnose(ex, view, img, p, ok, od, gk, gd, big):
     return "\n    " + "\n    ".join(out)
 
 
+STRESS = False                                  # --stress: big and saturated frames, tiny and huge quotas, banded frames, several frames per call
+
+
 def one_case(rng, i):
-    kind = ["scene", "scene", "noise", "checker", "flat", "texture", "cluster"][int(rng.integers(0, 7))]
-    w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
-    h = int(rng.integers(64, 1100)) if rng.random() < 0.85 else int(rng.integers(1100, 1700))
+    if STRESS:
+        kind = ["checker", "checker", "checker", "noise", "cluster", "band", "band", "scene"][int(rng.integers(0, 8))]
+        large = rng.random() < 0.45
+        w = int(rng.integers(1500, 4001)) if large else int(rng.integers(64, 1500))
+        h = int(rng.integers(1000, 3001)) if large else int(rng.integers(64, 1100))
+    else:
+        kind = ["scene", "scene", "noise", "checker", "flat", "texture", "cluster"][int(rng.integers(0, 7))]
+        w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
+        h = int(rng.integers(64, 1100)) if rng.random() < 0.85 else int(rng.integers(1100, 1700))
     if rng.random() < 0.95:
         h = min(h, 2 * w - 1)                   # w/h < 0.5 gives zero root nodes in the reference (division by zero, :183): refused by the library
     nfeat = int(rng.integers(20, 4000))
+    if STRESS:
+        r = rng.random()
+        nfeat = int(rng.integers(20, 120)) if r < 0.35 else (int(rng.integers(3000, 12000)) if r < 0.6 else nfeat)
     scale = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.25, 1.3, 1.4, 1.5, 2.0])))
     levels = int(rng.choice([1, 2, 4, 6, 8, 8, 8, 10, 12]))
     if levels <= 2:
@@ -112,7 +131,18 @@ def one_case(rng, i):
     msg = desc + " pad %d -> %d keypoints %s" % (pad, len(ok), "ok" if good else "MISMATCH (gpu %d)" % len(gk))
     if not good:
         msg += diagnose(ex, view, img, p, ok, od, gk, gd, big)
-    if good and len(ok) > 20 and rng.random() < 0.3:      # stereo: shifted copy with noise as the right frame
+    if good and STRESS and rng.random() < 0.3:             # several frames of the same size in ONE call (the batch paths: item lists, schedules, keys by batch size)
+        nb = int(rng.integers(2, 5))
+        frames = [img] + [make_image(rng, kind, w, h, seed + 1 + j) for j in range(nb - 1)]
+        bks, bds = ex.extract_batch(frames)
+        for j, (bk, bd) in enumerate(zip(bks, bds)):
+            okj, odj = (ok, od) if j == 0 else oracle.extract(p, np.ascontiguousarray(frames[j]), cap=big)
+            if not (len(bk) == len(okj) and bk.tobytes() == okj.tobytes() and np.array_equal(bd, odj)):
+                good = False
+                msg += "; batch of %d: frame %d MISMATCH" % (nb, j)
+        if good:
+            msg += "; batch of %d ok" % nb
+    if good and len(ok) > 20 and rng.random() < (0.5 if STRESS else 0.3):      # stereo: shifted copy with noise as the right frame
         sh = int(rng.integers(1, 40))
         right = np.roll(img, -sh, axis=1).copy()
         right = np.clip(right.astype(np.int32) + rng.integers(-3, 4, right.shape), 0, 255).astype(np.uint8)
@@ -136,7 +166,10 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    ap.add_argument("--stress", action="store_true", help="big / saturated / banded frames, tiny and huge quotas, several frames per call")
     a = ap.parse_args()
+    global STRESS
+    STRESS = a.stress
     rng = np.random.default_rng(a.seed)
     t0, bad = time.time(), 0
     for i in range(a.cases):
