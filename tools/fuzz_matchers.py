@@ -18,12 +18,21 @@ import hyslam_amd as HS                         # noqa: E402
 from hyslam_amd import _native as N             # noqa: E402
 
 
+STRESS = False                                  # --stress: frames up to 4000 x 3000, up to 8000 keypoints per frame, up to 20 landmark copies (160 000 landmarks)
+
+
 def one_case(rng, i, ex):
     seed = int(rng.integers(0, 1 << 30))
-    w, h = int(rng.integers(200, 900)), int(rng.integers(160, 640))
-    h = min(h, 2 * w - 1)
-    nfeat = int(rng.integers(50, 1500))
-    copies = int(rng.integers(1, 6))
+    if STRESS:
+        w, h = int(rng.integers(600, 4001)), int(rng.integers(400, 3001))
+        h = min(h, 2 * w - 1)
+        nfeat = int(rng.integers(1000, 8000))
+        copies = int(rng.integers(3, 21))
+    else:
+        w, h = int(rng.integers(200, 900)), int(rng.integers(160, 640))
+        h = min(h, 2 * w - 1)
+        nfeat = int(rng.integers(50, 1500))
+        copies = int(rng.integers(1, 6))
     sensor = int(rng.integers(0, 2))
     fx = float(rng.uniform(200, 900))
     nnratio = float(np.float32(rng.choice([0.6, 0.7, 0.8, 0.9, 1.0])))
@@ -112,7 +121,10 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=1e9)
+    ap.add_argument("--stress", action="store_true", help="large frames, thousands of keypoints per frame, up to 160 000 landmarks")
     a = ap.parse_args()
+    global STRESS
+    STRESS = a.stress
     rng = np.random.default_rng(a.seed)
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500))
     t0, bad = time.time(), 0
