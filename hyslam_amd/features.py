@@ -55,11 +55,12 @@ def _params(settings, blur_taps=None, fast_threshold=20):
 class ORBExtractor:
     """HYSLAM::ORBExtractor.  `extractor(image)` returns (keypoints[KP_DTYPE], descriptors[n,32] uint8)."""
 
-    def __init__(self, settings=None, device=0, blur_taps=None):
+    def __init__(self, settings=None, device=0, blur_taps=None, fast_threshold=20):
+        """fast_threshold: hs_orb_params::fast_threshold (the reference always runs 20: ORBFinder.cpp:58-60; other values are for tests and other callers)"""
         self.settings = settings or FeatureExtractorSettings()
         self._lib = N.lib()
         self._h = C.c_void_p()
-        self._p = _params(self.settings, blur_taps)
+        self._p = _params(self.settings, blur_taps, fast_threshold)
         st = self._lib.hs_orb_create(C.byref(self._p), device, C.byref(self._h))
         if st != N.HS_OK:
             self._h = C.c_void_p()

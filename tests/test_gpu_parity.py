@@ -246,6 +246,24 @@ def test_fast_kernel_variants_in_subprocess(gpu, env):
     assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_fast_thresholds_other_than_the_references_20(gpu):
+    """hs_orb_params::fast_threshold accepts 0..255 (the reference is stuck at 20, ORBFinder.cpp:58-60): the quick reject's reduced-precision bound
+    k = (t + 1) / 4, the one-polarity choice and 'score >= t is the segment test' must hold for every t, not only for 20"""
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:480, 0:640]
+    frames = [synth_image(5, 640, 480), rng.integers(0, 256, (480, 640), dtype=np.uint8),
+              np.clip((((yy // 5) + (xx // 5)) % 2 * 150).astype(np.int32) + rng.integers(0, 30, (480, 640)), 0, 255).astype(np.uint8),
+              ((xx * 255) // 639).astype(np.uint8)]
+    for t in (0, 1, 3, 4, 7, 19, 21, 40, 63, 64, 127, 128, 200, 255):
+        p = oracle.default_params(800, 1.2, 8)
+        p.fast_threshold = t
+        ex = HS.ORBExtractor(settings(800), fast_threshold=t)
+        for img in frames:
+            ok, od = oracle.extract(p, img, cap=8000)
+            gk, gd = ex(img)
+            assert len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od), "threshold %d" % t
+
+
 def test_quadtree_nodes_above_65535_points_rank_by_size(gpu):
     """a saturated 4 Mpx frame (checkerboard of pitch 4 + noise) with a small quota: level 1 holds 264 572 candidates in ONE root, whose four children
     hold more than 65 535 points each when the size-ordered passes start.  Their sort keys carried the count in 16 bits (clamped), so they tied and

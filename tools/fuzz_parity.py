@@ -107,9 +107,15 @@ def one_case(rng, i):
     if levels <= 2:
         nfeat = min(nfeat, int(rng.integers(20, 2000)))      # a level's quota is limited to 2040 (quadtree list in LDS)
     seed = int(rng.integers(0, 1 << 30))
+    cell, fth = 30, 20
+    if STRESS and rng.random() < 0.4:           # parameters the reference never varies but the C ABI accepts: the cell edge (N_CELLS) and the FAST threshold
+        cell = int(rng.choice([12, 16, 20, 25, 30, 37, 45, 62]))
+        fth = int(rng.choice([0, 1, 3, 5, 7, 10, 15, 20, 25, 40, 63, 64, 100, 128, 200]))
     desc = "case %d: %s %dx%d nfeat %d scale %.2f levels %d seed %d" % (i, kind, w, h, nfeat, scale, levels, seed)
+    if (cell, fth) != (30, 20):
+        desc += " cell %d threshold %d" % (cell, fth)
     try:
-        ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels))
+        ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels, N_CELLS=cell), fast_threshold=fth)
     except Exception as e:                      # configuration the library refuses (too many levels for the size etc.): must be refused cleanly
         return desc + "  -> refused at create: %s" % str(e)[:60], True
     img = make_image(rng, kind, w, h, seed)
@@ -125,6 +131,7 @@ def one_case(rng, i):
     except Exception as e:
         return desc + "  -> refused at extract: %s" % str(e)[:80], True
     p = oracle.default_params(nfeat, scale, levels)
+    p.cell_px, p.fast_threshold = cell, fth
     big = 4 * nfeat + 64 * levels + 1024         # small quotas overshoot: a breadth-first pass quadruples the list before the size is checked
     ok, od = oracle.extract(p, np.ascontiguousarray(img), cap=big)
     good = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
