@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle                                   # noqa: E402  (tests/oracle.py: the checker)
 import hyslam_amd as HS                         # noqa: E402
+from hyslam_amd import _native as N             # noqa: E402
 from hyslam_amd.synth import synth_image, synth_stereo_pair   # noqa: E402
 
 
@@ -149,6 +150,31 @@ def one_case(rng, i):
                 msg += "; batch of %d: frame %d MISMATCH" % (nb, j)
         if good:
             msg += "; batch of %d ok" % nb
+    if good and STRESS and w * h <= 700 * 700 and rng.random() < 0.35:
+        # the stereo FRONT END on several pairs in one call, through the ingest tickets (submit / wait: the strips binned inside the describe launch, the
+        # batch-dependent choices of item width, schedule and keys): n pairs of distinct content, right = shifted + noisy left
+        npairs = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17]))
+        lefts = [img] + [make_image(rng, kind, w, h, seed + 100 + j) for j in range(npairs - 1)]
+        sh = int(rng.integers(1, 40))
+        rights = [np.clip(np.roll(L, -sh, axis=1).astype(np.int32) + rng.integers(-3, 4, L.shape), 0, 255).astype(np.uint8) for L in lefts]
+        fx = float(rng.uniform(300, 1500))
+        osp = oracle.stereo_params(fx=fx, mbf=fx * 0.12, n_rows=h)
+        gsp = N.StereoParams(fx, fx * 0.12, h, 100.0, 50.0, 31.0)
+        t = ex.submit_batch([np.ascontiguousarray(a) for a in lefts + rights], gsp)
+        n, fk, fd, fu, fz = ex.wait(t)
+        fgood = True
+        for j in range(npairs):
+            okL, odL, okR, odR, ouR, oz = oracle.stereo_frontend(p, osp, lefts[j], rights[j], cap=big)
+            a, b = int(n[j]), int(n[npairs + j])
+            same = (a == len(okL) and b == len(okR) and fk[j, :a].tobytes() == okL.tobytes() and np.array_equal(fd[j, :a], odL)
+                    and fk[npairs + j, :b].tobytes() == okR.tobytes() and np.array_equal(fd[npairs + j, :b], odR)
+                    and np.array_equal(fu[j, :a], ouR) and np.array_equal(fz[j, :a], oz))
+            if not same:
+                fgood = False
+                msg += "; front end, %d pairs: pair %d MISMATCH (n %d/%d oracle %d/%d)" % (npairs, j, a, b, len(okL), len(okR))
+        good = good and fgood
+        if fgood:
+            msg += "; front end, %d pairs ok" % npairs
     if good and len(ok) > 20 and rng.random() < (0.5 if STRESS else 0.3):      # stereo: shifted copy with noise as the right frame
         sh = int(rng.integers(1, 40))
         right = np.roll(img, -sh, axis=1).copy()
