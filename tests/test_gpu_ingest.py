@@ -112,3 +112,46 @@ def test_ticket_survives_a_failed_wait_and_can_be_cancelled(gpu):
     t3, t4 = ex.submit_batch(a), ex.submit_batch(a)                        # both slots are free again
     r3, r4 = ex.wait(t3), ex.wait(t4)
     assert np.array_equal(r3[0], r1[0]) and r3[1][0, :r3[0][0]].tobytes() == r4[1][0, :r4[0][0]].tobytes()
+
+
+def test_concurrent_handles_random_geometry(gpu):
+    """distinct handles are concurrent (the reference runs its two extractors in two threads, ImageProcessing.cpp:82-84): three host threads, each with
+    its own handles, call with changing geometry, quota and batch size at the same time — every result must be the oracle's, whatever the other
+    threads' kernels are doing on the GPU"""
+    import threading
+    rng = np.random.default_rng(11)
+    cases = []
+    for i in range(8):
+        w, h = int(rng.integers(200, 1300)), int(rng.integers(160, 800))
+        h = min(h, w)
+        nf = int(rng.integers(100, 2500))
+        img = synth_image(100 + i, w, h)
+        ok, od = oracle.extract(oracle.default_params(nf, 1.2, 8), img, cap=4 * nf + 2000)
+        cases.append((img, nf, ok, od))
+    bad = []
+
+    def worker(t):
+        try:
+            ex, r = {}, np.random.default_rng(t)
+            for it in range(25):
+                j = int(r.integers(0, len(cases)))
+                img, nf, ok, od = cases[j]
+                if nf not in ex:
+                    ex[nf] = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nf, fScaleFactor=1.2, nLevels=8))
+                if r.random() < 0.3:
+                    ks, ds = ex[nf].extract_batch([img, img, img])
+                    res = list(zip(ks, ds))
+                else:
+                    res = [ex[nf](img)]
+                for gk, gd in res:
+                    if not (len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)):
+                        bad.append((t, it, j))
+        except Exception as e:                                             # a dead thread must fail the test, not shorten it
+            bad.append((t, "exception", repr(e)[:200]))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad[:5]
