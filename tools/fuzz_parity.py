@@ -150,6 +150,29 @@ def one_case(rng, i):
                 msg += "; batch of %d: frame %d MISMATCH" % (nb, j)
         if good:
             msg += "; batch of %d ok" % nb
+    if good and STRESS and rng.random() < 0.3:
+        # the SAME handle on a sequence of other frames: other sizes (reconfiguration, workspace reuse), saturated after nearly empty and back (whatever an
+        # earlier call left in the candidate slots, counters, key histograms and lists must not leak into the next result)
+        for q in range(3):
+            k2 = ["flat", "checker", "noise", "scene", "cluster", "band"][int(rng.integers(0, 6))]
+            if rng.random() < 0.5:
+                w2, h2 = w, h
+            else:
+                w2, h2 = int(rng.integers(64, 1400)), int(rng.integers(64, 1000))
+                h2 = min(h2, 2 * w2 - 1)
+            img2 = make_image(rng, k2, w2, h2, seed + 1000 + q)
+            try:
+                g2k, g2d = ex(img2)
+            except Exception as e:
+                msg += "; reuse %d (%s %dx%d) refused: %s" % (q, k2, w2, h2, str(e)[:40])
+                continue
+            o2k, o2d = oracle.extract(p, img2, cap=big)
+            if not (len(g2k) == len(o2k) and g2k.tobytes() == o2k.tobytes() and np.array_equal(g2d, o2d)):
+                good = False
+                msg += "; handle reuse %d (%s %dx%d after %s %dx%d) MISMATCH (gpu %d oracle %d)" % (q, k2, w2, h2, kind, w, h, len(g2k), len(o2k))
+                break
+        else:
+            msg += "; handle reused on 3 frames ok"
     if good and STRESS and w * h <= 700 * 700 and rng.random() < 0.35:
         # the stereo FRONT END on several pairs in one call, through the ingest tickets (submit / wait: the strips binned inside the describe launch, the
         # batch-dependent choices of item width, schedule and keys): n pairs of distinct content, right = shifted + noisy left
