@@ -116,12 +116,84 @@ def one_case(rng, i, ex):
     return desc + " -> " + ", ".join(n + ("" if g else " MISMATCH") for n, g in res), good
 
 
+def records_case(rng, i, ex):
+    """BASELINE config 5's device path on random shapes: `world` frame records (odd and even capacities: the padded descriptor offset), random counts
+    incl. empty records, descriptors with planted near-duplicates across the ranks; the cross-camera 2-NN of a random rank against every peer and the
+    vocabulary-grouped match on a random small vocabulary, both against the oracle"""
+    import hipmem
+    from hyslam_amd import distributed as D
+    from hyslam_amd.synth import synth_vocab_tree
+    world = int(rng.integers(1, 9))
+    cap = int(rng.integers(40, 2600 if STRESS else 700))
+    rb = D.record_bytes(cap)
+    base = rng.integers(0, 256, (int(rng.integers(1, 400)), 32), dtype=np.uint8)          # a pool the ranks draw from: real matches across cameras
+    feats, host = [], np.zeros((world, rb), np.uint8)
+    for r in range(world):
+        n = int(rng.choice([0, 1, cap, int(rng.integers(0, cap + 1))]))
+        k = np.zeros(n, N.KP_DTYPE)
+        k["x"], k["y"], k["angle"], k["octave"] = rng.uniform(0, 1900, n), rng.uniform(0, 1000, n), rng.uniform(0, 360, n), rng.integers(0, 8, n)
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        take = rng.random(n) < 0.6
+        d[take] = base[rng.integers(0, len(base), int(take.sum()))]
+        flip = rng.random(n) < 0.5                                                         # a few bits off: distances around the thresholds
+        d[flip, rng.integers(0, 32)] ^= np.uint8(rng.integers(1, 256))
+        host[r] = D.pack_record(k, d, cap)
+        feats.append((k, d))
+    recs = hipmem.DevBuf.from_numpy(host.reshape(-1))
+    rank = int(rng.integers(0, world))
+    desc = "case %d: records world %d cap %d rank %d counts %s" % (i, world, cap, rank, [len(f[0]) for f in feats])
+    res = []
+    outs = [hipmem.DevBuf(world * cap * 4) for _ in range(3)]
+    D.records_knn2_device(ex, recs.ptr, rb, world, rank, cap, outs[0].ptr, outs[1].ptr, outs[2].ptr, 0)
+    ex.synchronize()
+    bi, bd, sd = (o.to_numpy(np.int32, world * cap).reshape(world, cap) for o in outs)
+    nq, good = len(feats[rank][0]), True
+    for peer in range(world):
+        if peer == rank or nq == 0 or len(feats[peer][0]) == 0:
+            continue
+        obi, obd, osd = oracle.hamming_knn2(feats[rank][1], feats[peer][1])
+        good = good and np.array_equal(bi[peer, :nq], obi) and np.array_equal(bd[peer, :nq], obd) and np.array_equal(sd[peer, :nq], osd)
+    res.append(("knn2", good))
+    kk, LL = int(rng.choice([2, 4, 10])), int(rng.choice([2, 3, 4]))
+    up = int(rng.integers(0, LL))
+    Tg, keep, n_words = synth_vocab_tree(kk, LL, int(rng.integers(0, 1 << 20)))
+    To = oracle.VocabTree(Tg.n_nodes, Tg.levels, Tg.child_begin, Tg.child_count, Tg.desc, Tg.word_id, Tg.weight, None)
+    try:
+        voc = D.DeviceVocabulary(ex, Tg, up, keep)
+    except N.HsError as e:                                  # more feature-vector groups than the device search keeps counters for: refused cleanly
+        res.append(("bow k%d L%d up%d refused (%s)" % (kk, LL, up, str(e)[-60:]), True))
+        return desc + " -> " + ", ".join("%s%s" % (n, "" if g else " MISMATCH") for n, g in res), all(g for _, g in res)
+    fvs = [HS.ORBVocabulary.containers(*oracle.bow_transform(To, feats[r][1], up))[1] if len(feats[r][0]) else {} for r in range(world)]
+    th_low, ratio, ori = float(rng.choice([50.0, 70.0, 30.0])), float(np.float32(rng.choice([0.6, 0.8, 1.0]))), bool(rng.integers(0, 2))
+    d_m, d_nm = hipmem.DevBuf(world * cap * 4), hipmem.DevBuf(world * 4)
+    voc.records_bow_match_device(recs.ptr, rb, world, rank, cap, th_low, ratio, ori, d_m.ptr, d_nm.ptr, 0)
+    ex.synchronize()
+    gm, gn = d_m.to_numpy(np.int32, world * cap).reshape(world, cap), d_nm.to_numpy(np.int32, world)
+    good = True
+    k1, d1 = feats[rank]
+    for peer in range(world):
+        if peer == rank:
+            good = good and gn[peer] == 0 and bool((gm[peer] == -1).all())
+            continue
+        k2, d2 = feats[peer]
+        if len(k1) == 0 or len(k2) == 0:
+            good = good and gn[peer] == 0
+            continue
+        om, on = oracle.search_by_bow(k1, d1, fvs[rank], k2, d2, fvs[peer], None, th_low, ratio, ori)
+        good = good and gn[peer] == on and np.array_equal(gm[peer, :len(k1)], om)
+    res.append(("bow k%d L%d up%d" % (kk, LL, up), good))
+    voc.close()
+    ok = all(g for _, g in res)
+    return desc + " -> " + ", ".join("%s%s" % (n, "" if g else " MISMATCH") for n, g in res), ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=1e9)
     ap.add_argument("--stress", action="store_true", help="large frames, thousands of keypoints per frame, up to 160 000 landmarks")
+    ap.add_argument("--records", action="store_true", help="only the frame-record cases (BASELINE config 5's device path); otherwise every fifth case is one")
     a = ap.parse_args()
     global STRESS
     STRESS = a.stress
@@ -129,7 +201,7 @@ def main():
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500))
     t0, bad = time.time(), 0
     for i in range(a.cases):
-        msg, good = one_case(rng, i, ex)
+        msg, good = records_case(rng, i, ex) if (a.records or i % 5 == 4) else one_case(rng, i, ex)
         print(msg, flush=True)
         bad += not good
         if not good or time.time() - t0 > a.seconds:
