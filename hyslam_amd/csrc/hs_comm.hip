@@ -39,11 +39,24 @@ Rccl& rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // WHICH copy: the one that lives next to the HIP runtime this process actually runs on.  A process may hold two ROCm stacks (PyTorch ships its own
+        // libamdhip64 + librccl; whichever HIP runtime is loaded first serves everybody) and RCCL must match the runtime whose streams it is handed:
+        // PyTorch's RCCL on the system's runtime failed in ncclCommInitRank ("unhandled cuda error"), the system's RCCL next to PyTorch's runtime
+        // is the same mix the other way round.  So: the directory of the loaded libamdhip64 first, then the usual names.
+        std::string near1, near2;
+        {
+            Dl_info info;
+            if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+                std::string dir(info.dli_fname);
+                const size_t slash = dir.rfind('/');
+                if (slash != std::string::npos) { dir.resize(slash + 1); near1 = dir + "librccl.so.1"; near2 = dir + "librccl.so"; }
+            }
+        }
+        const char* names[] = { near1.c_str(), near2.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         // RTLD_LOCAL: a process may hold ANOTHER copy of RCCL (PyTorch ships its own and loads it by path; a copy that is already resident under the
         // same soname is simply reused).  With RTLD_GLOBAL this copy's symbols interposed on a PyTorch imported later and the process died in the static
         // destructors at exit ("double free or corruption")
-        for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.so) break; }
+        for (const char* n : names) { if (!*n) continue; r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.so) break; }
         if (!r.so) { const char* e = dlerror(); r.why = std::string("librccl not found: ") + (e ? e : ""); return; }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));

@@ -125,7 +125,6 @@ def verify_exchange(gathered, local_count, rank, world, match_outputs=None, grou
 
 def comm_available():
     """(ok, reason): can this process create an hs_comm communicator (librccl loads)?  Non-collective — ask on every rank before RecordExchange."""
-    import torch  # noqa: F401  (first: the library looks for librccl.so.1 and then finds the copy torch has already loaded instead of bringing a second one into the process)
     from . import _native as N
     L = N.lib()
     ok = L.hs_comm_available() == N.HS_OK
@@ -141,7 +140,6 @@ class RecordExchange:
     @staticmethod
     def unique_id():
         import ctypes as C
-        import torch  # noqa: F401  (before the library looks for librccl: see comm_available)
         from . import _native as N
         ident = (C.c_uint8 * 128)()
         st = N.lib().hs_comm_get_unique_id(ident)
@@ -151,7 +149,6 @@ class RecordExchange:
 
     def __init__(self, extractor, ident, world, rank):
         import ctypes as C
-        import torch  # noqa: F401
         from . import _native as N
         self._ex, self.world, self.rank = extractor, world, rank
         self._c = C.c_void_p()

@@ -389,8 +389,9 @@ int  hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_s
  * Lifetime: a communicator BORROWS its handle (device, stream).  The handle is reference-counted (the owner + one per communicator):
  * hs_orb_destroy on a handle that still has communicators only drops the owner's reference and the last hs_comm_destroy frees it, so the two
  * destroy calls are safe in either order and from two threads; the handle must not be used for anything else after its hs_orb_destroy.
- * hs_orb_borrowers() = communicators alive on the handle.  librccl is loaded RTLD_LOCAL: a host process that carries its own copy of RCCL
- * (PyTorch does) keeps using that one; a copy already resident under the soname librccl.so.1 is reused. */
+ * hs_orb_borrowers() = communicators alive on the handle.  librccl is taken from the directory of the HIP runtime the process runs on (a
+ * process may hold two ROCm stacks: PyTorch ships its own libamdhip64 + librccl, and RCCL must match the runtime whose streams it is handed),
+ * then by its usual names, and loaded RTLD_LOCAL so that a second copy in the process is left alone. */
 #define HS_COMM_ID_BYTES 128
 typedef struct hs_comm hs_comm;
 int  hs_comm_available(void);

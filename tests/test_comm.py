@@ -105,9 +105,34 @@ def test_comm_probe_and_borrowers_symbols():
     assert lib.hs_orb_borrowers(None) == 0
 
 
+@pytest.mark.gpu
+def test_comm_after_torch_uses_the_rccl_next_to_the_loaded_hip_runtime(gpu):
+    """the order of a multi-GPU bench run: PyTorch first (its own libamdhip64 + librccl become the process's ROCm stack), then hs_comm.  The library
+    must pick the RCCL that lives next to the HIP runtime in use — the system's librccl on PyTorch's runtime, or PyTorch's on the system's, failed in
+    ncclCommInitRank ('unhandled cuda error').  In a fresh process: communicator at world 1, all-gather in place, clean exit."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "torch.cuda.set_device(0); _ = torch.zeros(4, device='cuda')\n"
+            "import hipmem, hyslam_amd as HS\n"
+            "from hyslam_amd import distributed as D\n"
+            "ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500))\n"
+            "xc = D.RecordExchange(ex, D.RecordExchange.unique_id(), 1, 0)\n"
+            "src, dst = hipmem.DevBuf.from_numpy(np.arange(4096, dtype=np.uint8)), hipmem.DevBuf(4096)\n"
+            "xc.allgather(src.ptr, dst.ptr, 4096, 0); ex.synchronize()\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l or 'libamdhip64' in l))\n"
+            "print('GATHER_OK' if np.array_equal(dst.to_numpy(np.uint8, 4096), np.arange(4096, dtype=np.uint8)) else 'GATHER_BAD', libs)\n"
+            "xc.close()\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if "GATHER_OK" in l][0]
+    assert line.count("librccl") == 1 and line.count("libamdhip64") == 1, "one ROCm stack in the process: " + line
+
+
 def test_probe_before_torch_does_not_kill_the_process_at_exit():
     """librccl is loaded RTLD_LOCAL: a process that asks the C library for RCCL BEFORE it imports PyTorch ends up with two copies of RCCL (PyTorch ships
-    its own); with RTLD_GLOBAL the first copy interposed on the second and the interpreter died in the static destructors at exit ('double free or
+    its own and loads it by path); with RTLD_GLOBAL the first copy interposed on the second and the interpreter died in the static destructors at exit ('double free or
     corruption', exit code 134 — which is how a green test run turned into a failed one)"""
     import subprocess
     import sys
