@@ -112,11 +112,18 @@ def one_case(rng, i):
     if STRESS and rng.random() < 0.4:           # parameters the reference never varies but the C ABI accepts: the cell edge (N_CELLS) and the FAST threshold
         cell = int(rng.choice([12, 16, 20, 25, 30, 37, 45, 62]))
         fth = int(rng.choice([0, 1, 3, 5, 7, 10, 15, 20, 25, 40, 63, 64, 100, 128, 200]))
+    taps = None
+    if STRESS and rng.random() < 0.15:          # blur taps other than OpenCV's {18,34,49,55,49,34,18}: byte-sized sets (the fast path, with and without saturation),
+        tk = int(rng.integers(0, 5))            # sets that overflow a byte or whose sum needs the saturating generic path, the identity, zeros
+        taps = [[16, 34, 50, 56, 50, 34, 16], [int(v) for v in rng.integers(0, 74, 7)], [int(v) for v in rng.integers(0, 1200, 7)],
+                [0, 0, 0, 256, 0, 0, 0], [255, 255, 255, 255, 255, 255, 255]][tk]
     desc = "case %d: %s %dx%d nfeat %d scale %.2f levels %d seed %d" % (i, kind, w, h, nfeat, scale, levels, seed)
     if (cell, fth) != (30, 20):
         desc += " cell %d threshold %d" % (cell, fth)
+    if taps is not None:
+        desc += " taps %s" % taps
     try:
-        ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels, N_CELLS=cell), fast_threshold=fth)
+        ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels, N_CELLS=cell), blur_taps=taps, fast_threshold=fth)
     except Exception as e:                      # configuration the library refuses (too many levels for the size etc.): must be refused cleanly
         return desc + "  -> refused at create: %s" % str(e)[:60], True
     img = make_image(rng, kind, w, h, seed)
@@ -133,6 +140,9 @@ def one_case(rng, i):
         return desc + "  -> refused at extract: %s" % str(e)[:80], True
     p = oracle.default_params(nfeat, scale, levels)
     p.cell_px, p.fast_threshold = cell, fth
+    if taps is not None:
+        for j, tv in enumerate(taps):
+            p.blur_taps[j] = tv
     big = 4 * nfeat + 64 * levels + 1024         # small quotas overshoot: a breadth-first pass quadruples the list before the size is checked
     ok, od = oracle.extract(p, np.ascontiguousarray(img), cap=big)
     good = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and np.array_equal(gd, od)
