@@ -31,3 +31,31 @@ def test_fuzz_matchers(gpu):
     for i in range(40):
         msg, good = fuzz_matchers.one_case(rng, i, ex)
         assert good, msg
+
+
+def test_fuzz_stress_slice(gpu):
+    """a slice of the stress mode (round 4): big / saturated / banded frames, tiny and huge quotas, cell edge, FAST threshold and blur taps drawn at random,
+    several frames per call, the stereo front end through the ingest tickets on 1-17 pairs, the same handle reused on other sizes and content"""
+    import fuzz_parity
+    fuzz_parity.STRESS = True
+    try:
+        rng = np.random.default_rng(20261005)
+        compared = extras = 0
+        for i in range(60):
+            msg, good = fuzz_parity.one_case(rng, i)
+            assert good, msg
+            compared += "keypoints ok" in msg
+            extras += ("batch of" in msg) + ("front end" in msg) + ("handle reused" in msg)
+        assert compared >= 35 and extras >= 10
+    finally:
+        fuzz_parity.STRESS = False
+
+
+def test_fuzz_frame_records(gpu):
+    """config 5's device path on random shapes: 1-8 frame records of random capacity and counts, 2-NN and vocabulary-grouped match of a random rank vs every peer"""
+    import fuzz_matchers
+    rng = np.random.default_rng(20261006)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500))
+    for i in range(40):
+        msg, good = fuzz_matchers.records_case(rng, i, ex)
+        assert good, msg
