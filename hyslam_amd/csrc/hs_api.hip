@@ -319,8 +319,10 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         HIP_TRY(h, hipMemcpy(h->d_fast_qt, fq.data(), sizeof(HsFastQt) * L, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMalloc(&h->d_qhist, std::max<size_t>((size_t)hoff * batch * 4, 256)));
         HIP_TRY(h, hipMalloc(&h->d_qbest, std::max<size_t>((size_t)boff * batch * 8, 256)));
-        HIP_TRY(h, hipMemset(h->d_qhist, 0, std::max<size_t>((size_t)hoff * batch * 4, 256)));
-        HIP_TRY(h, hipMemset(h->d_qbest, 0, std::max<size_t>((size_t)boff * batch * 8, 256)));
+        // (on the handle's stream: hipMemset on device memory is asynchronous to the host and runs on the NULL stream, which the handle's non-blocking
+        //  streams are not ordered with — a memset that lands after the first kernels would wipe what they wrote)
+        HIP_TRY(h, hipMemsetAsync(h->d_qhist, 0, std::max<size_t>((size_t)hoff * batch * 4, 256), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_qbest, 0, std::max<size_t>((size_t)boff * batch * 8, 256), h->stream));
     }
     {   // which level pairs the fused pyramid kernel can produce (decided on the host copies of the tables)
         std::vector<const int16_t*> xt(L, nullptr), yo(L, nullptr);
@@ -430,8 +432,9 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         HIP_TRY(h, upload_items(h->lv, items, &h->d_fast_items));
         if (h->fast_items_n > 0) HIP_TRY(h, upload_items(h->lv_n, h->fast_items_n, &h->d_fast_items_n));
         HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, std::max(items, h->fast_items_n) * batch, h->fast_knobs), 256)));
-        HIP_TRY(h, hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4));       // all four work-queue counter sets start at zero
+        HIP_TRY(h, hipMemsetAsync(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4, h->stream));       // all four work-queue counter sets start at zero (stream-ordered before the first launch)
     }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));     // the memsets above have landed whatever stream the caller's launches will use (configuration is rare: it allocates)
     h->w = w; h->h = hh; h->batch_cap = batch;      // configured only now
     return HS_OK;
 }
@@ -534,9 +537,10 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             (void)hipDeviceSynchronize();
-            (void)hipMemset(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4);
-            if (h->d_qhist) (void)hipMemset(h->d_qhist, 0, (size_t)h->qhist_stride * h->batch_cap * 4);      // a launch that died half-way may have left keys behind
-            if (h->d_qbest) (void)hipMemset(h->d_qbest, 0, (size_t)h->qbest_stride * h->batch_cap * 8);
+            (void)hipMemsetAsync(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4, h->stream);
+            if (h->d_qhist) (void)hipMemsetAsync(h->d_qhist, 0, (size_t)h->qhist_stride * h->batch_cap * 4, h->stream);      // a launch that died half-way may have left keys behind
+            if (h->d_qbest) (void)hipMemsetAsync(h->d_qbest, 0, (size_t)h->qbest_stride * h->batch_cap * 8, h->stream);
+            (void)hipStreamSynchronize(h->stream);
             return fail(h, HS_ERR_HIP, std::string("FAST launch: ") + hipGetErrorString(e));
         }
         if (launched) h->fast_epoch++;

@@ -39,7 +39,10 @@ class DevBuf:
         _ok(hip().hipMalloc(C.byref(p), self.nbytes), "hipMalloc")
         self.ptr = p.value
         if zero:
+            # hipMemset on device memory is ASYNCHRONOUS to the host and runs on the null stream; the library's streams are non-blocking, so a kernel launched
+            # right after could finish BEFORE the memset and have its results zeroed (seen once in ~50 000 fuzz cases as a "mismatch" of all-zero outputs)
             _ok(hip().hipMemset(self.ptr, 0, self.nbytes), "hipMemset")
+            _ok(hip().hipStreamSynchronize(None), "hipStreamSynchronize")
 
     @classmethod
     def from_numpy(cls, a):
@@ -60,6 +63,7 @@ class DevBuf:
 
     def fill(self, byte):
         _ok(hip().hipMemset(self.ptr, byte, self.nbytes), "hipMemset")
+        _ok(hip().hipStreamSynchronize(None), "hipStreamSynchronize")
 
     def free(self):
         if self.ptr:

@@ -152,7 +152,15 @@ def records_case(rng, i, ex):
         if peer == rank or nq == 0 or len(feats[peer][0]) == 0:
             continue
         obi, obd, osd = oracle.hamming_knn2(feats[rank][1], feats[peer][1])
-        good = good and np.array_equal(bi[peer, :nq], obi) and np.array_equal(bd[peer, :nq], obd) and np.array_equal(sd[peer, :nq], osd)
+        same = np.array_equal(bi[peer, :nq], obi) and np.array_equal(bd[peer, :nq], obd) and np.array_equal(sd[peer, :nq], osd)
+        if not same:                                            # which query, what both sides say (and what a plain numpy scan says)
+            q = int(np.nonzero((bi[peer, :nq] != obi) | (bd[peer, :nq] != obd) | (sd[peer, :nq] != osd))[0][0])
+            dist = np.unpackbits(feats[rank][1][q][None, :] ^ feats[peer][1], axis=1).sum(1)
+            order = np.argsort(dist, kind="stable")
+            desc += " [peer %d query %d: gpu (%d, %d, %d) oracle (%d, %d, %d) numpy best %d at %d second %d; %d differing queries]" % (
+                peer, q, bi[peer, q], bd[peer, q], sd[peer, q], obi[q], obd[q], osd[q], dist[order[0]], order[0], dist[order[1]] if len(order) > 1 else -1,
+                int(((bi[peer, :nq] != obi) | (bd[peer, :nq] != obd) | (sd[peer, :nq] != osd)).sum()))
+        good = good and same
     res.append(("knn2", good))
     kk, LL = int(rng.choice([2, 4, 10])), int(rng.choice([2, 3, 4]))
     up = int(rng.integers(0, LL))
