@@ -125,10 +125,16 @@ int main(int argc, char** argv)
         CHECK(r >= 0); accepted += r; tried++;
     }
     for (int i = 0; i < n_geo; i++) {
+        // the tuning knobs that are PARSED (read once per handle): explicit pyramid plans incl. malformed ones, chain / deep-plan switches
+        static const char* const plans[] = { "3,4", "2,5", "1,2,3,1", "7", "9,9", "1,1,1,1,1,1,1", "", "a,b", "2,,3", "0,0,0", "2,2,2,2,2,2,2,2,2,2", "-3,4" };
+        if (i % 4 == 1) setenv("HS_PYRAMID_PLAN", plans[rnd(0, (int)(sizeof(plans) / sizeof(plans[0])) - 1)], 1); else unsetenv("HS_PYRAMID_PLAN");
+        if (i % 7 == 2) setenv("HS_PYRAMID_CHAIN", rnd(0, 1) ? "2" : "0", 1); else unsetenv("HS_PYRAMID_CHAIN");
+        if (i % 5 == 3) setenv("HS_PYRAMID_DEEP_MAX", rnd(0, 1) ? "0" : "100000", 1); else unsetenv("HS_PYRAMID_DEEP_MAX");
         const int w = rnd(1, 10) == 1 ? rnd(20, 120) : rnd(64, 2600), h = rnd(1, 10) == 1 ? rnd(20, 120) : rnd(64, 1600);
         const int r = geometry_case(w, h, rnd(20, 4000), 1.1f + 0.01f * (float)rnd(0, 90), rnd(1, 12), rnd(1, 8) == 1 ? rnd(8, 70) : 30, rnd(1, 5), (size_t)w * h < 1500000);
         CHECK(r >= 0); accepted += r; tried++;
     }
+    unsetenv("HS_PYRAMID_PLAN"); unsetenv("HS_PYRAMID_CHAIN"); unsetenv("HS_PYRAMID_DEEP_MAX");
     CHECK(accepted > tried / 2);
 
     // ---- a handle outliving its communicators: hs_orb_destroy and the last borrower's release race on two threads; exactly one of them frees
