@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Randomised extraction + stereo parity sweep: the HIP path against the oracle on random frame sizes, row strides, feature counts, scale
 factors, level counts and image statistics (structured scenes, noise, checkerboards that saturate FAST, nearly flat frames).
-Runs on the GPU box:  python3 tools/fuzz_parity.py --cases 300 --seed 1      (every case is printed; exit code 1 on the first mismatch)"""
+Runs on the GPU box:  python3 tools/fuzz_parity.py --cases 300 --seed 1      (every case is printed; exit code 1 on the first mismatch)
+
+--stress (round 4) shifts the draw to where capacity limits and batch-dependent paths live: frames up to 4000 x 3000, checkerboards / noise / clusters /
+frames whose texture sits in one or two bands, quotas of 20-120 and 3 000-12 000, the cell edge (12-62 px), the FAST threshold (0-200) and the blur taps
+drawn as well; in a share of the cases 2-4 frames per call, the stereo front end through the ingest tickets on 1-17 pairs, and the same handle reused
+on three more frames of other sizes and content.  A mismatch is diagnosed on the spot (repeatability, first differing stage per level through the
+debug taps, the differing records) and the frame is saved to gpurun_out/fuzz_mismatch.npz."""
 import argparse
 import os
 import sys
