@@ -60,6 +60,7 @@ struct hs_orb {
     uint32_t* d_qhist = nullptr; unsigned long long* d_qbest = nullptr; uint32_t qhist_stride = 0, qbest_stride = 0;
     int fast_keys_levels = HS_MAX_LEVELS;   // HS_FAST_KEYS_LEVELS (read once; tuning): only the levels 0 .. n-1 get keys
     int fast_keys_max_batch = 16;      // HS_FAST_KEYS_MAX_BATCH (read once): calls of more frames than this run without the keys (see run_extract)
+    bool keys_dirty = false;           // a keyed call was enqueued and did not reach its end (any error return of run_extract): d_qhist / d_qbest may hold stale keys -> zeroed before the next call
     bool fast_keys = true;             // HS_FAST_KEYS=0 (read once): the quadtree kernel gathers the candidates and computes the keys itself (the scheme until round 3)
     bool keep_points = false;          // hs_orb_set_debug(h, 1): the quadtree kernel also gathers the candidates into the dense point arrays (hs_orb_debug_candidates reads them)
     uint8_t* d_pyr_tabs = nullptr;     // tile / row records of the two-level pyramid kernel (hs_pyramid_build_tables)
@@ -137,7 +138,7 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_pyr_tabs); h->d_pyr_tabs = nullptr; h->pyr_fuse.clear(); h->pyr_chain.clear(); h->pyr_deep.clear();
     hipFree(h->d_qt_tabs); h->d_qt_tabs = nullptr;
     hipFree(h->d_qkeys); h->d_qkeys = nullptr; hipFree(h->d_fast_qt); h->d_fast_qt = nullptr;
-    hipFree(h->d_qhist); h->d_qhist = nullptr; hipFree(h->d_qbest); h->d_qbest = nullptr; h->qhist_stride = h->qbest_stride = 0;
+    hipFree(h->d_qhist); h->d_qhist = nullptr; hipFree(h->d_qbest); h->d_qbest = nullptr; h->qhist_stride = h->qbest_stride = 0; h->keys_dirty = false;
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_items_n); h->d_fast_items_n = nullptr; h->fast_items_n = 0;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
@@ -522,6 +523,16 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     // level-0 workgroup no longer gathers 5 000 records on one CU).  Both arrays are zero between calls whatever the mode, so the mode may change per call.
     const HsPyrChain* const deep = (batch <= h->deep_max_batch && !h->pyr_deep.empty()) ? h->pyr_deep.data() : nullptr;      // the pyramid's small-batch plan
     const bool use_keys = h->fast_keys && h->d_fast_qt != nullptr && batch <= h->fast_keys_max_batch;
+    // d_qhist / d_qbest are all zero between calls (the quadtree kernel zeroes what it consumes).  A call that fails anywhere between the keyed FAST
+    // launch and its end — an event / stream call of the split path, a later launch — breaks that: the flag makes the NEXT call start from zeroed arrays.
+    if (h->keys_dirty) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        if (h->d_qhist) HIP_TRY(h, hipMemsetAsync(h->d_qhist, 0, (size_t)h->qhist_stride * h->batch_cap * 4, s));
+        if (h->d_qbest) HIP_TRY(h, hipMemsetAsync(h->d_qbest, 0, (size_t)h->qbest_stride * h->batch_cap * 8, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        h->keys_dirty = false;
+    }
+    if (use_keys) h->keys_dirty = true;                          // cleared at the end of a call that enqueued everything without error
     const std::vector<HsLevel>& lvh = narrow ? h->lv_n : h->lv;
     const HsLevel* const d_lv = h->d_lv + (narrow ? L : 0);
     const HsFastItem* const d_items = narrow ? h->d_fast_items_n : h->d_fast_items;
@@ -582,6 +593,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
                        h->d_taps, out, s, h->fast_taps, sf ? *sf : HsStripFuse{});
     mark(h, -1, s);
     HIP_TRY(h, hipGetLastError());
+    h->keys_dirty = false;
     h->last_batch = batch; h->last_img0 = img0;
     return HS_OK;
 }

@@ -59,15 +59,17 @@ __device__ __forceinline__ int wave_append(bool flag, int& base)
 // Corner score of one polarity: cv::FAST's cornerScore<16> is max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1; for a corner of one
 // polarity the other polarity's term cannot exceed t (no 9-arc passes it) while its own term does, so score = max_arc min(d) - 1 with
 // d[k] = v - ring[k] (dark) or ring[k] - v (bright), and the pixel IS a corner of that polarity exactly when max_arc min(d) > t.
-// Three-input min / max: lo3[k] = min(d[k..k+2]), arc9[k] = min(lo3[k], lo3[k+3], lo3[k+6]), a max3 tree over the 16 arcs — 16 + 16 + 8
-// instructions after the 16 multiply-adds that make d with the per-lane sign (56 in all; the packed 16-bit network this replaces took 66
-// with its byte permutes, the two-input network of round 2 111).
+// Three-input min / max: lo3[k] = min(d[k..k+2]), arc9[k] = min(lo3[k], lo3[k+3], lo3[k+6]), a max3 tree over the 16 arcs — 16 + 16 + 8.
+// Round 5: the network runs on the RAW bytes.  min / max commute with subtracting a constant, so max_arc min(ring - v) = max_arc min(ring) - v,
+// and the dark polarity is the bright one on complemented bytes: v - ring = (255 - ring) - (255 - v) = (ring ^ 0xFF) - (v ^ 0xFF).  With the per-lane
+// mask m = 0 (bright) / 0xFF (dark) the 16 differences are 16 v_xor_b32 — a plain VOP2 op of the class this chip issues at up to 1.4-1.6 wave-
+// instructions per cycle and CU — instead of the 16 v_mad_i32_i24 of round 3 (VOP3: 0.85; profiles/r04_valu_issue_rates.txt), and one subtraction at the end.
 __device__ __forceinline__ int fast_corner_score3(const int (&r)[16], int v, bool bright)
 {
-    const int a = bright ? 1 : -1, b = bright ? -v : v;          // d = a * ring + b
+    const int m = bright ? 0 : 0xFF;
     int d[16], lo3[16], arc[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d[k]) : "v"(r[k]), "v"(a), "v"(b));   // as asm: the compiler turns r * a into a select of r and -r
+    for (int k = 0; k < 16; k++) asm("v_xor_b32 %0, %1, %2" : "=v"(d[k]) : "v"(m), "v"(r[k]));   // as asm: the compiler turns r ^ m into a select of r and ~r & 0xFF
     // (as asm as well: left to itself the compiler shares min(d[k+1], d[k+2]) between neighbours and ends up with 32 two-input minima)
     auto min3 = [](int x, int y, int z) { int o; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
     auto max3 = [](int x, int y, int z) { int o; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
@@ -75,11 +77,11 @@ __device__ __forceinline__ int fast_corner_score3(const int (&r)[16], int v, boo
     for (int k = 0; k < 16; k++) lo3[k] = min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
 #pragma unroll
     for (int k = 0; k < 16; k++) arc[k] = min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-    int m[6];
+    int m6[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) m[k] = max3(arc[3 * k], arc[3 * k + 1], arc[3 * k + 2]);
-    m[5] = arc[15];
-    return max(max3(m[0], m[1], m[2]), max3(m[3], m[4], m[5])) - 1;
+    for (int k = 0; k < 5; k++) m6[k] = max3(arc[3 * k], arc[3 * k + 1], arc[3 * k + 2]);
+    m6[5] = arc[15];
+    return max(max3(m6[0], m6[1], m6[2]), max3(m6[3], m6[4], m6[5])) - (v ^ m) - 1;
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -246,7 +248,10 @@ __device__ __forceinline__ int wave_scan_incl(int x)
 }
 
 // TR = tile rows held in LDS (6 + 8*RS*blocks); the item's tile (th <= TR rows) is fetched with 16-byte loads, 64/LPR rows per load
-template <int LC, int TR>
+// KEYS: the quadtree's geometric keys are produced by this launch (calls of <= 16 frames: hs_api.hip).  A template parameter, not a runtime
+// flag: the large-batch instantiation pays neither registers nor instructions for a path it never runs (round 4 carried it as a runtime
+// flag: 139 -> 147 VGPRs and +1 M wave-instructions per 32 frames for nothing).
+template <int LC, int TR, bool KEYS>
 __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         uint32_t kx0 = 0, kx1 = 0, ky0 = 0;
         bool keys_on = false;
         uint32_t* khist = nullptr; unsigned long long* kbest = nullptr;
-        if (qt != nullptr) {
+        if constexpr (KEYS) {
             typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
             const HsFastQt Q = __builtin_bit_cast(HsFastQt, hs_cload<u32x8>(qt + cur.level));      // one s_load_dwordx8
             keys_on = Q.enabled != 0;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 const int gc = ((sc - 1) * inv_w1) >> 16;
                 const int px = sc - 1 - gc;                      // interior column within the item
                 uint32_t gk = 0;
-                if (keys_on) {                                   // (wave-uniform; every lane takes part in the permutes: inactive lanes read lane 0)
+                if (KEYS && keys_on) {                           // (wave-uniform; every lane takes part in the permutes: inactive lanes read lane 0)
                     const int pxc = act ? px : 0, ryc = act ? r - 1 : 0;
                     uint32_t vx = (uint32_t)__builtin_amdgcn_ds_bpermute(((pxc & 127) >> 1) << 2, (int)kx0);
                     if (COLS > 32) { const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((pxc & 127) >> 1) << 2, (int)kx1); if (pxc >= 128) vx = v1; }
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 if (keep) {
                     const uint32_t xy = ((uint32_t)(r - 1 + 3 + cur.yoff) << 16) | (uint32_t)(px + 3 + cur.xoff), sk = ((uint32_t)s << 24) | (uint32_t)(cur.c0 + gc);
                     cand[slot_base + (size_t)slot] = make_uint2(xy, sk);
-                    if (keys_on) {
+                    if (KEYS && keys_on) {
                         // k_quadtree's `offer`: maximum response, first in (cell, y, x) order on ties (ORBExtractor.cpp:381-400)
                         const unsigned long long order = ((unsigned long long)(sk & 0xFFFFFFu) << 32) | xy;
                         const unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
@@ -888,12 +893,14 @@ static bool launch_fast_rows(const HsFastItem* d_items, HsImg0 img0, int batch, 
     const int force_scan_b = knobs.force_scan_b;
     const FastSched S = fast_sched(batch, items_per_img, knobs, nblk);
     const uint32_t spill_base = (uint32_t)spill_slot * (uint32_t)fast_rows_grid(c, items_all * batch) * c.ovf_stride;      // the second spill half starts after a full-size first one
-#define FR_LAUNCH(LC_, TR_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
+#define FR_LAUNCH_K(LC_, TR_, K_) hipLaunchKernelGGL((k_fast_rows<LC_, TR_, K_>), dim3(nblk), dim3(64), L.total, s, d_items, img0, fast_th, cand, \
                                                cell_count, cand_img_stride, total_cells, items_per_img, total_work, L, force_scan_b, overflow, c.ovf_stride, epoch, item_first, spill_base, S, \
                                                d_qt, qhist, qbest, qhist_img_stride, qbest_img_stride)
+#define FR_LAUNCH(LC_, TR_) do { if (d_qt != nullptr) FR_LAUNCH_K(LC_, TR_, true); else FR_LAUNCH_K(LC_, TR_, false); } while (0)
     if (lc == 6) { if (tr == 38) FR_LAUNCH(6, 38); else if (tr == 40) FR_LAUNCH(6, 40); else if (tr == 44) FR_LAUNCH(6, 44); else if (tr == 54) FR_LAUNCH(6, 54); else if (tr == 70) FR_LAUNCH(6, 70); else if (tr == 102) FR_LAUNCH(6, 102); else FR_LAUNCH(6, 134); }
     else         { if (tr == 38) FR_LAUNCH(5, 38); else if (tr == 40) FR_LAUNCH(5, 40); else if (tr == 44) FR_LAUNCH(5, 44); else if (tr == 54) FR_LAUNCH(5, 54); else if (tr == 70) FR_LAUNCH(5, 70); else if (tr == 102) FR_LAUNCH(5, 102); else FR_LAUNCH(5, 134); }
 #undef FR_LAUNCH
+#undef FR_LAUNCH_K
     return true;
 }
 
