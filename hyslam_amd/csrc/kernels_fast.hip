@@ -84,6 +84,30 @@ __device__ __forceinline__ int fast_corner_score3(const int (&r)[16], int v, boo
     return max(max3(m6[0], m6[1], m6[2]), max3(m6[3], m6[4], m6[5])) - (v ^ m) - 1;
 }
 
+// TWO candidates per lane (round 5): gfx950 has a packed three-input minimum / maximum, but only for f16 (v_pk_minimum3_f16 / v_pk_maximum3_f16).
+// A byte b under the bit pattern 0x6400 | b IS the f16 number 1024 + b (exponent 2^10, mantissa step 1): exact, ordered like b, never a NaN or a
+// denormal — so the score network above runs on (candidate A, candidate B) pairs of such halves with the same 40 instructions one candidate needed.
+// P[k] = ring_A[k] | ring_B[k] << 16 (bytes); mx = polarity masks (0 / 0xFF per half, as in fast_corner_score3) | 0x64006400: one v_xor_b32 per
+// ring position complements AND biases both halves.  Returns the two halves 0x6400 + max_arc min(ring ^ m).
+__device__ __forceinline__ uint32_t fast_arc_max_pk(const uint32_t (&P)[16], uint32_t mx)
+{
+    uint32_t d[16], lo3[16], arc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) asm("v_xor_b32 %0, %1, %2" : "=v"(d[k]) : "v"(mx), "v"(P[k]));
+    auto min3 = [](uint32_t x, uint32_t y, uint32_t z) { uint32_t o; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
+    auto max3 = [](uint32_t x, uint32_t y, uint32_t z) { uint32_t o; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(y), "v"(z)); return o; };
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo3[k] = min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) arc[k] = min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    uint32_t m6[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) m6[k] = max3(arc[3 * k], arc[3 * k + 1], arc[3 * k + 2]);
+    m6[5] = arc[15];
+    const uint32_t a = max3(m6[0], m6[1], m6[2]);
+    return max3(a, m6[3], max3(m6[4], m6[5], m6[5]));
+}
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
 __device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
@@ -447,51 +471,72 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #endif
             int n_corner = n_done;
             int nend = npx;                                  // list end including the re-queued pixels (below)
-            for (int i0 = n_done; i0 < nend; i0 += 64) {
-                const int i = i0 + tid;
-                const bool act = i < nend;
-                const int code = plist[act ? i : 0];
-                const bool redo_dark = code & 0x8000;       // re-queued: passed both compass tests and is no bright corner
-                const int eb = code & 31, ew = (code >> 5) & 63;                 // bit of the scan mask (8 * pixel + row), lane that held the word
-                const int el = (ew & 48) | ((ew - ((code & 24) >> 1)) & 15);     // lane that found it: byte j sits 4 j lanes up in its row of 16
-                const int py = BR * (RS * ((code >> 11) & 15) + (el >> LC)) + (eb & 7);
-                const int px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
-                const uint8_t* ctr = &tile[(py + 3) * PITCH + c_first + px];
-                const int v = ctr[0];
-                const int lo = v - t, hi = v + t;
-                int r[16];
+            // Two candidates per lane and iteration: A = entry i0 + lane, B = entry i0 + 64 + lane (neighbouring lanes keep neighbouring entries: the
+            // ring reads of a wave-instruction stay spatially close).  Decoding, ring reads and the exact compass test are per candidate; the score
+            // network — 40 of the ~110 instructions a candidate cost — serves both (fast_arc_max_pk).
+            for (int i0 = n_done; i0 < nend; i0 += 128) {
+                const int iA = i0 + tid, iB = iA + 64;
+                const bool actA = iA < nend, actB = iB < nend;
+                const int codeA = plist[actA ? iA : 0], codeB = plist[actB ? iB : 0];
+                int pyA, pxA, pyB, pxB;
+                auto decode = [&](int code, int& py, int& px) {
+                    const int eb = code & 31, ew = (code >> 5) & 63;                 // bit of the scan mask (8 * pixel + row), lane that held the word
+                    const int el = (ew & 48) | ((ew - ((code & 24) >> 1)) & 15);     // lane that found it: byte j sits 4 j lanes up in its row of 16
+                    py = BR * (RS * ((code >> 11) & 15) + (el >> LC)) + (eb & 7);
+                    px = 4 * (el & (COLS - 1)) + (eb >> 3) - c_first;
+                };
+                decode(codeA, pyA, pxA); decode(codeB, pyB, pxB);
+                const bool redo_darkA = codeA & 0x8000, redo_darkB = codeB & 0x8000;   // re-queued: passed both compass tests and is no bright corner
+                const uint8_t* ctrA = &tile[(pyA + 3) * PITCH + c_first + pxA];
+                const uint8_t* ctrB = &tile[(pyB + 3) * PITCH + c_first + pxB];
+                const int vA = ctrA[0], vB = ctrB[0];
+                int rA[16], rB[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) r[k] = ctr[RO[k]];
+                for (int k = 0; k < 16; k++) { rA[k] = ctrA[RO[k]]; rB[k] = ctrB[RO[k]]; }
                 // ONE polarity per pixel, and the corner SCORE as the segment test.  A 9-arc contains two adjacent compass points (ring 0, 4,
                 // 8, 12), so a dark corner passes the exact compass test "(r0 or r8 darker) and (r4 or r12 darker)" and a bright corner its
                 // mirror image; the pixel goes through the score network of the polarity that can still succeed: it is a corner of that
-                // polarity exactly when max_arc min(d) > t, i.e. score >= t (cornerScore's own definition) — 56 instructions that yield the
-                // decision AND the score, instead of a segment test of both polarities (82) followed by a second pass over the corners
-                // (decode, 17 ring reads and a score network for ~40 % of the pixels).
-                const bool dark_ok = max(min(r[0], r[8]), min(r[4], r[12])) < lo, bright_ok = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
-                const bool bright = bright_ok && !redo_dark;
-                int sc = fast_corner_score3(r, v, bright);
-                bool corner = sc >= t && act && (dark_ok || bright_ok);
+                // polarity exactly when max_arc min(d) > t, i.e. score >= t (cornerScore's own definition).
+                const bool dark_okA = max(min(rA[0], rA[8]), min(rA[4], rA[12])) < vA - t, bright_okA = min(max(rA[0], rA[8]), max(rA[4], rA[12])) > vA + t;
+                const bool dark_okB = max(min(rB[0], rB[8]), min(rB[4], rB[12])) < vB - t, bright_okB = min(max(rB[0], rB[8]), max(rB[4], rB[12])) > vB + t;
+                const bool brightA = bright_okA && !redo_darkA, brightB = bright_okB && !redo_darkB;
+                uint32_t P[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) P[k] = (uint32_t)rA[k] | ((uint32_t)rB[k] << 16);
+                const int mA = brightA ? 0 : 0xFF, mB = brightB ? 0 : 0xFF;
+                const uint32_t R = fast_arc_max_pk(P, 0x64006400u | (uint32_t)mA | ((uint32_t)mB << 16));
+                int scA = (int)(R & 0x3FFu) - (vA ^ mA) - 1, scB = (int)((R >> 16) & 0x3FFu) - (vB ^ mB) - 1;
+                bool cornerA = scA >= t && actA && (dark_okA || bright_okA), cornerB = scB >= t && actB && (dark_okB || bright_okB);
                 // Pixels that pass BOTH compass tests (6-8 % of the candidates on the reduced levels, 0.1 % on level 0) and are no bright
                 // corner need the dark test as well: they go back to the END of the list with bit 15 set and fill the lanes of the last,
                 // partly empty iteration (running the second test in place would double the cost of nearly every iteration).  The last
                 // iteration itself (whose lanes already cover the list end) and a full list run the second test in place.
-                const bool redo = act && dark_ok && bright_ok && !corner && !redo_dark;
-                if (__any(redo)) {
-                    if (i0 + 64 < nend && nend + 64 <= lds.pcap) {
-                        const int slot = wave_append(redo, nend);
-                        if (redo) plist[slot] = (uint16_t)(code | 0x8000);
+                const bool redoA = actA && dark_okA && bright_okA && !cornerA && !redo_darkA, redoB = actB && dark_okB && bright_okB && !cornerB && !redo_darkB;
+                if (__any(redoA || redoB)) {
+                    if (i0 + 128 < nend && nend + 128 <= lds.pcap) {
+                        const int slotA = wave_append(redoA, nend);
+                        if (redoA) plist[slotA] = (uint16_t)(codeA | 0x8000);
+                        const int slotB = wave_append(redoB, nend);
+                        if (redoB) plist[slotB] = (uint16_t)(codeB | 0x8000);
                     } else {
-                        const int sc2 = fast_corner_score3(r, v, false);
-                        if (redo && sc2 >= t) { corner = true; sc = sc2; }
+                        const uint32_t R2 = fast_arc_max_pk(P, 0x64FF64FFu);
+                        const int s2A = (int)(R2 & 0x3FFu) - (vA ^ 0xFF) - 1, s2B = (int)((R2 >> 16) & 0x3FFu) - (vB ^ 0xFF) - 1;
+                        if (redoA && s2A >= t) { cornerA = true; scA = s2A; }
+                        if (redoB && s2B >= t) { cornerB = true; scB = s2B; }
                     }
                 }
                 FR_FENCE();                                // this iteration's reads precede the in-place compaction writes
-                const int slot = wave_append(corner, n_corner);
-                if (corner) {
-                    const int gc = (px * inv_w) >> 16;           // cell of the item; its columns start at 1 + gc*(wcell+1)
-                    plist[slot] = (uint16_t)(((py + 1) << 8) | (1 + px + gc));     // score tile coordinates: what nms_and_emit reads
-                    pscore[slot] = (uint8_t)sc;
+                const int slotA = wave_append(cornerA, n_corner);
+                if (cornerA) {
+                    const int gc = (pxA * inv_w) >> 16;          // cell of the item; its columns start at 1 + gc*(wcell+1)
+                    plist[slotA] = (uint16_t)(((pyA + 1) << 8) | (1 + pxA + gc));     // score tile coordinates: what nms_and_emit reads
+                    pscore[slotA] = (uint8_t)scA;
+                }
+                const int slotB = wave_append(cornerB, n_corner);
+                if (cornerB) {
+                    const int gc = (pxB * inv_w) >> 16;
+                    plist[slotB] = (uint16_t)(((pyB + 1) << 8) | (1 + pxB + gc));
+                    pscore[slotB] = (uint8_t)scB;
                 }
             }
             FR_FENCE();

@@ -15,8 +15,9 @@
 //            landmarks are passed SORTED BY ADDRESS, which reproduces the iteration order of the reference's std::map<MapPoint*, ...>
 //            (FeatureMatcher.cc:64,113-118; deviation D6 of DESIGN.md)
 //   search   one C-ABI call (GPU)
-//   replay   Frame::associateLandMark(idx, lm, true) for every match, in that same address order (FeatureMatcher.cc:113-118) — a later
-//            landmark that picked the same keypoint overwrites the earlier one, exactly as in the reference.
+//   replay   Frame::associateLandMark(idx, lm, true) in that same address order (FeatureMatcher.cc:113-118) — a later landmark that picked the same
+//            keypoint overwrites the earlier one, exactly as in the reference — but only the calls that matter: HipAssociationReplay.h plans the
+//            shortest subsequence that leaves views_to_landmarks, outliers and n_matches as the full loop would (checked on a model per call).
 // Overridden: all twelve search entry points of FeatureMatcher (src/features/FeatureMatcher.h:114-150) — the four SearchByProjection overloads,
 // SearchByBoW(KF, Frame), SearchByBoW(KF, KF) (legacy: no call site in hySLAM, "aim to replace this with SearchByBoW2", FeatureMatcher.cc:939),
 // SearchByBoW2, SearchForTriangulation, SearchForInitialization, Fuse(pKF, points, ...), Fuse(pKF, Scw, ...) (an empty body in the reference,
@@ -31,13 +32,16 @@
 #include "cv_compat.h"
 #endif
 #include <algorithm>
+#include <future>
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../include/hyslam_amd.h"
 #include "HipORBExtractor.h"
+#include "HipAssociationReplay.h"
 
 namespace HYSLAM {
 
@@ -212,6 +216,7 @@ public:
 
     hs_orb* handle() const { return h; }
     HipCallTiming timing;             // of the last SearchByProjection(Frame...) / Fuse / key-frame BoW call (HipORBExtractor.h)
+    size_t replay_calls = 0, replay_full = 0; int replay_rule = 0;      // of the last SearchByProjection(Frame...): associateLandMark calls made / of the reference's loop
 
 private:
     struct Views { std::vector<hs_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> uR; };
@@ -279,21 +284,34 @@ private:
         for (const auto& kv : F.getLandMarkMatches()) assoc.insert({ kv.second, kv.first });                 // ascending view index: the first view wins, like the scan
         if (prev) for (const auto& kv : const_cast<Frame*>(prev)->getLandMarkMatches()) assoc_prev.insert({ kv.second, kv.first });
         std::vector<hs_landmark> out(std::max<size_t>(lms.size(), 1));
-        for (size_t i = 0; i < lms.size(); i++) {
-            hs_landmark& L = out[i]; std::memset(&L, 0, sizeof(L));
-            MapPoint* lm = lms[i];
-            L.assoc_kp = -1;
-            if (!lm) { L.skip = 1; continue; }
-            const cv::Mat P = lm->GetWorldPos(), Nn = lm->GetNormal();
-            for (int k = 0; k < 3; k++) { L.pos[k] = P.at<float>(k); L.normal[k] = Nn.at<float>(k); }
-            L.size = lm->getSize();
-            L.min_dist = lm->GetMinDistanceInvariance(); L.max_dist = lm->GetMaxDistanceInvariance();         // with dist_is_invariance_range = 1
-            auto it = assoc.find(lm);
-            if (it != assoc.end()) L.assoc_kp = it->second;
-            if (prev) { auto ip = assoc_prev.find(lm); if (ip != assoc_prev.end()) L.prev_angle = prev->getViews().keypt(ip->second).angle; }
-            const cv::Mat row = lm->GetDescriptor().rawDescriptor();
-            std::memcpy(L.desc, row.ptr(0), HS_DESC_BYTES);
-        }
+        auto fill = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                hs_landmark& L = out[i]; std::memset(&L, 0, sizeof(L));
+                MapPoint* lm = lms[i];
+                L.assoc_kp = -1;
+                if (!lm) { L.skip = 1; continue; }
+                const cv::Mat P = lm->GetWorldPos(), Nn = lm->GetNormal();
+                for (int k = 0; k < 3; k++) { L.pos[k] = P.at<float>(k); L.normal[k] = Nn.at<float>(k); }
+                L.size = lm->getSize();
+                L.min_dist = lm->GetMinDistanceInvariance(); L.max_dist = lm->GetMaxDistanceInvariance();         // with dist_is_invariance_range = 1
+                auto it = assoc.find(lm);
+                if (it != assoc.end()) L.assoc_kp = it->second;
+                if (prev) { auto ip = assoc_prev.find(lm); if (ip != assoc_prev.end()) L.prev_angle = prev->getViews().keypt(ip->second).angle; }
+                const cv::Mat row = lm->GetDescriptor().rawDescriptor();
+                std::memcpy(L.desc, row.ptr(0), HS_DESC_BYTES);
+            }
+        };
+        // Three clones per landmark (GetWorldPos / GetNormal / GetDescriptor().rawDescriptor(): the only accessors MapPoint offers, each under the
+        // MapPoint's own mutex — Tracking and Mapping already call them concurrently): 5.2 ms for TrackLocalMap's 50 000 landmarks on one thread.
+        // Disjoint slices of the output on helper threads; the two maps are only read.
+        const size_t n = lms.size();
+        unsigned workers = n >= 8192 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u) : 1u;
+        if (workers <= 1) { fill(0, n); return out; }
+        std::vector<std::future<void>> helpers;
+        const size_t chunk = (n + workers - 1) / workers;
+        for (unsigned w = 1; w < workers; w++) helpers.push_back(std::async(std::launch::async, fill, std::min(n, w * chunk), std::min(n, (w + 1) * chunk)));
+        fill(0, std::min(n, chunk));
+        for (auto& f : helpers) f.get();
         return out;
     }
     // _SearchByBoW_ between two key frames (FeatureMatcher.cc:281-345): the index criteria apply to BOTH sides (:306-309).
@@ -328,10 +346,16 @@ private:
         // address order == iteration order of the reference's std::map<MapPoint*, SingleMatchData> (FeatureMatcher.cc:64); duplicates collapse like map keys
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<MapPoint*> lms;
-        lms.reserve(landmarks.size());
-        for (MapPoint* p : landmarks) if (p) lms.push_back(p);
-        std::sort(lms.begin(), lms.end());
-        lms.erase(std::unique(lms.begin(), lms.end()), lms.end());
+        // TrackLocalMap hands over the contents of a std::set<MapPoint*> (TrackLocalMap.cpp:73): already ascending and unique — one pass instead of a sort
+        bool ascending = true;
+        for (size_t i = 0; i < landmarks.size() && ascending; i++) ascending = landmarks[i] != nullptr && (i == 0 || landmarks[i - 1] < landmarks[i]);
+        if (ascending) lms = landmarks;
+        else {
+            lms.reserve(landmarks.size());
+            for (MapPoint* p : landmarks) if (p) lms.push_back(p);
+            std::sort(lms.begin(), lms.end());
+            lms.erase(std::unique(lms.begin(), lms.end()), lms.end());
+        }
         if (lms.empty()) return 0;
         FrameArrays fa; hs_frame_view V = gather_frame(F, fa);
         std::vector<hs_landmark> L = gather_landmarks(lms, F, prev);
@@ -341,8 +365,9 @@ private:
         check(hs_search_by_projection(h, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n), "SearchByProjection");
         timing.abi_ms = hip_detail::ms_since(t1);
         const auto t2 = std::chrono::steady_clock::now();
-        for (size_t i = 0; i < lms.size(); i++)          // replay, FeatureMatcher.cc:113-118
-            if (midx[i] >= 0) F.associateLandMark(midx[i], lms[i], true);
+        // replay (FeatureMatcher.cc:113-118): the calls that decide the frame's final LandMarkMatches, in address order (HipAssociationReplay.h)
+        const hip_detail::ReplayPlan plan = hip_detail::replay_associations(F, lms, midx);
+        replay_calls = plan.ops.size(); replay_full = plan.full_ops; replay_rule = plan.rule;
         timing.scatter_ms = hip_detail::ms_since(t2);
         return n;
     }
@@ -369,6 +394,7 @@ public:
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint) override { return core.Fuse(pKF, Scw, vpPoints, th, vpReplacePoint); }
     int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th) override { return core.SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th); }
     hs_orb* handle() const { return core.handle(); }
+    const HipMatcherCore& matcherCore() const { return core; }      // replay_calls / replay_full / replay_rule of the last projection search
 private:
     HipMatcherCore core;
 public:

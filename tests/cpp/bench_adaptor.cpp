@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <set>
 #include <thread>
 #include <vector>
 #include "../../hyslam_amd/host/HipORBFactory.h"
@@ -138,16 +139,22 @@ int main(int argc, char** argv)
         m->mDescriptor = FeatureDescriptor(row, dist);
         lms[j] = m;
     }
-    std::vector<double> p_total, p_gather, p_abi, p_scatter; int n_proj = 0;
+    // TrackLocalMap keeps its local map in a std::set<MapPoint*> and hands the matcher a vector built from it (TrackLocalMap.cpp:73): address order
+    std::set<MapPoint*> local_map_points(lms.begin(), lms.end());
+    local_map_points.erase(static_cast<MapPoint*>(nullptr));
+    const std::vector<MapPoint*> v_lmp(local_map_points.begin(), local_map_points.end());
+    std::vector<double> p_total, p_gather, p_abi, p_scatter; int n_proj = 0; size_t replay_calls = 0, replay_full = 0; int replay_rule = -1;
     for (int r = 0; r < std::max(reps / 3, 5) + 2; r++) {
         Frame F(last_views, cam); F.SetPose(Tcw);
         const auto t0 = clk::now();
         std::unique_ptr<FeatureMatcher> matcher = factory->getFeatureMatcher();          // TrackLocalMap.cpp:72
-        n_proj = matcher->SearchByProjection(F, lms, 5.f);
+        n_proj = matcher->SearchByProjection(F, v_lmp, 5.f);
         const auto t1 = clk::now();
         if (r >= 2) {
             const HipCallTiming& t = static_cast<HipFeatureMatcher*>(matcher.get())->timing;
             p_total.push_back(ms(t0, t1)); p_gather.push_back(t.gather_ms); p_abi.push_back(t.abi_ms); p_scatter.push_back(t.scatter_ms);
+            const HipMatcherCore& core = static_cast<HipFeatureMatcher*>(matcher.get())->matcherCore();
+            replay_calls = core.replay_calls; replay_full = core.replay_full; replay_rule = core.replay_rule;
         }
     }
     // ---- LandMarkTriangulator: two key frames with hashed feature vectors (a stand-in for DBoW2's, ~100 nodes like level 2 of ORBvoc on 2000 features)
@@ -171,9 +178,9 @@ int main(int argc, char** argv)
            " \"HipStereoFrontend_ms\": {\"process_total\": %.3f, \"submit_plus_wait\": %.3f, \"FeatureViews_build\": %.3f, \"pipelined_per_pair\": %.3f},\n"
            " \"ProcessStereoImage_ms\": {\"total\": %.3f, \"extract_LR_threads\": %.3f, \"extract_c_abi\": %.3f, \"extract_scatter\": %.3f, \"FeatureViews_ctor\": %.3f,"
            " \"stereo_gather\": %.3f, \"stereo_c_abi\": %.3f, \"getData\": %.3f},\n"
-           " \"TrackLocalMap_SearchByProjection_ms\": {\"landmarks\": %d, \"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f, \"scatter\": %.3f},\n"
+           " \"TrackLocalMap_SearchByProjection_ms\": {\"landmarks\": %d, \"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f, \"scatter\": %.3f, \"associateLandMark_calls\": %zu, \"of_full_replay\": %zu, \"replay_rule\": %d},\n"
            " \"SearchForTriangulation_ms\": {\"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f}}\n",
            w, h, n_kp, n_stereo, reps, median(f_total), median(f_abi), median(f_scatter), median(f_pipe), median(t_total), median(t_extract), median(t_exL_abi), median(t_exL_scatter), median(t_views), median(t_sm_gather), median(t_sm_abi),
-           median(t_getdata), n_lm, n_proj, median(p_total), median(p_gather), median(p_abi), median(p_scatter), n_tri, median(q_total), median(q_gather), median(q_abi));
+           median(t_getdata), n_lm, n_proj, median(p_total), median(p_gather), median(p_abi), median(p_scatter), replay_calls, replay_full, replay_rule, n_tri, median(q_total), median(q_gather), median(q_abi));
     return 0;
 }

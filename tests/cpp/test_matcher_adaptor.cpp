@@ -197,6 +197,7 @@ int main(int argc, char** argv)
         const int n_got = matcher->SearchByProjection(F, lm, 5.f);
         if (n_got != n_want || n_want < 50) FAIL(10, "local map: %d matches, expected %d", n_got, n_want);
         if (F.getLandMarkMatches().views_to_landmarks != want.views_to_landmarks) FAIL(11, "local map: associations differ after the replay");
+        if (F.getLandMarkMatches().outliers != want.outliers || F.getLandMarkMatches().n_matches != want.n_matches) FAIL(11, "local map: outliers / n_matches differ after the (planned) replay");
         total_matches += n_got;
     }
     // ---- TrackMotionModel variant: the previous frame holds one keypoint per landmark whose angle is the record's prev_angle
@@ -212,6 +213,7 @@ int main(int argc, char** argv)
         const int n_got = matcher->SearchByProjection(F, Last, 7.f, false);
         if (n_got != n_want || n_want < 50) FAIL(12, "last frame: %d matches, expected %d", n_got, n_want);
         if (F.getLandMarkMatches().views_to_landmarks != want.views_to_landmarks) FAIL(13, "last frame: associations differ after the replay");
+        if (F.getLandMarkMatches().outliers != want.outliers || F.getLandMarkMatches().n_matches != want.n_matches) FAIL(13, "last frame: outliers / n_matches differ after the (planned) replay");
         total_matches += n_got;
     }
     // ---- Fuse on a KeyFrame: vector order, first landmark per keypoint wins, pre-screen of bad / protected / already-observed landmarks

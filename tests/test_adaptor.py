@@ -77,6 +77,21 @@ def run_bench(w=640, h=480, reps=6, n_lm=5000):
     return subprocess.run([EXE_B, str(w), str(h), fl, fr, str(reps), str(n_lm)], capture_output=True, timeout=900)
 
 
+def test_planned_association_replay_equals_the_reference_loop():
+    """hyslam_amd/host/HipAssociationReplay.h: the subsequence of Frame::associateLandMark calls the matcher adaptor makes after a projection search
+    leaves views_to_landmarks, outliers AND n_matches exactly as the reference's loop over every match does (FeatureMatcher.cc:113-118,
+    LandMarkMatches.cpp:26-51) — 3 000 randomised frames (stale outliers entries, landmarks on several views, landmarks that move, fresh frames) +
+    BASELINE config 4's shape (14 000 matches onto 2 000 views -> one call per view).  Host only, under ASan + UBSan."""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "test_replay")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           os.path.join(ROOT, "tests", "cpp", "test_replay.cpp"), "-o", exe])
+    for args in (["3000"], ["1500", "991"]):
+        r = subprocess.run([exe] + args, capture_output=True, timeout=600)
+        assert r.returncode == 0 and b"REPLAY OK" in r.stdout, r.stdout + r.stderr
+        assert b"config-4 shape" in r.stdout
+
+
 def test_adaptor_compiles_and_fails_loudly_without_gpu():
     build()
     r = run()
