@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -87,6 +88,8 @@ struct hs_orb {
     // hs_orb_extract_batch (host-pointer call): one pinned block the three outputs come back into
     uint8_t* h_pin_out = nullptr; size_t pin_out_bytes = 0;
     int last_batch = 0; HsImg0 last_img0{};
+    // where the last host-pointer extraction (hs_orb_extract[_batch], hs_orb_wait) left its results on the DEVICE: what hs_frame_publish keeps
+    const hs_keypoint* pub_kps = nullptr; const uint8_t* pub_desc = nullptr; int pub_cap = 0, pub_batch = 0;
     // bump-allocated scratch for the host-pointer matcher entry points
     uint8_t* d_scratch = nullptr; size_t scratch_bytes = 0, scratch_used = 0;
     // pipelined host ingest (hs_orb_submit_batch / hs_orb_wait): two staging slots, a copy-in and a copy-out stream next to the compute stream
@@ -893,6 +896,7 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
     if (w == 0 || h_px == 0 || !imgs) { for (int i = 0; i < batch; i++) n[i] = 0; return HS_OK; }   // ORBExtractor.cpp:499-500
     if (!kps || !desc || stride < w || cap < 1 || cap > 65535) return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    h->pub_kps = nullptr; h->pub_desc = nullptr; h->pub_batch = 0;
     int rc = configure(h, w, h_px, batch);
     if (rc != HS_OK) return rc;
     if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
@@ -928,6 +932,7 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
         memcpy(kps + (size_t)i * cap, h->h_pin_out + nb + (size_t)i * cap * sizeof(hs_keypoint), cnt * sizeof(hs_keypoint));
         memcpy(desc + (size_t)i * cap * HS_DESC_BYTES, h->h_pin_out + nb + kb + (size_t)i * cap * HS_DESC_BYTES, cnt * HS_DESC_BYTES);
     }
+    h->pub_kps = h->d_kps; h->pub_desc = h->d_desc; h->pub_cap = cap; h->pub_batch = batch;
     return HS_OK;
 }
 
@@ -1094,6 +1099,7 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
     if (!imgs || !ticket || batch < 1 || batch > 65535 || w < 1 || h_px < 1 || stride < w || (sp && (batch & 1))) return fail(h, HS_ERR_INVALID, "bad argument");
     for (int i = 0; i < batch; i++) if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
     *ticket = 0;
+    h->pub_kps = nullptr; h->pub_desc = nullptr; h->pub_batch = 0;      // a slot's device block may be rewritten from here on
     HIP_TRY(h, hipSetDevice(h->device));
     hs_orb::IngestSlot* sl = nullptr;
     for (auto& c : h->slot) if (!c.busy) { sl = &c; break; }
@@ -1227,6 +1233,8 @@ int hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int3
         memcpy(depth + (size_t)i * cap, sl->h_out + sl->off_z + (size_t)i * c0 * 4, cnt * 4);
     }
     sl->busy = false;
+    // (the slot's device block stays as it is until the slot is handed to another hs_orb_submit_batch)
+    h->pub_kps = reinterpret_cast<const hs_keypoint*>(sl->d_out + sl->off_k); h->pub_desc = sl->d_out + sl->off_d; h->pub_cap = c0; h->pub_batch = B;
     return HS_OK;
 }
 
@@ -1290,6 +1298,193 @@ int hs_search_by_projection(hs_orb* h, const hs_frame_view* F, const hs_landmark
     HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     for (int i = 0; i < L; i++) if (match_idx[i] < 0) match_dist[i] = -1.f;      // entries dropped by the rotation check
+    return HS_OK;
+}
+
+// ================= device-resident frames (FeatureViews stay in HBM between ImageProcessing and Tracking) =================
+// hySLAM copies a frame's keypoints and descriptors out of the extractor into FeatureViews (host objects), and every matcher call gathers them
+// again and uploads them (Frame.cc:45-72, FeatureViews.h:20-81).  The features were produced on this device a moment earlier: hs_frame_publish
+// keeps a copy of one extracted frame in a small per-device cache (device-to-device, on the extractor's stream), hs_frame_find recognises a frame by
+// its keypoint array (exact comparison with the host copy kept beside the slot — hySLAM has no field that could carry a token through FeatureViews),
+// and the *_frame(s) entry points take the keypoints and descriptors from the cache instead of the host.  A slot is reused oldest first; a token
+// whose slot was reused is simply unknown again (HS_ERR_INVALID) and the caller falls back to the host-pointer call.
+namespace {
+constexpr int HS_FRAME_SLOTS = 16;
+struct FrameSlot {
+    uint64_t token = 0, stamp = 0;     // token 0 = empty
+    int n = 0, cap = 0, readers = 0;
+    hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr;
+    std::vector<hs_keypoint> h_kps;
+    hipEvent_t ready = nullptr;        // recorded behind the copy that filled the slot
+};
+struct FrameCache { int device = 0; FrameSlot slot[HS_FRAME_SLOTS]; };
+std::mutex g_frames_mu;
+std::vector<FrameCache*> g_frames;     // one per device that ever published; never freed (process lifetime: static destructors must not call HIP)
+uint64_t g_frame_serial = 0;
+FrameCache* frame_cache_of(int device, bool create)
+{
+    for (FrameCache* c : g_frames) if (c->device == device) return c;
+    if (!create) return nullptr;
+    FrameCache* c = new FrameCache(); c->device = device; g_frames.push_back(c);
+    return c;
+}
+struct FrameRef { FrameSlot* slot = nullptr; const hs_keypoint* d_kps = nullptr; const uint8_t* d_desc = nullptr; int n = 0; hipEvent_t ready = nullptr; };
+bool frame_acquire(hs_frame_token tok, int device, FrameRef* r)
+{
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    FrameCache* c = frame_cache_of(device, false);
+    if (!c || !tok) return false;
+    for (FrameSlot& sl : c->slot) if (sl.token == tok) { sl.readers++; r->slot = &sl; r->d_kps = sl.d_kps; r->d_desc = sl.d_desc; r->n = sl.n; r->ready = sl.ready; return true; }
+    return false;
+}
+void frame_release(FrameRef* r) { if (r->slot) { std::lock_guard<std::mutex> g(g_frames_mu); r->slot->readers--; r->slot = nullptr; } }
+struct FrameGuard { FrameRef* a; FrameRef* b; ~FrameGuard() { if (a) frame_release(a); if (b) frame_release(b); } };
+}
+
+int hs_frame_publish(hs_orb* h, int image, const hs_keypoint* kps, int n, hs_frame_token* token)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (token) *token = 0;
+    if (!token || !kps || n < 1 || n > 65535 || image < 0) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (!h->pub_kps || image >= h->pub_batch || n > h->pub_cap) return fail(h, HS_ERR_INVALID, "hs_frame_publish: no host-pointer extraction result of this handle to publish (call right after hs_orb_extract / hs_orb_extract_batch / hs_orb_wait)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    FrameCache* c = frame_cache_of(h->device, true);
+    FrameSlot* sl = nullptr;
+    for (FrameSlot& q : c->slot) if (q.readers == 0 && (!sl || (q.token == 0 && sl->token != 0) || ((q.token == 0) == (sl->token == 0) && q.stamp < sl->stamp))) sl = &q;
+    if (!sl) return fail(h, HS_ERR_CAPACITY, "hs_frame_publish: every cache slot is being read");
+    sl->token = 0;
+    if (!sl->ready) HIP_TRY(h, hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming));
+    if (n > sl->cap) {
+        HIP_TRY(h, hipEventSynchronize(sl->ready));      // (a never-recorded event is complete)
+        hipFree(sl->d_kps); hipFree(sl->d_desc); sl->d_kps = nullptr; sl->d_desc = nullptr; sl->cap = 0;
+        const int grow = std::max(n, 2048);
+        HIP_TRY(h, hipMalloc(&sl->d_kps, (size_t)grow * sizeof(hs_keypoint)));
+        HIP_TRY(h, hipMalloc(&sl->d_desc, (size_t)grow * HS_DESC_BYTES));
+        sl->cap = grow;
+    }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipStreamWaitEvent(s, sl->ready, 0));     // the copy that filled the slot last time (another handle's stream) comes first
+    HIP_TRY(h, hipMemcpyAsync(sl->d_kps, h->pub_kps + (size_t)image * h->pub_cap, (size_t)n * sizeof(hs_keypoint), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(sl->d_desc, h->pub_desc + (size_t)image * h->pub_cap * HS_DESC_BYTES, (size_t)n * HS_DESC_BYTES, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipEventRecord(sl->ready, s));
+    sl->h_kps.assign(kps, kps + n);
+    sl->n = n; sl->stamp = ++g_frame_serial; sl->token = sl->stamp;
+    *token = sl->token;
+    return HS_OK;
+}
+
+int hs_frame_find(int device, const hs_keypoint* kps, int n, hs_frame_token* token)
+{
+    if (!token) return HS_ERR_INVALID;
+    *token = 0;
+    if (!kps || n < 1) return HS_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    FrameCache* c = frame_cache_of(device, false);
+    if (!c) return HS_ERR_INVALID;
+    const FrameSlot* best = nullptr;
+    for (const FrameSlot& sl : c->slot)
+        if (sl.token && sl.n == n && (!best || sl.stamp > best->stamp) && memcmp(sl.h_kps.data(), kps, (size_t)n * sizeof(hs_keypoint)) == 0) best = &sl;
+    if (!best) return HS_ERR_INVALID;
+    *token = best->token;
+    return HS_OK;
+}
+
+int hs_frame_release(int device, hs_frame_token token)
+{
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    FrameCache* c = frame_cache_of(device, false);
+    if (!c || !token) return HS_ERR_INVALID;
+    for (FrameSlot& sl : c->slot) if (sl.token == token) { sl.token = 0; return HS_OK; }      // (a slot that is being read keeps its buffers until the reader is done: readers > 0 keeps it from being refilled)
+    return HS_ERR_INVALID;
+}
+
+int hs_frame_info(int device, hs_frame_token token, int32_t* n)
+{
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    FrameCache* c = frame_cache_of(device, false);
+    if (!c || !token) return HS_ERR_INVALID;
+    for (const FrameSlot& sl : c->slot) if (sl.token == token) { if (n) *n = sl.n; return HS_OK; }
+    return HS_ERR_INVALID;
+}
+
+int hs_search_by_projection_frame(hs_orb* h, hs_frame_token frame, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
+                                  int32_t* match_idx, float* match_dist, int32_t* n_matches)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!F || !pp || L < 0 || !n_matches || (L > 0 && (!lms || !match_idx || !match_dist)) || F->n < 1 || F->n > 65535 ||
+        (pp->use_stereo && F->sensor != 0 && !F->uR))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    *n_matches = 0;
+    FrameRef ref;
+    if (!frame_acquire(frame, h->device, &ref)) return fail(h, HS_ERR_INVALID, "hs_search_by_projection_frame: unknown frame token (its cache slot was reused, or it lives on another device)");
+    FrameGuard guard{ &ref, nullptr };
+    if (ref.n != F->n) return fail(h, HS_ERR_INVALID, "hs_search_by_projection_frame: F->n differs from the published frame");
+    if (L == 0) return HS_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = F->n;
+    const size_t nn = (size_t)n;
+    int rc = scratch_begin(h, 2 * pad256(nn * 4) + pad256(hs_frame_grid_bytes((int)nn)) + pad256(nn * 4) + pad256((size_t)L * sizeof(hs_landmark)) + 3 * pad256((size_t)L * 4) + 256);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = h->stream;
+    float* d_uR = carve<float>(h, nn); int32_t* d_obs = carve<int32_t>(h, nn); int8_t* d_cell = carve<int8_t>(h, hs_frame_grid_bytes((int)nn));
+    int32_t* d_winner = carve<int32_t>(h, nn);
+    hs_landmark* d_lms = carve<hs_landmark>(h, L);
+    int32_t* d_midx = carve<int32_t>(h, L); float* d_mdist = carve<float>(h, L); float* d_pangle = carve<float>(h, L);
+    int32_t* d_nm = carve<int32_t>(h, 1);
+    if (F->uR) HIP_TRY(h, hipMemcpyAsync(d_uR, F->uR, nn * 4, hipMemcpyHostToDevice, s));
+    if (F->kp_lm_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, F->kp_lm_obs, nn * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_lms, lms, (size_t)L * sizeof(hs_landmark), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamWaitEvent(s, ref.ready, 0));
+    hs_launch_frame_grid(*F, ref.d_kps, d_cell, true, s);
+    hs_launch_search_projection(*F, ref.d_kps, ref.d_desc, F->uR ? d_uR : nullptr, F->kp_lm_obs ? d_obs : nullptr, d_cell, d_lms, L, *pp,
+                                d_midx, d_mdist, d_winner, d_pangle, d_nm, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(match_idx, d_midx, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(match_dist, d_mdist, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_matches, d_nm, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int i = 0; i < L; i++) if (match_idx[i] < 0) match_dist[i] = -1.f;      // entries dropped by the rotation check
+    return HS_OK;
+}
+
+int hs_stereo_match_frames(hs_orb* h, hs_frame_token left, hs_frame_token right, const hs_stereo_params* sp, float* uRight, float* depth)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!sp || !uRight || !depth) return fail(h, HS_ERR_INVALID, "bad argument");
+    FrameRef L, R;
+    if (!frame_acquire(left, h->device, &L)) return fail(h, HS_ERR_INVALID, "hs_stereo_match_frames: unknown left frame token");
+    FrameGuard guard{ &L, nullptr };
+    if (!frame_acquire(right, h->device, &R)) return fail(h, HS_ERR_INVALID, "hs_stereo_match_frames: unknown right frame token");
+    guard.b = &R;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nL = L.n, nR = R.n, cap = std::max(nL, nR);
+    hipStream_t s = h->stream;
+    if (!h->d_sm_n) HIP_TRY(h, hipMalloc(&h->d_sm_n, 8));
+    const size_t pin_need = 16 + 2 * (size_t)cap * 4;
+    if (pin_need > h->pin_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (h->h_pin) hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_bytes = 0;
+        const size_t grow = std::max<size_t>(pin_need, 1 << 18);
+        HIP_TRY(h, hipHostMalloc(&h->h_pin, grow, hipHostMallocDefault));
+        h->pin_bytes = grow;
+    }
+    int rc = ensure_stereo_scratch(h, (size_t)cap);
+    if (rc == HS_OK) rc = ensure_stereo_strips(h, 1, cap, sp->n_rows);
+    if (rc != HS_OK) return rc;
+    int32_t* pn = reinterpret_cast<int32_t*>(h->h_pin); float* pout = reinterpret_cast<float*>(h->h_pin + 16);
+    pn[0] = nL; pn[1] = nR;
+    HIP_TRY(h, hipMemcpyAsync(h->d_sm_n, pn, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamWaitEvent(s, L.ready, 0));
+    HIP_TRY(h, hipStreamWaitEvent(s, R.ready, 0));
+    run_stereo(h, L.d_kps, L.d_desc, h->d_sm_n, R.d_kps, R.d_desc, h->d_sm_n + 1, 1, cap, *sp, h->d_ur, h->d_depth, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(pout, h->d_ur, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(pout + cap, h->d_depth, (size_t)nL * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    memcpy(uRight, pout, (size_t)nL * 4);
+    memcpy(depth, pout + cap, (size_t)nL * 4);
     return HS_OK;
 }
 

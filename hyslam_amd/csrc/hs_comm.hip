@@ -32,6 +32,9 @@ struct Rccl {
     hs_nccl_result (*AllGather)(const void*, void*, size_t, int, hs_nccl_comm, hipStream_t) = nullptr;
     hs_nccl_result (*CommDestroy)(hs_nccl_comm) = nullptr;
     const char* (*GetErrorString)(hs_nccl_result) = nullptr;
+    hs_nccl_result (*CommCount)(const hs_nccl_comm, int*) = nullptr;      // optional: what RCCL itself says about a communicator (evidence for a multi-GPU run)
+    hs_nccl_result (*CommUserRank)(const hs_nccl_comm, int*) = nullptr;
+    hs_nccl_result (*GetVersion)(int*) = nullptr;
     std::string why;
 };
 Rccl& rccl()
@@ -63,6 +66,9 @@ Rccl& rccl()
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.so, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.so, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.so, "ncclCommUserRank"));
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.so, "ncclGetVersion"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { r.why = "librccl lacks an expected symbol"; r.so = nullptr; }
     });
     return r;
@@ -131,6 +137,31 @@ void hs_comm_destroy(hs_comm* c)
     hs_orb* const h = c->h;
     delete c;
     hs_orb_borrow(h, -1);                                   // completes a deferred hs_orb_destroy when this was the last borrower
+}
+
+// What RCCL ITSELF reports (not what the caller passed in): ncclCommCount / ncclCommUserRank of the live communicator, ncclGetVersion of the library
+// that was loaded.  -1 = unknown (no communicator, librccl not loaded, or the entry point is missing).  A multi-GPU run prints these, so that the
+// first run on real hardware leaves evidence of how many ranks the collective really spanned.
+int hs_comm_rccl_ranks(const hs_comm* c)
+{
+    Rccl& r = rccl();
+    int n = -1;
+    if (!c || !c->comm || !r.so || !r.CommCount || r.CommCount(c->comm, &n) != 0) return -1;
+    return n;
+}
+int hs_comm_rccl_rank(const hs_comm* c)
+{
+    Rccl& r = rccl();
+    int n = -1;
+    if (!c || !c->comm || !r.so || !r.CommUserRank || r.CommUserRank(c->comm, &n) != 0) return -1;
+    return n;
+}
+int hs_comm_rccl_version(void)
+{
+    Rccl& r = rccl();
+    int v = -1;
+    if (!r.so || !r.GetVersion || r.GetVersion(&v) != 0) return -1;
+    return v;
 }
 
 int hs_comm_world(const hs_comm* c) { return c ? c->world : 0; }

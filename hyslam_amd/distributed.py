@@ -164,6 +164,11 @@ class RecordExchange:
         if st != N.HS_OK:
             raise N.HsError(st, "hs_comm_allgather_records: " + lib.hs_comm_last_error(self._c).decode())
 
+    def rccl_info(self):
+        """what RCCL itself reports for this communicator: {"version": ncclGetVersion, "ranks": ncclCommCount, "rank": ncclCommUserRank} (-1 = unknown)"""
+        lib = self._ex._lib
+        return {"version": int(lib.hs_comm_rccl_version()), "ranks": int(lib.hs_comm_rccl_ranks(self._c)), "rank": int(lib.hs_comm_rccl_rank(self._c))}
+
     def close(self):
         if getattr(self, "_c", None) is not None and self._c.value:
             self._ex._lib.hs_comm_destroy(self._c)
@@ -174,6 +179,39 @@ class RecordExchange:
             self.close()
         except Exception:
             pass
+
+
+def rccl_probe(extractor, rank, world, dev):
+    """A throw-away communicator over all ranks of the default torch.distributed group (the id travels by broadcast): returns RecordExchange.rccl_info()
+    gathered from every rank as {"version", "ranks_seen_by_rccl": [per rank], "consistent"} — or {"error": ...}.  Collective; call it OUTSIDE timed regions.
+    Every rank first answers whether hs_comm is available (non-collective) and the answers are MIN-reduced, so no rank blocks in ncclCommInitRank alone."""
+    import torch
+    import torch.distributed as dist
+    ok, why = comm_available()
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"error": "hs_comm unavailable on at least one rank (%s)" % (why or "another rank")}
+    ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        ident.copy_(torch.frombuffer(bytearray(RecordExchange.unique_id()), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    xc = RecordExchange(extractor, bytes(ident.cpu().numpy().tobytes()), world, rank)
+    info = xc.rccl_info()
+    # one tiny all-gather through the communicator, so that the probe has also MOVED bytes between the ranks
+    send = torch.full((16,), rank + 1, dtype=torch.uint8, device=dev)
+    recv = torch.zeros((world, 16), dtype=torch.uint8, device=dev)
+    xc.allgather(send.data_ptr(), recv.data_ptr(), 16, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    moved = bool((recv[:, 0].cpu() == torch.arange(1, world + 1, dtype=torch.uint8)).all().item())
+    xc.close()
+    mine = torch.tensor([info["ranks"], info["rank"], 1 if moved else 0], dtype=torch.int64, device=dev)
+    allv = torch.empty((world, 3), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allv.view(-1), mine)
+    allv = allv.cpu()
+    seen = allv[:, 0].tolist()
+    return {"version": info["version"], "ranks_seen_by_rccl": seen, "rccl_rank_of_each_rank": allv[:, 1].tolist(), "allgather_moved_bytes": bool(allv[:, 2].min().item() == 1),
+            "consistent": all(v == world for v in seen) and allv[:, 1].tolist() == list(range(world)) and bool(allv[:, 2].min().item() == 1)}
 
 
 def records_knn2_device(extractor, d_records, record_stride, world, rank, cap, d_best_idx, d_best_dist, d_second_dist, stream=0):

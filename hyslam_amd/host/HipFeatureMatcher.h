@@ -32,6 +32,7 @@
 #include "cv_compat.h"
 #endif
 #include <algorithm>
+#include <cstdlib>
 #include <future>
 #include <set>
 #include <stdexcept>
@@ -217,10 +218,11 @@ public:
     hs_orb* handle() const { return h; }
     HipCallTiming timing;             // of the last SearchByProjection(Frame...) / Fuse / key-frame BoW call (HipORBExtractor.h)
     size_t replay_calls = 0, replay_full = 0; int replay_rule = 0;      // of the last SearchByProjection(Frame...): associateLandMark calls made / of the reference's loop
+    bool frame_on_device = false;     // the last SearchByProjection(Frame...) took the frame's keypoints / descriptors from the device's frame cache
 
 private:
     struct Views { std::vector<hs_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> uR; };
-    struct FrameArrays { Views v; std::vector<int32_t> obs; };
+    struct FrameArrays { Views v; std::vector<int32_t> obs; hs_frame_token token = 0; };
     struct Csr { std::vector<int32_t> id, ptr, idx; };
 
     void check(int st, const char* what) const {
@@ -233,18 +235,26 @@ private:
         pp.dist_is_invariance_range = 1;       // MapPoint only exposes GetMin/MaxDistanceInvariance() (= 0.8f*min, 1.2f*max), MapPoint.cc:139-149
         return pp;
     }
-    static Views gather_views(const FeatureViews& views) {
+    static Views gather_views(const FeatureViews& views, bool with_descriptors = true) {
         Views o; const int n = views.numViews();
-        o.kps.resize(std::max(n, 1)); o.desc.resize((size_t)std::max(n, 1) * HS_DESC_BYTES); o.uR.resize(std::max(n, 1), -1.f);
+        o.kps.resize(std::max(n, 1)); o.uR.resize(std::max(n, 1), -1.f);
         for (int i = 0; i < n; i++) {
             const cv::KeyPoint k = views.keypt(i);
             o.kps[i] = hs_keypoint{ k.pt.x, k.pt.y, k.size, k.angle, k.response, k.octave };
-            const cv::Mat row = views.descriptor(i).rawDescriptor();
-            std::memcpy(o.desc.data() + (size_t)i * HS_DESC_BYTES, row.ptr(0), HS_DESC_BYTES);
             o.uR[i] = views.uR(i);
         }
         o.kps.resize(n); o.uR.resize(n);
+        if (with_descriptors) gather_descriptors(views, o);
         return o;
+    }
+    // the expensive half of a frame gather: FeatureDescriptor::rawDescriptor() is the only accessor and clones a cv::Mat per keypoint
+    static void gather_descriptors(const FeatureViews& views, Views& o) {
+        const int n = views.numViews();
+        o.desc.resize((size_t)std::max(n, 1) * HS_DESC_BYTES);
+        for (int i = 0; i < n; i++) {
+            const cv::Mat row = views.descriptor(i).rawDescriptor();
+            std::memcpy(o.desc.data() + (size_t)i * HS_DESC_BYTES, row.ptr(0), HS_DESC_BYTES);
+        }
     }
     static Csr gather_featvec(const DBoW2::FeatureVector& fv) {     // std::map: node ids ascending, indices in insertion (ascending) order
         Csr c; c.ptr.push_back(0);
@@ -256,7 +266,9 @@ private:
     // Frame / KeyFrame -> hs_frame_view (Frame.cc:45-72,137-180; Camera.cpp:116-153).  `T` needs mTcw-like pose access: see pose_of().
     static cv::Mat pose_of(Frame& F) { return F.mTcw; }
     static cv::Mat pose_of(KeyFrame& K) { return K.GetPose(); }
-    template <class T> static hs_frame_view gather_frame(T& F, FrameArrays& a) {
+    // device >= 0: look the frame up in the device's frame cache first (hs_frame_find: the extractor adaptors publish what they extract, include/hyslam_amd.h
+    // "device-resident frames").  Found -> a.token is set, the descriptors are NOT gathered (V.desc = NULL) and the caller uses a *_frame entry point.
+    template <class T> static hs_frame_view gather_frame(T& F, FrameArrays& a, int device = -1) {
         hs_frame_view V; std::memset(&V, 0, sizeof(V));
         const cv::Mat Tcw = pose_of(F);
         if (!Tcw.empty()) {
@@ -269,49 +281,66 @@ private:
         V.min_x = F.mnMinX; V.max_x = F.mnMaxX; V.min_y = F.mnMinY; V.max_y = F.mnMaxY;
         const FeatureViews& views = F.getViews();
         V.size_ref = views.orbParams().size_ref;
-        a.v = gather_views(views);
+        a.v = gather_views(views, false);
         V.n = (int)a.v.kps.size();
+        a.token = 0;
+        if (device >= 0 && V.n > 0 && hs_frame_find(device, a.v.kps.data(), V.n, &a.token) != HS_OK) a.token = 0;
+        if (!a.token) gather_descriptors(views, a.v);
         a.obs.assign(std::max(V.n, 1), -1);
         for (const auto& kv : F.getLandMarkMatches())       // PreviouslyMatchedCriterionCore: Observations() of the keypoint's landmark (MatchCriteria.cpp:124-144)
             if (kv.second && kv.first >= 0 && kv.first < V.n) a.obs[kv.first] = kv.second->Observations();
-        V.kps = a.v.kps.data(); V.desc = a.v.desc.data(); V.uR = a.v.uR.data(); V.kp_lm_obs = a.obs.data();
+        V.kps = a.v.kps.data(); V.desc = a.token ? nullptr : a.v.desc.data(); V.uR = a.v.uR.data(); V.kp_lm_obs = a.obs.data();
         return V;
     }
     // MapPoints -> hs_landmark records.  `F` supplies hasAssociation(lm) (landMarkSizePixels, Frame.cc:296-300) through ONE reverse map instead
     // of the reference's linear scan per landmark; `prev` (may be null) supplies the previous frame's keypoint angle (rotation check).
-    template <class T> static std::vector<hs_landmark> gather_landmarks(const std::vector<MapPoint*>& lms, T& F, const Frame* prev) {
+    template <class T> static std::vector<hs_landmark> gather_landmarks(const std::vector<MapPoint*>& lms, T& F, const Frame* prev, bool need_normals = true) {
         std::unordered_map<MapPoint*, int> assoc, assoc_prev;
         for (const auto& kv : F.getLandMarkMatches()) assoc.insert({ kv.second, kv.first });                 // ascending view index: the first view wins, like the scan
         if (prev) for (const auto& kv : const_cast<Frame*>(prev)->getLandMarkMatches()) assoc_prev.insert({ kv.second, kv.first });
         std::vector<hs_landmark> out(std::max<size_t>(lms.size(), 1));
-        auto fill = [&](size_t a, size_t b) {
+        std::memset(out.data(), 0, out.size() * sizeof(hs_landmark));
+        // geometry of landmarks [a, b): position (+ normal: only Fuse's viewing-angle criterion reads it), size, distance range, associations
+        auto fill_geometry = [&](size_t a, size_t b) {
             for (size_t i = a; i < b; i++) {
-                hs_landmark& L = out[i]; std::memset(&L, 0, sizeof(L));
+                hs_landmark& L = out[i];
                 MapPoint* lm = lms[i];
                 L.assoc_kp = -1;
                 if (!lm) { L.skip = 1; continue; }
-                const cv::Mat P = lm->GetWorldPos(), Nn = lm->GetNormal();
-                for (int k = 0; k < 3; k++) { L.pos[k] = P.at<float>(k); L.normal[k] = Nn.at<float>(k); }
+                const cv::Mat P = lm->GetWorldPos();
+                for (int k = 0; k < 3; k++) L.pos[k] = P.at<float>(k);
+                if (need_normals) { const cv::Mat Nn = lm->GetNormal(); for (int k = 0; k < 3; k++) L.normal[k] = Nn.at<float>(k); }
                 L.size = lm->getSize();
                 L.min_dist = lm->GetMinDistanceInvariance(); L.max_dist = lm->GetMaxDistanceInvariance();         // with dist_is_invariance_range = 1
                 auto it = assoc.find(lm);
                 if (it != assoc.end()) L.assoc_kp = it->second;
                 if (prev) { auto ip = assoc_prev.find(lm); if (ip != assoc_prev.end()) L.prev_angle = prev->getViews().keypt(ip->second).angle; }
-                const cv::Mat row = lm->GetDescriptor().rawDescriptor();
-                std::memcpy(L.desc, row.ptr(0), HS_DESC_BYTES);
             }
         };
-        // Three clones per landmark (GetWorldPos / GetNormal / GetDescriptor().rawDescriptor(): the only accessors MapPoint offers, each under the
-        // MapPoint's own mutex — Tracking and Mapping already call them concurrently): 5.2 ms for TrackLocalMap's 50 000 landmarks on one thread.
-        // Disjoint slices of the output on helper threads; the two maps are only read.
+        auto fill_descriptors = [&](size_t a, size_t b) {      // walks DOWN: the geometry helpers walk up through the same records (one cache line each) — meet once, not at every record
+            for (size_t i = b; i-- > a;) {
+                if (!lms[i]) continue;
+                const cv::Mat row = lms[i]->GetDescriptor().rawDescriptor();
+                std::memcpy(out[i].desc, row.ptr(0), HS_DESC_BYTES);
+            }
+        };
+        // Every accessor MapPoint offers clones (GetWorldPos / GetNormal: a cv::Mat each; GetDescriptor(): a FeatureDescriptor copy, then
+        // rawDescriptor(): another clone), each under the MapPoint's own mutex: ~100 ns per landmark, 5.2 ms for TrackLocalMap's 50 000 on one
+        // thread; the normals (a third of it) are only fetched for the one search that reads them.  Splitting the LANDMARKS over threads makes it
+        // slower, not faster (5.2 -> 5.7 ms with 8 threads on the GPU box): every FeatureDescriptor copy increments and decrements the reference count
+        // of the ONE DescriptorDistance object all descriptors share (FeatureDescriptor.h:31-33), and that cache line then bounces between the cores.
+        // Splitting by FIELD does not: the calling thread takes all descriptors (the shared count stays in its cache), two helper threads take the
+        // geometry, whose clones share nothing (GPU box, 50 000 landmarks, 0 / 1 / 2 / 4 helpers: 3.3 / 3.8 / 2.2 / 2.9 ms).  Disjoint fields of the
+        // output records; the two association maps are only read.
         const size_t n = lms.size();
-        unsigned workers = n >= 8192 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u) : 1u;
-        if (workers <= 1) { fill(0, n); return out; }
-        std::vector<std::future<void>> helpers;
-        const size_t chunk = (n + workers - 1) / workers;
-        for (unsigned w = 1; w < workers; w++) helpers.push_back(std::async(std::launch::async, fill, std::min(n, w * chunk), std::min(n, (w + 1) * chunk)));
-        fill(0, std::min(n, chunk));
-        for (auto& f : helpers) f.get();
+        static const unsigned max_helpers = [] { const char* e = std::getenv("HYSLAM_AMD_GATHER_THREADS"); const int v = e ? std::atoi(e) : -1; return v >= 0 ? (unsigned)std::min(v, 2) : 2u; }();
+        const unsigned helpers_n = n >= 4096 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()) - 1u, max_helpers) : 0u;
+        if (helpers_n == 0) { fill_geometry(0, n); fill_descriptors(0, n); return out; }
+        hip_detail::Worker* const helpers = hip_detail::thread_workers();      // persistent per calling thread (HipORBExtractor.h)
+        const size_t chunk = (n + helpers_n - 1) / helpers_n;
+        for (unsigned w = 0; w < helpers_n; w++) { const size_t a = std::min(n, w * chunk), b = std::min(n, (w + 1) * chunk); helpers[w].run([&fill_geometry, a, b] { fill_geometry(a, b); }); }
+        try { fill_descriptors(0, n); } catch (...) { for (unsigned w = 0; w < helpers_n; w++) { try { helpers[w].wait(); } catch (...) {} } throw; }
+        for (unsigned w = 0; w < helpers_n; w++) helpers[w].wait();
         return out;
     }
     // _SearchByBoW_ between two key frames (FeatureMatcher.cc:281-345): the index criteria apply to BOTH sides (:306-309).
@@ -357,12 +386,19 @@ private:
             lms.erase(std::unique(lms.begin(), lms.end()), lms.end());
         }
         if (lms.empty()) return 0;
-        FrameArrays fa; hs_frame_view V = gather_frame(F, fa);
-        std::vector<hs_landmark> L = gather_landmarks(lms, F, prev);
+        FrameArrays fa; hs_frame_view V = gather_frame(F, fa, hs_orb_get_device(h));
+        std::vector<hs_landmark> L = gather_landmarks(lms, F, prev, pp.use_viewing_angle != 0);
         std::vector<int32_t> midx(lms.size(), -1); std::vector<float> mdist(lms.size(), -1.f); int32_t n = 0;
         timing.gather_ms = hip_detail::ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
-        check(hs_search_by_projection(h, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n), "SearchByProjection");
+        frame_on_device = false;
+        if (fa.token) {      // the frame's keypoints and descriptors are still on the device (published by the extractor adaptor): nothing of them is uploaded
+            const int st = hs_search_by_projection_frame(h, fa.token, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n);
+            if (st == HS_OK) frame_on_device = true;
+            else if (st != HS_ERR_INVALID) check(st, "SearchByProjection(frame on device)");
+            else { gather_descriptors(F.getViews(), fa.v); V.desc = fa.v.desc.data(); }      // the slot was reused meanwhile: the host path
+        }
+        if (!frame_on_device) check(hs_search_by_projection(h, &V, L.data(), (int)lms.size(), &pp, midx.data(), mdist.data(), &n), "SearchByProjection");
         timing.abi_ms = hip_detail::ms_since(t1);
         const auto t2 = std::chrono::steady_clock::now();
         // replay (FeatureMatcher.cc:113-118): the calls that decide the frame's final LandMarkMatches, in address order (HipAssociationReplay.h)

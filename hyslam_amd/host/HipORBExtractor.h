@@ -18,7 +18,11 @@
 #endif
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
+#include <thread>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -47,6 +51,46 @@ inline hs_orb* thread_handle(int device, const char* who) {
     o.by_device[device] = h;
     return h;
 }
+// A helper thread that lives as long as its owner: run(f) hands it one job, wait() blocks until that job is done.  (std::async starts a new thread per
+// call: ~35 us to create it, and a fresh thread allocates from a fresh malloc arena whose pages are touched for the first time — for the ~60 us of
+// FeatureDescriptor constructions an extractor call hands out, that overhead was most of the helper's time.)
+class Worker {
+public:
+    Worker() = default;
+    Worker(const Worker&) = delete;
+    Worker& operator=(const Worker&) = delete;
+    ~Worker() {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    template <class F> void run(F&& f) {
+        std::unique_lock<std::mutex> g(mu);
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        job = std::forward<F>(f); busy = true;
+        g.unlock();
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> g(mu); done_cv.wait(g, [this] { return !busy; }); if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); } }
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(mu);
+        for (;;) {
+            cv.wait(g, [this] { return quit || (busy && job); });
+            if (quit) return;
+            std::function<void()> f; f.swap(job);
+            g.unlock();
+            std::exception_ptr e;
+            try { f(); } catch (...) { e = std::current_exception(); }
+            g.lock();
+            err = e; busy = false;
+            done_cv.notify_all();
+        }
+    }
+    std::mutex mu; std::condition_variable cv, done_cv; std::thread th; std::function<void()> job; bool busy = false, quit = false; std::exception_ptr err;
+};
+// two helpers per CALLING thread, for adaptors that are short-lived objects themselves (a FeatureMatcher is made per call: FeatureFactory.cpp:7-9)
+inline Worker* thread_workers() { static thread_local Worker w[2]; return w; }
 // the GPU of the per-thread handles that have no factory to ask (HipStereomatcher's reference constructor, replace/FeatureMatcher.cc)
 inline std::atomic<int>& default_device() { static std::atomic<int> d{ 0 }; return d; }
 }  // namespace hip_detail
@@ -93,14 +137,17 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         int st = hs_orb_extract(h, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(), cap, &n);
         if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        // keep what was just extracted on the device for the matchers (device-to-device; a full cache or a failed publish only means the host path later)
+        last_token = 0;
+        if (publish_frames && n > 0 && hs_frame_publish(h, 0, kps.data(), n, &last_token) != HS_OK) last_token = 0;
         timing.gather_ms = 0; timing.abi_ms = hip_detail::ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         _keypoints.clear();
         _keypoints.resize(n);
         const size_t d0 = descriptors.size();
         descriptors.resize(d0 + n);                          // appended, like the reference (ORBExtractor.cpp:558-561)
-        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is two thirds of this call's wall time; the
-        // second half of the range is built on a helper thread (disjoint elements of pre-sized vectors, independent Mat allocations).
+        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is two thirds of this call's wall time: two
+        // persistent helper threads of this extractor take a third of the range each (disjoint elements of pre-sized vectors, independent Mat allocations).
         auto fill = [&](int a, int b) {
             for (int i = a; i < b; i++) {
                 cv::KeyPoint& k = _keypoints[i];
@@ -110,9 +157,11 @@ public:
             }
         };
         if (n >= 512) {
-            std::future<void> helper = std::async(std::launch::async, fill, n / 2, n);
-            fill(0, n / 2);
-            helper.get();
+            const int a = n / 3, b = 2 * n / 3;
+            helpers[0].run([&fill, a, b] { fill(a, b); });
+            helpers[1].run([&fill, b, n] { fill(b, n); });
+            try { fill(0, a); } catch (...) { try { helpers[0].wait(); } catch (...) {} try { helpers[1].wait(); } catch (...) {} throw; }      // the helpers hold references to this frame
+            helpers[0].wait(); helpers[1].wait();
         } else fill(0, n);
         timing.scatter_ms = hip_detail::ms_since(t1);
     }
@@ -124,8 +173,12 @@ public:
     std::vector<float> GetInverseScaleSigmaSquares() override { return table(3); }
     hs_orb* handle() { return h; }
     HipCallTiming timing;             // of the last operator() call
+    bool publish_frames = true;       // keep every extracted frame in the device's frame cache (hs_frame_publish) for the stereo matcher and the projection matchers
+    hs_frame_token lastFrameToken() const { return last_token; }
 
 private:
+    hs_frame_token last_token = 0;
+    hip_detail::Worker helpers[2];
     std::vector<float> table(int which) {
         std::vector<float> t[4];
         for (auto& v : t) v.resize(GetLevels());
@@ -151,9 +204,14 @@ public:
         const FeatureExtractorSettings orb_params = views.orbParams();
         sp.fx = cam_data.fx(); sp.mbf = cam_data.mbf; sp.n_rows = (int)cam_data.mnMaxY;
         sp.th_high = settings.TH_HIGH; sp.th_low = settings.TH_LOW; sp.size_ref = orb_params.size_ref;
-        // (2 x 2000 rawDescriptor() clones, the only accessor the reference's FeatureDescriptor offers: 0.16 ms; a helper thread for the right view
-        //  gains nothing — 0.17 ms — the clones are short-lived and the thread start costs what it saves)
-        gather(views.getKeys(), views.getDescriptors(), kL, dL); gather(views.getKeysR(), views.getDescriptorsR(), kR, dR);
+        // Both views were extracted a moment ago by HipORBExtractor instances, which keep their results on the device (hs_frame_publish): when the
+        // frame cache still holds both, only the keypoints are read here (to recognise the frames) and the matcher runs on the device copies —
+        // no 2 x 2000 rawDescriptor() clones (the only accessor the reference's FeatureDescriptor offers: 0.16 ms), no upload.
+        gather_keys(views.getKeys(), kL); gather_keys(views.getKeysR(), kR);
+        const int device = hip_detail::default_device().load();
+        if (kL.empty() || kR.empty() || hs_frame_find(device, kL.data(), (int)kL.size(), &tokL) != HS_OK || hs_frame_find(device, kR.data(), (int)kR.size(), &tokR) != HS_OK) tokL = tokR = 0;
+        if (tokL) held = std::move(views);                 // (the by-value parameter: no copy) kept for the host path should a slot be reused before computeStereoMatches
+        else { gather_descs(views.getDescriptors(), dL); gather_descs(views.getDescriptorsR(), dR); }
         timing.gather_ms = hip_detail::ms_since(t0);
     }
     // explicit-handle form (tests, callers that own an extractor on another device)
@@ -170,24 +228,39 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         mvuRight.assign(kL.size(), -1.0f); mvDepth.assign(kL.size(), -1.0f);
         hs_orb* use = h ? h : hip_detail::thread_handle(hip_detail::default_device().load(), "HipStereomatcher");
-        int st = hs_stereo_match(use, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
-        if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
+        frames_on_device = false;
+        if (tokL && tokR) {
+            const int st = hs_stereo_match_frames(use, tokL, tokR, &sp, mvuRight.data(), mvDepth.data());
+            if (st == HS_OK) frames_on_device = true;
+            else if (st != HS_ERR_INVALID) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st) + ": " + hs_orb_last_error(use));
+            else { gather_descs(held.getDescriptors(), dL); gather_descs(held.getDescriptorsR(), dR); }      // a cache slot was reused meanwhile: the host path
+        }
+        if (!frames_on_device) {
+            int st = hs_stereo_match(use, kL.data(), dL.data(), (int)kL.size(), kR.data(), dR.data(), (int)kR.size(), &sp, mvuRight.data(), mvDepth.data());
+            if (st != HS_OK) throw std::runtime_error(std::string("HipStereomatcher: ") + hs_status_string(st));
+        }
         timing.abi_ms = hip_detail::ms_since(t0);
     }
     void getData(std::vector<float>& mvuRight_, std::vector<float>& mvDepth_) { mvuRight_ = mvuRight; mvDepth_ = mvDepth; }
     void getData(FeatureViews& views) { views.setuRs(mvuRight); views.setDepths(mvDepth); }       // Stereomatcher.cpp:31-34
     static void setDefaultDevice(int device) { hip_detail::default_device().store(device); }
     HipCallTiming timing;             // gather = constructor, abi = computeStereoMatches
+    bool frames_on_device = false;    // computeStereoMatches ran on the extractors' device copies (frame cache), nothing was gathered or uploaded
 
 private:
-    static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) {
-        ok.resize(k.size()); od.resize(k.size() * HS_DESC_BYTES);
-        for (size_t i = 0; i < k.size(); i++) {
-            ok[i] = hs_keypoint{ k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave };
+    static void gather_keys(const std::vector<cv::KeyPoint>& k, std::vector<hs_keypoint>& ok) {
+        ok.resize(k.size());
+        for (size_t i = 0; i < k.size(); i++) ok[i] = hs_keypoint{ k[i].pt.x, k[i].pt.y, k[i].size, k[i].angle, k[i].response, k[i].octave };
+    }
+    static void gather_descs(const std::vector<FeatureDescriptor>& d, std::vector<uint8_t>& od) {
+        od.resize(d.size() * HS_DESC_BYTES);
+        for (size_t i = 0; i < d.size(); i++) {
             cv::Mat row = d[i].rawDescriptor();
             std::memcpy(od.data() + i * HS_DESC_BYTES, row.ptr(0), HS_DESC_BYTES);
         }
     }
+    static void gather(const std::vector<cv::KeyPoint>& k, const std::vector<FeatureDescriptor>& d, std::vector<hs_keypoint>& ok, std::vector<uint8_t>& od) { gather_keys(k, ok); gather_descs(d, od); }
+    hs_frame_token tokL = 0, tokR = 0; FeatureViews held;
     hs_orb* h; hs_stereo_params sp;
     std::vector<hs_keypoint> kL, kR; std::vector<uint8_t> dL, dR;
     std::vector<float> mvuRight, mvDepth;
@@ -240,6 +313,8 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         int st = hs_orb_wait(h, ticket, kps.data(), desc.data(), n, cap, uR.data(), depth.data());
         if (st != HS_OK) throw std::runtime_error(std::string("HipStereoFrontend: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        hs_frame_token tok = 0;
+        if (n[0] > 0) (void)hs_frame_publish(h, 0, kps.data(), n[0], &tok);      // the left view stays on the device for Tracking's projection searches
         timing.abi_ms = hip_detail::ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<cv::KeyPoint> keys[2]; std::vector<FeatureDescriptor> descs[2];

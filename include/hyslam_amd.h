@@ -244,6 +244,30 @@ int  hs_frame_grid(hs_orb* h, const hs_frame_view* F, int8_t* cell_xy);
 int  hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_landmark* d_lms, int L, const hs_proj_params* pp,
                                     int32_t* d_match_idx, float* d_match_dist, int32_t* d_n_matches, void* stream);
 
+/* ---- device-resident frames: a frame's keypoints and descriptors stay in HBM between ImageProcessing and Tracking ----
+ * The reference copies them into FeatureViews (src/core/FeatureViews.h:20-81, built in ImageProcessing.cpp:85,100 and stored by the Frame
+ * constructor, src/core/Frame.cc:45-72), and every matcher call reads them back out of those host objects.  Here the extractor can keep what it
+ * just produced on the device, and the matchers take it from there:
+ *   hs_frame_publish   right after a host-pointer extraction (hs_orb_extract / hs_orb_extract_batch / hs_orb_wait) on `h`: keeps image `image` of
+ *                      that call — device-to-device, on the handle's stream, no host round trip — in a per-device cache of 16 slots (oldest reused
+ *                      first).  kps[n] = the keypoints the call returned for that image (kept beside the slot to recognise the frame later).
+ *   hs_frame_find      hySLAM has no field that could carry a token through FeatureViews / Frame: a frame is recognised by its keypoint array
+ *                      (exact comparison of all n records).  HS_ERR_INVALID when no live slot of `device` holds it.
+ *   hs_frame_release   optional: give a slot back early.      hs_frame_info: its keypoint count.
+ *   hs_search_by_projection_frame   hs_search_by_projection with F->kps / F->desc taken from the cache (both may be NULL in *F; F->n must equal the
+ *                      published count; F->uR / F->kp_lm_obs are host arrays as before: they change between calls).
+ *   hs_stereo_match_frames          hs_stereo_match on two published frames (left, right).
+ * A token whose slot has been reused is unknown again: the call returns HS_ERR_INVALID and the caller uses the host-pointer entry point (the C++
+ * adaptors do).  Tokens are per device; the calls are thread-safe against each other; a slot that a call is reading is never refilled. */
+typedef uint64_t hs_frame_token;    /* 0 = none */
+int  hs_frame_publish(hs_orb* h, int image, const hs_keypoint* kps, int n, hs_frame_token* token);
+int  hs_frame_find(int device, const hs_keypoint* kps, int n, hs_frame_token* token);
+int  hs_frame_release(int device, hs_frame_token token);
+int  hs_frame_info(int device, hs_frame_token token, int32_t* n);
+int  hs_search_by_projection_frame(hs_orb* h, hs_frame_token frame, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
+                                   int32_t* match_idx, float* match_dist, int32_t* n_matches);
+int  hs_stereo_match_frames(hs_orb* h, hs_frame_token left, hs_frame_token right, const hs_stereo_params* sp, float* uRight, float* depth);
+
 /* ---- legacy loop-closing matchers (the reference keeps them for LoopClosing, which is a stub: src/main/System.cc:149) ----
  * FeatureMatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (FeatureMatcher.cc:628-737).  KF = the keyframe (its OWN pose is used by
  * landMarkSizePixels, KeyFrame.cc:258-279 — reference quirk), Scw = the caller's Sim3 as a row-major 4x4.  lms[L] in vpPoints order with
@@ -400,6 +424,9 @@ int  hs_orb_borrowers(const hs_orb* h);
 int  hs_comm_get_unique_id(uint8_t* id /* [HS_COMM_ID_BYTES] */);
 int  hs_comm_create(hs_orb* h, const uint8_t* id, int world, int rank, hs_comm** out);
 void hs_comm_destroy(hs_comm* c);
+int  hs_comm_rccl_ranks(const hs_comm* c);     /* ncclCommCount of the live communicator: what RCCL itself says, -1 = unknown */
+int  hs_comm_rccl_rank(const hs_comm* c);      /* ncclCommUserRank, -1 = unknown */
+int  hs_comm_rccl_version(void);               /* ncclGetVersion of the librccl in use (e.g. 22203), -1 = not loaded */
 int  hs_comm_world(const hs_comm* c);
 int  hs_comm_rank(const hs_comm* c);
 const char* hs_comm_last_error(const hs_comm* c);

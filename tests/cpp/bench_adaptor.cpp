@@ -66,7 +66,7 @@ int main(int argc, char** argv)
 
     cv::Mat imL(h, w, CV_8UC1, rawL.data(), (size_t)w), imR(h, w, CV_8UC1, rawR.data(), (size_t)w);
     FeatureViews last_views;
-    std::vector<double> t_total, t_extract, t_exL_abi, t_exL_scatter, t_views, t_sm_gather, t_sm_abi, t_getdata;
+    std::vector<double> t_total, t_extract, t_exL_abi, t_exL_scatter, t_views, t_sm_gather, t_sm_abi, t_getdata; int stereo_on_device = 0;
     for (int r = 0; r < reps + 3; r++) {
         const auto t0 = clk::now();
         std::vector<cv::KeyPoint> mvKeys, mvKeysRight; std::vector<FeatureDescriptor> mDescriptors, mDescriptorsRight;
@@ -86,6 +86,7 @@ int main(int argc, char** argv)
             t_total.push_back(ms(t0, t4)); t_extract.push_back(ms(t0, t1)); t_views.push_back(ms(t1, t2)); t_getdata.push_back(ms(t3, t4));
             t_exL_abi.push_back(std::max(hxL->timing.abi_ms, hxR->timing.abi_ms)); t_exL_scatter.push_back(std::max(hxL->timing.scatter_ms, hxR->timing.scatter_ms));
             t_sm_gather.push_back(stereomatch.timing.gather_ms); t_sm_abi.push_back(stereomatch.timing.abi_ms);
+            stereo_on_device = stereomatch.frames_on_device;
         }
         last_views = LMviews;
     }
@@ -143,7 +144,7 @@ int main(int argc, char** argv)
     std::set<MapPoint*> local_map_points(lms.begin(), lms.end());
     local_map_points.erase(static_cast<MapPoint*>(nullptr));
     const std::vector<MapPoint*> v_lmp(local_map_points.begin(), local_map_points.end());
-    std::vector<double> p_total, p_gather, p_abi, p_scatter; int n_proj = 0; size_t replay_calls = 0, replay_full = 0; int replay_rule = -1;
+    std::vector<double> p_total, p_gather, p_abi, p_scatter; int n_proj = 0; size_t replay_calls = 0, replay_full = 0; int replay_rule = -1, frame_on_device = 0;
     for (int r = 0; r < std::max(reps / 3, 5) + 2; r++) {
         Frame F(last_views, cam); F.SetPose(Tcw);
         const auto t0 = clk::now();
@@ -154,7 +155,7 @@ int main(int argc, char** argv)
             const HipCallTiming& t = static_cast<HipFeatureMatcher*>(matcher.get())->timing;
             p_total.push_back(ms(t0, t1)); p_gather.push_back(t.gather_ms); p_abi.push_back(t.abi_ms); p_scatter.push_back(t.scatter_ms);
             const HipMatcherCore& core = static_cast<HipFeatureMatcher*>(matcher.get())->matcherCore();
-            replay_calls = core.replay_calls; replay_full = core.replay_full; replay_rule = core.replay_rule;
+            replay_calls = core.replay_calls; replay_full = core.replay_full; replay_rule = core.replay_rule; frame_on_device = core.frame_on_device;
         }
     }
     // ---- LandMarkTriangulator: two key frames with hashed feature vectors (a stand-in for DBoW2's, ~100 nodes like level 2 of ORBvoc on 2000 features)
@@ -177,10 +178,10 @@ int main(int argc, char** argv)
     printf("{\"frame\": \"%dx%d\", \"keypoints\": %d, \"stereo_matches\": %d, \"reps\": %d,\n"
            " \"HipStereoFrontend_ms\": {\"process_total\": %.3f, \"submit_plus_wait\": %.3f, \"FeatureViews_build\": %.3f, \"pipelined_per_pair\": %.3f},\n"
            " \"ProcessStereoImage_ms\": {\"total\": %.3f, \"extract_LR_threads\": %.3f, \"extract_c_abi\": %.3f, \"extract_scatter\": %.3f, \"FeatureViews_ctor\": %.3f,"
-           " \"stereo_gather\": %.3f, \"stereo_c_abi\": %.3f, \"getData\": %.3f},\n"
-           " \"TrackLocalMap_SearchByProjection_ms\": {\"landmarks\": %d, \"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f, \"scatter\": %.3f, \"associateLandMark_calls\": %zu, \"of_full_replay\": %zu, \"replay_rule\": %d},\n"
+           " \"stereo_gather\": %.3f, \"stereo_c_abi\": %.3f, \"getData\": %.3f, \"stereo_frames_on_device\": %d},\n"
+           " \"TrackLocalMap_SearchByProjection_ms\": {\"landmarks\": %d, \"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f, \"scatter\": %.3f, \"associateLandMark_calls\": %zu, \"of_full_replay\": %zu, \"replay_rule\": %d, \"frame_on_device\": %d},\n"
            " \"SearchForTriangulation_ms\": {\"matches\": %d, \"total\": %.3f, \"gather\": %.3f, \"c_abi\": %.3f}}\n",
            w, h, n_kp, n_stereo, reps, median(f_total), median(f_abi), median(f_scatter), median(f_pipe), median(t_total), median(t_extract), median(t_exL_abi), median(t_exL_scatter), median(t_views), median(t_sm_gather), median(t_sm_abi),
-           median(t_getdata), n_lm, n_proj, median(p_total), median(p_gather), median(p_abi), median(p_scatter), replay_calls, replay_full, replay_rule, n_tri, median(q_total), median(q_gather), median(q_abi));
+           median(t_getdata), stereo_on_device, n_lm, n_proj, median(p_total), median(p_gather), median(p_abi), median(p_scatter), replay_calls, replay_full, replay_rule, frame_on_device, n_tri, median(q_total), median(q_gather), median(q_abi));
     return 0;
 }

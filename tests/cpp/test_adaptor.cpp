@@ -1,10 +1,12 @@
 // Exercises hyslam_amd/host/HipORBExtractor.h the way ImageProcessing::ProcessStereoImage uses an extractor and the
 // stereo matcher (src/main/ImageProcessing.cpp:82-103), and compares with the CPU oracle (test infrastructure).
 // usage: test_adaptor W H  < left.raw right.raw on stdin        prints "ADAPTOR OK ..." on success
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "../../hyslam_amd/host/HipORBExtractor.h"
+#include "../../hyslam_amd/host/HipFeatureMatcher.h"
 #include "../../oracle/hs_oracle.h"
 
 int main(int argc, char** argv)
@@ -78,6 +80,74 @@ int main(int argc, char** argv)
         try { fe.submit(L, R); } catch (const std::exception&) { threw = true; }
         if (!threw) { printf("a third ticket was accepted\n"); return 13; }
         if (!same(fe.collect(t2), "frontend ticket 2") || !same(fe.collect(t1), "frontend ticket 1")) return 14;
+    }
+    // ---- device-resident frames (include/hyslam_amd.h): the extractors published what they extracted; the reference-signature
+    //      Stereomatcher and the projection matcher find the frames by their keypoints and run on the device copies
+    {
+        Camera cam; cam.sensor = 1;
+        for (int i = 0; i < 9; i++) cam.K.at<float>(i / 3, i % 3) = 0.f;
+        cam.K.at<float>(0, 0) = 500.f; cam.K.at<float>(1, 1) = 500.f; cam.K.at<float>(0, 2) = W / 2.f; cam.K.at<float>(1, 2) = H / 2.f; cam.K.at<float>(2, 2) = 1.f;
+        cam.mbf = 60.f; cam.mnMaxX = (float)W; cam.mnMaxY = (float)H;
+        exL(L, cv::Mat(), kL, dL = std::vector<FeatureDescriptor>());       // (the empty-image call above was the handle's last extraction)
+        exR(R, cv::Mat(), kR, dR = std::vector<FeatureDescriptor>());
+        const hs_frame_token tokL = exL.lastFrameToken(), tokR = exR.lastFrameToken();
+        int32_t n_info = 0;
+        if (!tokL || !tokR || hs_frame_info(0, tokL, &n_info) != HS_OK || n_info != nL) { printf("extractors did not publish their frames\n"); return 15; }
+        FeatureViews views(kL, kR, dL, dR, FeatureExtractorSettings());
+        HipStereomatcher sm2(views, cam, ms);
+        sm2.computeStereoMatches();
+        std::vector<float> uR2, depth2; sm2.getData(uR2, depth2);
+        if (!sm2.frames_on_device) { printf("Stereomatcher(views, cam, settings) did not find the frames on the device\n"); return 16; }
+        for (int i = 0; i < nL; i++) if (uR2[i] != ouR[i] || depth2[i] != odepth[i]) { printf("stereo on device frames: %d differs\n", i); return 17; }
+        sm2.getData(views);
+        // a frame is recognised by ALL its keypoints: one changed field -> unknown
+        std::vector<hs_keypoint> probe(nL);
+        for (int i = 0; i < nL; i++) probe[i] = hs_keypoint{ kL[i].pt.x, kL[i].pt.y, kL[i].size, kL[i].angle, kL[i].response, kL[i].octave };
+        hs_frame_token found = 0;
+        if (hs_frame_find(0, probe.data(), nL, &found) != HS_OK || found != tokL) { printf("hs_frame_find missed the left frame\n"); return 18; }
+        const float angle_saved = probe[nL / 2].angle;
+        probe[nL / 2].angle += 1.f;
+        if (hs_frame_find(0, probe.data(), nL, &found) == HS_OK || found != 0) { printf("hs_frame_find accepted a changed frame\n"); return 19; }
+        // TrackLocalMap-like search on the left frame: once from the device copy, once (token released) from the host objects — same associations
+        cv::Mat Tcw(4, 4, CV_32F);
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw.at<float>(r, c) = r == c ? 1.f : 0.f;
+        Tcw.at<float>(0, 3) = 0.01f; Tcw.at<float>(2, 3) = 0.02f;
+        std::vector<MapPoint*> lms;
+        for (int j = 0; j < 3 * nL; j++) {
+            const int i = j % nL; const cv::KeyPoint k = views.keypt(i);
+            const double d = (views.depth(i) > 0 ? views.depth(i) : 4.0 + (j % 17)) * (1.0 + 0.01 * (j % 5 - 2));
+            const double pc[3] = { (k.pt.x + (j % 3 - 1) - cam.cx()) * d / 500.0 - 0.01, (k.pt.y - cam.cy()) * d / 500.0, d - 0.02 };
+            const double dd = std::sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+            MapPoint* m = new MapPoint();
+            for (int c = 0; c < 3; c++) { m->mWorldPos.at<float>(c) = (float)pc[c]; m->mNormalVector.at<float>(c) = (float)(pc[c] / dd); }
+            m->size = (float)(k.size * d / 500.0); m->mfMinDistance = (float)(dd * 0.5); m->mfMaxDistance = (float)(dd * 2.0); m->nObs = 2;
+            cv::Mat row = views.descriptor(i).rawDescriptor();
+            if (j >= nL) row.ptr(0)[j % 32] ^= (uint8_t)(1u << (j % 8));
+            m->mDescriptor = FeatureDescriptor(row, dist);
+            lms.push_back(m);
+        }
+        FeatureMatcherSettings fms; fms.nnratio = 0.8f;
+        HipMatcherCore core(fms, exL.handle());
+        Frame F1(views, cam); F1.SetPose(Tcw);
+        const int n1 = core.SearchByProjection(F1, lms, 5.f);
+        if (!core.frame_on_device) { printf("SearchByProjection did not find the frame on the device\n"); return 20; }
+        if (hs_frame_release(0, tokL) != HS_OK || hs_frame_release(0, tokL) == HS_OK) { printf("hs_frame_release\n"); return 21; }
+        probe[nL / 2].angle = angle_saved;      // (the same frame was published several times above — the front end's tickets, the first extraction: every copy goes)
+        for (int guard = 0; guard < 32 && hs_frame_find(0, probe.data(), nL, &found) == HS_OK; guard++) hs_frame_release(0, found);
+        Frame F2(views, cam); F2.SetPose(Tcw);
+        const int n2 = core.SearchByProjection(F2, lms, 5.f);
+        if (core.frame_on_device) { printf("a released frame was still found\n"); return 22; }
+        if (n1 != n2 || n1 < nL / 4 || F1.getLandMarkMatches().views_to_landmarks != F2.getLandMarkMatches().views_to_landmarks ||
+            F1.getLandMarkMatches().n_matches != F2.getLandMarkMatches().n_matches) { printf("device frame vs host frame: %d vs %d matches, associations differ\n", n1, n2); return 23; }
+        // slot reuse: 16 more publishes push the right frame out; its token is unknown afterwards and the stereo matcher falls back to the host path
+        for (int r = 0; r < 17; r++) { std::vector<cv::KeyPoint> kk; std::vector<FeatureDescriptor> ddd; exL(L, cv::Mat(), kk, ddd); }
+        if (hs_frame_info(0, tokR, &n_info) == HS_OK) { printf("a slot survived 17 publishes\n"); return 24; }
+        HipStereomatcher sm3(views, cam, ms);      // left: found again (just re-published), right: gone -> host path
+        sm3.computeStereoMatches();
+        std::vector<float> uR3, depth3; sm3.getData(uR3, depth3);
+        if (sm3.frames_on_device) { printf("stereo matcher used a frame that is not cached\n"); return 25; }
+        for (int i = 0; i < nL; i++) if (uR3[i] != ouR[i] || depth3[i] != odepth[i]) { printf("stereo host fallback: %d differs\n", i); return 26; }
+        printf("device frames: stereo on cached frames ok, projection search %d matches (device == host), slot reuse ok\n", n1);
     }
     printf("ADAPTOR OK %d %d keypoints, %d stereo matches\n", nL, nR, matches);
     return 0;

@@ -132,6 +132,10 @@ def test_bench_adaptor_runs_on_gpu(gpu):
     assert j["keypoints"] > 500 and j["stereo_matches"] > 100
     assert j["TrackLocalMap_SearchByProjection_ms"]["matches"] > 200 and j["SearchForTriangulation_ms"]["matches"] > 100
     assert j["ProcessStereoImage_ms"]["total"] > 0
+    # the extractor adaptors publish their frames; the stereo matcher and the projection search must have run on the device copies
+    assert j["ProcessStereoImage_ms"]["stereo_frames_on_device"] == 1 and j["TrackLocalMap_SearchByProjection_ms"]["frame_on_device"] == 1
+    t = j["TrackLocalMap_SearchByProjection_ms"]
+    assert t["associateLandMark_calls"] <= j["keypoints"] < t["of_full_replay"] or t["of_full_replay"] <= j["keypoints"]
 
 
 @pytest.mark.gpu
