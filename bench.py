@@ -850,7 +850,7 @@ def cpu_baseline(pairs, budget_s):
     import tempfile
     nproc = os.cpu_count() or 2
 
-    def leg(workers, pin):
+    def leg(workers, pin, seconds):
         total, el_all, per_worker, note = 0, 0.0, [], None
         try:
             with tempfile.TemporaryDirectory() as td:
@@ -858,10 +858,10 @@ def cpu_baseline(pairs, budget_s):
                 np.save(fpath, np.stack([np.stack(pr) for pr in pairs]))
                 env = dict(os.environ, MALLOC_MMAP_THRESHOLD_=str(1 << 30), MALLOC_TRIM_THRESHOLD_=str(1 << 30), MALLOC_TOP_PAD_=str(64 << 20), OMP_NUM_THREADS="1")
                 go = time.time() + 3.0 + 0.01 * workers               # common start: the workers import numpy and warm up first, then wait for `go`
-                cmd = [sys.executable, os.path.abspath(__file__), "--cpu-frames", fpath, "--cpu-seconds", str(budget_s), "--cpu-workers", str(workers if pin else 0)]
+                cmd = [sys.executable, os.path.abspath(__file__), "--cpu-frames", fpath, "--cpu-seconds", str(seconds), "--cpu-workers", str(workers if pin else 0)]
                 procs = [subprocess.Popen(cmd + ["--cpu-worker", str(i)], env=dict(env, HS_CPU_GO=repr(go)), stdout=subprocess.PIPE) for i in range(workers)]
                 for pr_ in procs:
-                    o, _ = pr_.communicate(timeout=budget_s * 6 + 120)
+                    o, _ = pr_.communicate(timeout=seconds * 6 + 120)
                     try:
                         r = json.loads(o.decode().strip().splitlines()[-1])
                         per_worker.append(r["pairs"] / r["seconds"]); total += r["pairs"]; el_all = max(el_all, r["seconds"])
@@ -871,12 +871,30 @@ def cpu_baseline(pairs, budget_s):
             note = str(e)[:200]
         return total, el_all, per_worker, note
 
-    n, el, one, note1 = leg(1, False)
+    n, el, one, note1 = leg(1, False, budget_s)
     ref = one[0] if one else None
-    workers = max(1, nproc // 2)
-    total, el_all, per_worker, note = leg(workers, True)
+    # How many cores does this job really have?  os.cpu_count() says what the MACHINE has (256 logical cores on the GPU box), not what the job may
+    # use: the box gives one GPU's job a CPU share (a cgroup quota) of a fraction of that, and 128 workers on a 16-CPU share is what round 4 measured
+    # as "72.7 pairs/s on all 256 cores".  So: the affinity mask and the cgroup quota when they are visible, and in any case a short scaling probe
+    # (2-s legs, the worker count doubling while the throughput still grows by >= 25 %) — the all-cores figure is the best point of that curve,
+    # measured again over the full budget.
+    cores_hint, how = effective_cpus()
+    probe, w = {}, max(1, min(4, nproc // 2))
+    best_w, best_v = 1, ref or 0.0
+    while w <= max(1, nproc // 2):
+        t_, e_, pw, _ = leg(w, True, min(2.0, budget_s))
+        v = sum(pw) if pw else 0.0
+        probe[str(w)] = round(v, 2)
+        if v > 1.1 * best_v:                                          # more workers only when they buy >= 10 %: past the job's CPU share they only time-slice
+            best_w, best_v = w, v
+        if v < 1.25 * probe.get(str(w // 2), 0.0) or w == nproc // 2:
+            break
+        w = min(2 * w, max(1, nproc // 2))
+    workers = best_w
+    total, el_all, per_worker, note = leg(workers, True, budget_s)
     all_cores = {"value": round(sum(per_worker), 2) if per_worker else None, "threads": 2 * workers, "nproc": nproc, "workers": workers,
-                 "kind": "worker processes, 2 threads each, pinned to 2 logical CPUs each",
+                 "cpus_available_to_this_job": cores_hint, "cpus_available_how": how, "scaling_probe_pairs_per_s_by_workers": probe,
+                 "kind": "worker processes, 2 threads each, pinned to 2 logical CPUs each; worker count = the best point of the scaling probe",
                  "per_worker_pairs_per_s": {"min": round(min(per_worker), 3), "median": round(float(np.median(per_worker)), 3), "max": round(max(per_worker), 3)} if per_worker else None,
                  "sample": "%d pairs in %.1f s" % (total, el_all)}
     if per_worker and ref:
@@ -887,11 +905,35 @@ def cpu_baseline(pairs, budget_s):
            "cpu_ref_structure": {"value": None if ref is None else round(ref, 3), "threads": 2, "kind": "one worker process, 2 threads, not pinned"},
            "cpu_all_cores": all_cores,
            "sample": "%d synthetic 1920x1080 pairs in %.1f s; oracle/ C++ restatement (left||right threads + stereo match), "
-                     "omits the reference's cv::Mat/FeatureDescriptor allocation overheads (an optimistic stand-in); host has %d logical cores"
-                     % (n, el, nproc)}
+                     "omits the reference's cv::Mat/FeatureDescriptor allocation overheads (an optimistic stand-in); host has %d logical cores, "
+                     "this job may use %s" % (n, el, nproc, cores_hint if cores_hint else "an unknown share")}
     if note1:
         out["note"] = note1
     return out
+
+
+def effective_cpus():
+    """(cpus this job may use, how it is known): the affinity mask capped by the cgroup CPU quota (v2: cpu.max, v1: cpu.cfs_quota_us / cpu.cfs_period_us)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    how = "affinity mask"
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            c = int(np.ceil(float(q[0]) / float(q[1])))
+            if c < n:
+                n, how = c, "cgroup v2 cpu.max"
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0 and int(np.ceil(quota / period)) < n:
+                n, how = int(np.ceil(quota / period)), "cgroup v1 cfs quota"
+        except Exception:
+            pass
+    return n, how
 
 
 def cpu_worker(args):

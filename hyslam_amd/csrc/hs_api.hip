@@ -61,6 +61,7 @@ struct hs_orb {
     uint32_t* d_qhist = nullptr; unsigned long long* d_qbest = nullptr; uint32_t qhist_stride = 0, qbest_stride = 0;
     int fast_keys_levels = HS_MAX_LEVELS;   // HS_FAST_KEYS_LEVELS (read once; tuning): only the levels 0 .. n-1 get keys
     int fast_keys_max_batch = 16;      // HS_FAST_KEYS_MAX_BATCH (read once): calls of more frames than this run without the keys (see run_extract)
+    bool qt_small_ok = false;          // every level's list (quota + 8 nodes) fits the quadtree kernel's small instance (two workgroups per CU; HS_QT_SMALL=0 switches it off, read once)
     bool keys_dirty = false;           // a keyed call was enqueued and did not reach its end (any error return of run_extract): d_qhist / d_qbest may hold stale keys -> zeroed before the next call
     bool fast_keys = true;             // HS_FAST_KEYS=0 (read once): the quadtree kernel gathers the candidates and computes the keys itself (the scheme until round 3)
     bool keep_points = false;          // hs_orb_set_debug(h, 1): the quadtree kernel also gathers the candidates into the dense point arrays (hs_orb_debug_candidates reads them)
@@ -88,6 +89,7 @@ struct hs_orb {
     // hs_orb_extract_batch (host-pointer call): one pinned block the three outputs come back into
     uint8_t* h_pin_out = nullptr; size_t pin_out_bytes = 0;
     int last_batch = 0; HsImg0 last_img0{};
+    int last_stereo_launches = 2;      // launches of stage 4 in the last stereo call: strips + match (run_stereo) or match only (the front end with the strips inside the describe launch)
     // where the last host-pointer extraction (hs_orb_extract[_batch], hs_orb_wait) left its results on the DEVICE: what hs_frame_publish keeps
     const hs_keypoint* pub_kps = nullptr; const uint8_t* pub_desc = nullptr; int pub_cap = 0, pub_batch = 0;
     // bump-allocated scratch for the host-pointer matcher entry points
@@ -563,7 +565,8 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
     auto quadtree = [&](int level_first, int level_count, hipStream_t st) {
         hs_launch_quadtree(d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
                            h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0,
-                           level_first, level_count, use_keys ? h->d_qhist : nullptr, h->d_qbest, h->qhist_stride, h->qbest_stride, h->keep_points ? 1 : 0, st);
+                           level_first, level_count, use_keys ? h->d_qhist : nullptr, h->d_qbest, h->qhist_stride, h->qbest_stride, h->keep_points ? 1 : 0,
+                           h->qt_small_ok ? 1 : 0, st);
     };
     if (split) {
         if (!h->s_aux) {
@@ -625,6 +628,7 @@ void run_stereo(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const int32
                 const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
 {
     mark(h, 4, s);
+    h->last_stereo_launches = 2;
     hs_launch_stereo(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
     mark(h, 5, s);
     hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, h->d_strip_count, sp.n_rows, s);
@@ -639,6 +643,7 @@ void run_stereo_fused(hs_orb* h, const hs_keypoint* kL, const uint8_t* dL, const
                       const int32_t* nR, int pairs, int cap, const hs_stereo_params& sp, float* ur, float* depth, hipStream_t s)
 {
     mark(h, 4, s);
+    h->last_stereo_launches = 1;
     hs_launch_stereo_match_only(kL, dL, nL, kR, dR, nR, pairs, cap, sp, ur, depth, h->d_bd, h->d_strip_count, h->d_strip_list, s);
     mark(h, 5, s);
     hs_launch_stereo_median(nL, pairs, cap, ur, depth, h->d_bd, h->d_strip_count, sp.n_rows, s);
@@ -754,6 +759,12 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     h->quota[L - 1] = std::max(p->nfeatures - sum, 0);
     for (int l = 0; l < L; l++)
         if (h->quota[l] + 8 > HS_QT_MAX_NODES) { delete h; return HS_ERR_INVALID; }
+    h->qt_small_ok = true;
+    for (int l = 0; l < L; l++) if (h->quota[l] + 8 > hs_quadtree_small_nodes()) h->qt_small_ok = false;
+    // ... and only on request (HS_QT_SMALL=1, read once): measured at 32 / 64 pairs per call the two-per-CU instance is SLOWER (quadtree 0.0631 against 0.0606 ms,
+    // 0.1198 against 0.1117): without the points in LDS every sweep goes through L2, which costs a workgroup more than sharing the CU buys.  Kept as a parity /
+    // tuning variant (tests/test_gpu_parity.py runs it).
+    { const char* e = getenv("HS_QT_SMALL"); if (!e || atoi(e) == 0) h->qt_small_ok = false; }
 
     if (hipSetDevice(device) != hipSuccess) { delete h; return HS_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1872,9 +1883,15 @@ int hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes
 
 int hs_orb_stage_launches(const hs_orb* h, int stage)
 {
+    // launches per stage OF THE LAST CALL on the handle (what hs_orb_profile_end's per-stage times are divided by): the pyramid's plan depends on the
+    // batch (calls of <= deep_max_batch frames run the small-batch plan: one launch at 1080p instead of three), the stereo stage on the entry point
     if (!h || stage < 0 || stage >= HS_NUM_STAGES) return 0;
-    if (stage == 0) return h->lv.empty() ? std::max(h->p.nlevels - 1, 0) : hs_pyramid_launch_count(h->lv.data(), h->p.nlevels);
-    return stage == 4 ? 2 : 1;
+    if (stage == 0) {
+        if (h->lv.empty()) return std::max(h->p.nlevels - 1, 0);
+        if (h->last_batch > 0 && h->last_batch <= h->deep_max_batch && !h->pyr_deep.empty()) { int32_t o[8]; hs_debug_plan_summary(h, o); return o[1]; }
+        return hs_pyramid_launch_count(h->lv.data(), h->p.nlevels);
+    }
+    return stage == 4 ? h->last_stereo_launches : 1;
 }
 
 int hs_orb_profile_begin(hs_orb* h)

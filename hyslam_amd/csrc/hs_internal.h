@@ -230,7 +230,9 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count,
                         uint32_t* qhist /*nullptr: the FAST launch left no keys — gather*/, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
-                        int keep_points /*debug: gather the candidates into pts_* even when the keys make it unnecessary*/, hipStream_t s);
+                        int keep_points /*debug: gather the candidates into pts_* even when the keys make it unnecessary*/,
+                        int small_lists_ok /*every level's quota + 8 <= hs_quadtree_small_nodes(): launches of > 256 workgroups may use the two-per-CU instance*/, hipStream_t s);
+int hs_quadtree_small_nodes();
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
                         const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps, HsStripFuse strips);

@@ -69,9 +69,13 @@ __constant__ MomW c_momw = make_momw();
 #define RAW_BYTES (RAW_N * RAW_P + 16)
 #define BL_N 37
 #define H_P 38                   // generic path: row-major u16 row sums
-#define HT_P 46                  // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
+#ifndef HT_P
+#define HT_P 46
+#endif                           // fast path: transposed u16 row sums, 43 rows + pad; 46 u16 = 23 dwords (odd) keeps column-strided stores off the same banks
 #define H_ELEMS (40 * HT_P)       // fast path: 40 columns are written (37 used); 1840 >= RAW_N * H_P = 1634
-#define BL_P 40                  // blurred tile: COLUMN-major, 40 bytes per column (8-byte aligned columns for the 8-byte stores of the column pass)
+#ifndef BL_P
+#define BL_P 40
+#endif                           // blurred tile: COLUMN-major, 40 bytes per column (8-byte aligned columns for the 8-byte stores of the column pass)
 #define KP_PER_BLOCK 4
 
 __device__ __forceinline__ int reflect101(int p, int len)

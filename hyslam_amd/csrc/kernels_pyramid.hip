@@ -13,6 +13,7 @@
 // four aligned dwords and the taps are picked out with v_alignbyte instead of 16 byte loads; the x table is one
 // 8-byte record {sx, a0, a1, -} per output.
 #include "hs_internal.h"
+#include <atomic>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -762,9 +763,20 @@ static int pyr_nw8_wg_per_cu()
 }
 void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s, const HsPyrChain* deep)
 {
-    static const bool big_lds = [] {      // the deep chains of small batches may want more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess;
+    // the deep chains of small batches may want more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU).  Function attributes are PER DEVICE:
+    // the raise is done once for every device a launch sequence is enqueued on (a handle on a second GPU of the process gets its own), and a device
+    // where it failed only ever runs deep chains of <= 64 KB (the standard plan otherwise)
+    const bool big_lds = deep != nullptr && [] {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+        static std::atomic<int8_t> state[64];       // 0 = not tried on this device, 1 = raised, 2 = failed
+        const int8_t st = state[dev].load(std::memory_order_acquire);
+        if (st) return st == 1;
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<8>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_resize_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, HS_PYR_DEEP_LDS) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        state[dev].store(ok ? 1 : 2, std::memory_order_release);
+        return ok;
     }();
     for (int l = 1; l < nlevels; l++) {
         const HsLevel& D = h_lv[l];

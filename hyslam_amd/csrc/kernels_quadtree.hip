@@ -43,14 +43,22 @@
 #include <cstdlib>
 
 #define QT_T HS_QT_THREADS
-#define QT_M HS_QT_MAX_NODES
-#define QT_PTS 6144              // points kept in LDS (a 1080p level has ~5000 candidates); more fall back to the global arrays
+// The kernel is a template over <QT_M, QT_PTS> (round 5):
+//   QT_M    list capacity in LDS (>= the largest per-level quota + 8)
+//   QT_PTS  points kept in LDS (a 1080p level has ~5000 candidates); more fall back to the global arrays
+// <HS_QT_MAX_NODES = 2048, 6144> is the general instance: 152 KB of LDS, ONE workgroup per CU — every sweep over the points runs from LDS, which is what a
+// launch of few workgroups (one per (image, level): 16 for a stereo pair) wants.  <1024, 0> keeps no points in LDS (the sweeps read them through L2)
+// and fits 77 KB: TWO workgroups per CU, for launches of more than 256 workgroups (more than 16 stereo pairs per call), which used to run in
+// rounds of 256.  The arrays that double as scratch (histogram pyramid, marks, key tables, gather offsets) are sized by what they must hold, not by QT_M.
+#define QT_PTS_BIG 6144
+#define QT_M_SMALL 1024
 
 #define QT_HPYR 10928             // histogram pyramid entries (u16): n_ini * (4^(DH+1) - 1) / 3 <= 10922 for (n_ini <= 2, DH = 6) and (n_ini <= 8, DH = 5)
 
 // Node list, double buffered.  Rectangles are only kept in the point domain; in the count domain their LDS holds the histogram pyramid.
-struct alignas(16) QtRects { int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M]; };
-static_assert(2 * sizeof(QtRects) >= QT_HPYR * 2, "the histogram pyramid lives in the rectangle arrays");
+template <int QT_M> struct alignas(16) QtRects { int16_t x0[QT_M], x1[QT_M], y0[QT_M], y1[QT_M]; };
+constexpr int qt_cmax(int a, int b) { return a > b ? a : b; }
+#define QT_MAXT 4096              // 64-px tiles of a level that the spatial order of the kept keypoints is built for (more: list order)
 struct QtNodes {                 // a view of buffer `c`
     int16_t *x0, *x1, *y0, *y1; uint32_t* cnt; uint16_t* ekey;
 };
@@ -116,6 +124,7 @@ extern "C" void hs_debug_qt_profile(unsigned long long* out128) { (void)hipDevic
 #else
 #define QT_MARK(tag)
 #endif
+template <int QT_M, int QT_PTS>
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint2* __restrict__ cand,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
@@ -126,17 +135,24 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    uint32_t* __restrict__ qhist, unsigned long long* __restrict__ qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
                                                    int keep_points)
 {
-    __shared__ QtRects s_rect[2];                  // point domain: node rectangles; count domain: the histogram pyramid (u16)
+    // point domain: node rectangles; count domain: the histogram pyramid (u16) — sized for the larger of the two
+    __shared__ alignas(16) uint8_t s_r1[qt_cmax(2 * (int)sizeof(QtRects<QT_M>), QT_HPYR * 2)];
+    QtRects<QT_M>* const s_rect = reinterpret_cast<QtRects<QT_M>*>(s_r1);
     __shared__ uint32_t s_cnt[2][QT_M];            // points per node
     __shared__ uint16_t s_ekey[2][QT_M];           // count domain: depth << 13 | cell index at that depth (root * 4^depth + path)
-    __shared__ uint32_t ccount[4 * QT_M];          // child counts, indexed 4*rank + child
-    __shared__ alignas(16) int16_t s_idx3[3 * QT_M];   // three per-node index arrays (12 KB, idle during the gather: the geometric-key tables live here then)
+    // child counts, indexed 4*rank + child; also: the marks (u16 per pyramid entry), the sort keys of phase 2 (<= 8 bytes per node), and at the
+    // end the best-point slots (8 QT_M bytes) followed by the tile counters of the spatial order
+    constexpr int CCOUNT_BYTES = qt_cmax(qt_cmax(16 * QT_M, QT_HPYR * 2), qt_cmax(8 * QT_M + 4 * QT_MAXT, (QT_M + 3) * 8));
+    __shared__ alignas(16) uint32_t ccount[CCOUNT_BYTES / 4];
+    // three per-node index arrays (idle during the gather: the geometric-key tables, 8192 + 4096 bytes, live here then)
+    __shared__ alignas(16) int16_t s_idx3[qt_cmax(3 * QT_M, (8192 + 4096) / 2)];
     int16_t* const proc_rank = s_idx3;                                                  // processing rank of a node in this pass, -1 = not split
     int16_t* const order_node = s_idx3 + QT_M;                                          // rank -> node
     uint16_t* const new_index = reinterpret_cast<uint16_t*>(s_idx3 + 2 * QT_M);         // surviving node -> index in the next list
-    __shared__ alignas(16) uint16_t child_index[4 * QT_M];     // 4*rank+child -> index in the next list
-    __shared__ uint32_t s_pxy[QT_PTS];             // the level's points (y<<16|x) and their node (count domain: their geometric key), when there
-    __shared__ uint16_t s_pnode[QT_PTS];           // are <= QT_PTS of them: every sweep walks the points from LDS instead of through L2
+    // 4*rank+child -> index in the next list; also the gather's per-item offsets ((2 QT_T + 4) dwords), the partial ranks of phase 2 and the best-point slots
+    __shared__ alignas(16) uint16_t child_index[qt_cmax(4 * QT_M, (2 * QT_T + 4) * 2)];
+    __shared__ uint32_t s_pxy[QT_PTS > 0 ? QT_PTS : 1];      // the level's points (y<<16|x) and their node (count domain: their geometric key), when there
+    __shared__ uint16_t s_pnode[QT_PTS > 0 ? QT_PTS : 1];    // are <= QT_PTS of them: every sweep walks the points from LDS instead of through L2
     __shared__ int s_wave[2 * (QT_T / 64)];
     __shared__ int s_misc[8];
     __shared__ uint32_t s_dcnt[8];                 // per depth: existing nodes | single-point nodes << 16
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     auto root_of = [&](int x) { return min((int)((float)x / hX), nIni - 1); };      // vpIniNodes[kp.pt.x/hX]
     // the tables depend on the level geometry alone: the host builds them once per configuration (hs_quadtree_build_tables: the same
     // expressions, IEEE float division and multiplication), the workgroup copies them with 16-byte loads when it needs them — i.e. when it
-    // gathers the candidates (round 4: normally it does not, see `pre` below).  They live in LDS that is idle then (s_idx3).
+    // gathers the candidates (round 4: normally it does not, see `have_keys` below).  They live in LDS that is idle then (s_idx3).
     auto load_key_tables = [&]() {
         if (!use_tab) return;
         if (tid >= 1 && tid < nIni) s_rbound[tid] = L.qt_rbound[tid];
@@ -208,20 +224,20 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     //      below (a third of the level-0 workgroup's time: item scan, run search, record fetch, key computation, LDS atomics) only runs when
     //      the points themselves are needed: point-domain passes (clustered corners, > 65535 points, HS_QT_POINT_DOMAIN) or the debug taps.
     //      Whatever happens, the workgroup leaves both global arrays ZERO for the next call.
-    const bool pre = qhist != nullptr && L.qt_hist_off != 0xFFFFFFFFu;          // uniform; the level has key tables (nIni <= 8)
-    const int ncell = nIni << (2 * DH);                                         // deepest cells (pre: nIni <= 8, so <= 8192)
-    uint32_t* const ghist = pre ? qhist + (size_t)img * qhist_img_stride + L.qt_hist_off : nullptr;
-    unsigned long long* const gbest = pre ? qbest + (size_t)img * qbest_img_stride + L.qt_best_off : nullptr;
-    bool best_pending = pre;                                                     // gbest still holds this call's keys
+    const bool have_keys = qhist != nullptr && L.qt_hist_off != 0xFFFFFFFFu;    // uniform; the level has key tables (nIni <= 8)
+    const int ncell = nIni << (2 * DH);                                         // deepest cells (have_keys: nIni <= 8, so <= 8192)
+    uint32_t* const ghist = have_keys ? qhist + (size_t)img * qhist_img_stride + L.qt_hist_off : nullptr;
+    unsigned long long* const gbest = have_keys ? qbest + (size_t)img * qbest_img_stride + L.qt_best_off : nullptr;
+    bool best_pending = have_keys;                                                     // gbest still holds this call's keys
     auto zero_gbest = [&]() {
         if (!best_pending) return;
         for (int i = tid; i < ncell / 2; i += QT_T) *reinterpret_cast<uint4*>(gbest + 2 * i) = make_uint4(0, 0, 0, 0);
         best_pending = false;
     };
     int n_pre = 0;
-    if (cf_geom || pre) {
+    if (cf_geom || have_keys) {
         uint32_t* const h32 = reinterpret_cast<uint32_t*>(s_rect);
-        if (pre) {
+        if (have_keys) {
             // the deepest level of the pyramid comes from global memory (16 bytes per thread and round: <= 8192 cells are ONE round) and goes back
             // to zero there; the levels above it are written in full by the pyramid build below, so nothing else needs clearing
             if (tid < 16) s_wave[tid] = 0;
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
         gathered = true;
     };
-    if (!pre) gather(cf_geom);
+    if (!have_keys) gather(cf_geom);
     else {
         n = n_pre;
         // the points themselves are needed from the start: no count domain at all (HS_QT_POINT_DOMAIN, > 65535 points) or the debug taps
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     }
     if (tid == 0) cand_count[img * nlevels + level] = n;
     QT_MARK(1);
-    const bool in_lds = n <= QT_PTS;               // uniform
+    const bool in_lds = QT_PTS > 0 && n <= QT_PTS; // uniform
     auto ld_xy = [&](int p) -> uint32_t { return in_lds ? s_pxy[p] : pxy[p]; };
     auto st_node = [&](int p, int v) { if (in_lds) s_pnode[p] = (uint16_t)v; else pnode[p] = (uint16_t)v; };
 
@@ -381,11 +397,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     auto relabel_from_keys = [&](const QtNodes C) {
         build_marks(C);
         if (in_lds) {
+            if constexpr (QT_PTS > 0) {
             int gk[QT_PTS / QT_T];
 #pragma unroll
             for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; gk[k] = p < n ? (int)s_pnode[p] : 0; }
 #pragma unroll
             for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) s_pnode[p] = (uint16_t)node_of_key(gk[k]); }
+            }
         } else {
             for (int p0 = tid; p0 < n; p0 += 8 * QT_T) {              // points in global memory: eight loads in flight per thread
                 int gk[8];
@@ -570,7 +588,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         // leave the count domain when a node that may be split has no children in the pyramid: label the points, build the rectangles
         if (cm && (!phase2 || (T_prev > 0 && (int)(s_ekey[cur][0] >> 13) >= DH))) {
             const QtNodes C = view(cur);
-            if (pre && !gathered) { gather(false); zero_gbest(); }      // the point-domain passes need the points after all: fetch them now (keys into s_pnode / pnode)
+            if (have_keys && !gathered) { gather(false); zero_gbest(); }      // the point-domain passes need the points after all: fetch them now (keys into s_pnode / pnode)
             relabel_from_keys(C);                       // the pyramid is dead from here on: its LDS becomes the rectangles
             for (int i = tid; i < S; i += QT_T) {
                 const int ek = C.ekey[i], d = ek >> 13, g = ek & 0x1FFF, r = g >> (2 * d);
@@ -687,6 +705,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         for (int i = tid; i < 4 * E; i += QT_T) ccount[i] = 0;
         __syncthreads();
         if (in_lds) {
+            if constexpr (QT_PTS > 0) {
             // all of a thread's points at once: independent LDS loads instead of one dependent chain per point
             int nd[QT_PTS / QT_T], rk[QT_PTS / QT_T];
 #pragma unroll
@@ -701,6 +720,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                 const int key = on ? 4 * rk[k] + child_of(C, nd[k], xy & 0xFFFF, xy >> 16) : 0;
                 if (E <= 4) wave_agg_inc(ccount, key, on);           // <= 16 counters: aggregate per wave
                 else if (on) atomicAdd(&ccount[key], 1u);
+            }
             }
         } else {
             for (int p = tid; p < n; p += QT_T) {
@@ -813,6 +833,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         // -- relabel the points (point domain; in the count domain the points keep their geometric keys until the end)
         if (cm) {
         } else if (in_lds) {
+            if constexpr (QT_PTS > 0) {
             int nd[QT_PTS / QT_T], rk[QT_PTS / QT_T];
 #pragma unroll
             for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; nd[k] = p < n ? (int)s_pnode[p] : 0; }
@@ -827,6 +848,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                         s_pnode[p] = child_index[4 * rk[k] + child_of(C, nd[k], xy & 0xFFFF, xy >> 16)];
                     } else s_pnode[p] = new_index[nd[k]];
                 }
+            }
             }
         } else {
             for (int p = tid; p < n; p += QT_T) {
@@ -863,7 +885,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         unsigned long long key = ((unsigned long long)(sk >> 24) << 56) | (0x00FFFFFFFFFFFFFFull - order);
         atomicMax(&best[node], key);
     };
-    if (keyed && pre && !gathered) {
+    if (keyed && have_keys && !gathered) {
         // the candidates were never fetched: every occupied deepest cell offers the best candidate the FAST kernel recorded for it (the same
         // 64-bit key a sweep over the cell's points would end with) to the list node on the cell's root-to-leaf chain; the global slots go back to zero
         // The eight consecutive cells of a thread share their ancestors down to depth DH - 2 (one mark lookup per depth for all of them) and, in
@@ -894,6 +916,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
         best_pending = false;
     } else if (in_lds) {
+        if constexpr (QT_PTS > 0) {
         uint32_t sk[QT_PTS / QT_T]; int nd[QT_PTS / QT_T];
 #pragma unroll
         for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; sk[k] = p < n ? psk[p] : 0u; nd[k] = p < n ? (int)s_pnode[p] : 0; }      // global loads, all in flight
@@ -903,6 +926,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
         }
 #pragma unroll
         for (int k = 0; k < QT_PTS / QT_T; k++) { const int p = tid + k * QT_T; if (p < n) offer(s_pxy[p], sk[k], nd[k]); }
+        }
     } else {
         for (int p0 = tid; p0 < n; p0 += 8 * QT_T) {                  // points in global memory: eight records in flight per thread
             uint32_t xy[8], sk[8]; int nd[8];
@@ -934,7 +958,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     {
         const int Sc = min(S, L.sel_cap);
         uint16_t* const perm = sel_perm + (size_t)img * sel_img_stride + L.sel_off;
-        constexpr int MAXT = 2 * QT_M;                                 // tile counters live in the upper half of ccount (best[] occupies the lower half)
+        constexpr int MAXT = QT_MAXT;                                  // tile counters live in ccount behind the best-point slots (8 QT_M bytes, whichever array holds them)
         uint32_t* const tcnt = ccount + 2 * QT_M;
         static_assert(sizeof(ccount) >= (2 * QT_M + MAXT) * 4, "tile counters");
         const int ntx = (L.w + 63) >> 6, ntiles = ntx * ((L.h + 63) >> 6);
@@ -965,7 +989,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
             for (int k = 0; k < (QT_M + QT_T - 1) / QT_T; k++)
                 if (tile[k] >= 0) perm[atomicAdd(&tcnt[tile[k]], 1u)] = (uint16_t)(tid + k * QT_T);
         } else {
-            for (int i = tid; i < Sc; i += QT_T) perm[i] = (uint16_t)i;       // levels beyond 4096 tiles: list order
+            for (int i = tid; i < Sc; i += QT_T) perm[i] = (uint16_t)i;       // levels beyond QT_MAXT tiles: list order
         }
     }
     QT_MARK(4);
@@ -978,14 +1002,24 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, int level_first, int level_count,
-                        uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, int keep_points, hipStream_t s)
+                        uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, int keep_points, int small_lists_ok, hipStream_t s)
 {
     if (level_count <= 0) return;
     dim3 grid(level_count, batch, 1);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
-                       pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
-                       qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
+    // more workgroups than CUs and every list fits the small instance: two workgroups per CU (77 KB of LDS each) instead of rounds of 256
+    const bool small = small_lists_ok && (long long)level_count * batch > 256;
+    if (small)
+        hipLaunchKernelGGL((k_quadtree<QT_M_SMALL, 0>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
+                           pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
+                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
+    else
+        hipLaunchKernelGGL((k_quadtree<HS_QT_MAX_NODES, QT_PTS_BIG>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
+                           pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
+                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
 }
+
+// largest list the small instance holds (hs_api.hip: every level's quota + 8 must fit)
+int hs_quadtree_small_nodes() { return QT_M_SMALL; }
 
 // Host side of the geometric-key tables (see k_quadtree): the expressions of the kernel's former in-kernel build, evaluated once per
 // configuration.  hs_api.hip is compiled with -ffp-contract=off and IEEE division, like the device code, so the floats agree.

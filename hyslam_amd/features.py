@@ -172,8 +172,17 @@ class ORBExtractor:
                    np.zeros((b // 2, cap), np.float32) if stereo else None, np.zeros((b // 2, cap), np.float32) if stereo else None)
         n, kps, desc, uR, depth = out
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-        if kps.shape[1] < cap:
-            raise ValueError("wait(): the reused output arrays hold %d keypoints per frame, the ticket needs %d" % (kps.shape[1], cap))
+        # hs_orb_wait writes all five arrays in ONE [batch][c] layout: every reused array must have exactly that shape and dtype, or the C side
+        # would write out of bounds
+        c = kps.shape[1] if (isinstance(kps, np.ndarray) and kps.ndim == 2) else -1
+        want = [(n, (b,), np.int32), (kps, (b, c), KP_DTYPE), (desc, (b, c, 32), np.uint8)]
+        if stereo:
+            want += [(uR, (b // 2, c), np.float32), (depth, (b // 2, c), np.float32)]
+        for a, shape, dt in want:
+            if not isinstance(a, np.ndarray) or a.shape != shape or a.dtype != dt or not a.flags.c_contiguous or not a.flags.writeable:
+                raise ValueError("wait(): a reused output array does not have the ticket's layout (need %s %s, C-contiguous)" % (shape, np.dtype(dt).name))
+        if c < cap:
+            raise ValueError("wait(): the reused output arrays hold %d keypoints per frame, the ticket needs %d" % (c, cap))
         try:
             N.check(self._h, self._lib.hs_orb_wait(self._h, ticket, p(kps), p(desc), p(n), kps.shape[1], p(uR), p(depth)))
         except HsError as e:

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <future>
 #include <mutex>
@@ -28,6 +29,14 @@
 #include <string>
 #include <vector>
 #include "../../include/hyslam_amd.h"
+
+// helper threads of an extractor's descriptor scatter (0 = the calling thread alone; the environment variable HYSLAM_AMD_SCATTER_THREADS overrides).
+// Default 0: measured on the GPU box (2 x 2000 descriptors, two extractors side by side) 0 / 1 / 2 helpers = 0.145 / 0.144 / 0.145 ms — every
+// FeatureDescriptor construction copies the ONE shared_ptr<DescriptorDistance> all descriptors of an extractor share (FeatureDescriptor.cpp:6-10), and
+// with more than one thread that reference count bounces between cores: what the split saves, the contention costs.
+#ifndef HYSLAM_AMD_SCATTER_HELPERS
+#define HYSLAM_AMD_SCATTER_HELPERS 0
+#endif
 
 namespace HYSLAM {
 
@@ -146,8 +155,8 @@ public:
         _keypoints.resize(n);
         const size_t d0 = descriptors.size();
         descriptors.resize(d0 + n);                          // appended, like the reference (ORBExtractor.cpp:558-561)
-        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is two thirds of this call's wall time: two
-        // persistent helper threads of this extractor take a third of the range each (disjoint elements of pre-sized vectors, independent Mat allocations).
+        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is 40 % of this call's wall time.  Helper threads
+        // (HYSLAM_AMD_SCATTER_HELPERS) do not shorten it — see the note at that macro — so by default the calling thread does it alone.
         auto fill = [&](int a, int b) {
             for (int i = a; i < b; i++) {
                 cv::KeyPoint& k = _keypoints[i];
@@ -156,12 +165,13 @@ public:
                 descriptors[d0 + i] = FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + (size_t)i * HS_DESC_BYTES, HS_DESC_BYTES), dist_func);
             }
         };
-        if (n >= 512) {
-            const int a = n / 3, b = 2 * n / 3;
+        static const int n_helpers = [] { const char* e = std::getenv("HYSLAM_AMD_SCATTER_THREADS"); const int v = e ? std::atoi(e) : -1; return v >= 0 ? std::min(v, 2) : HYSLAM_AMD_SCATTER_HELPERS; }();
+        if (n >= 512 && n_helpers > 0) {
+            const int parts = n_helpers + 1, a = n / parts, b = n_helpers > 1 ? 2 * n / parts : n;
             helpers[0].run([&fill, a, b] { fill(a, b); });
-            helpers[1].run([&fill, b, n] { fill(b, n); });
-            try { fill(0, a); } catch (...) { try { helpers[0].wait(); } catch (...) {} try { helpers[1].wait(); } catch (...) {} throw; }      // the helpers hold references to this frame
-            helpers[0].wait(); helpers[1].wait();
+            if (n_helpers > 1) helpers[1].run([&fill, b, n] { fill(b, n); });
+            try { fill(0, a); } catch (...) { try { helpers[0].wait(); } catch (...) {} if (n_helpers > 1) { try { helpers[1].wait(); } catch (...) {} } throw; }      // the helpers hold references to this frame
+            helpers[0].wait(); if (n_helpers > 1) helpers[1].wait();
         } else fill(0, n);
         timing.scatter_ms = hip_detail::ms_since(t1);
     }

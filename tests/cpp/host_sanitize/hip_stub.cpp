@@ -21,6 +21,7 @@ long hip_stub_launches() { return g_launches.load(); }
 
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 hipError_t hipSetDevice(int) { return 0; }
+hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 hipError_t hipDeviceSynchronize() { return 0; }
 hipError_t hipGetLastError() { return 0; }
 const char* hipGetErrorString(hipError_t) { return "hip_stub"; }

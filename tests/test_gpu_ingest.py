@@ -94,6 +94,16 @@ def test_ticket_survives_a_failed_wait_and_can_be_cancelled(gpu):
     with pytest.raises(ValueError):
         ex.wait(t1, small)
     assert t1 in ex._tickets
+    # reused arrays whose shapes disagree with each other (hs_orb_wait writes ALL of them in one [batch][cap] layout), or of the wrong type or batch:
+    # refused before the C side can write out of bounds
+    big = cap1 + 8
+    for bad in ((np.zeros(2, np.int32), np.zeros((2, big), N.KP_DTYPE), np.zeros((2, 10, 32), np.uint8), None, None),            # descriptors too short
+                (np.zeros(2, np.int32), np.zeros((1, big), N.KP_DTYPE), np.zeros((1, big, 32), np.uint8), None, None),           # one frame short
+                (np.zeros(2, np.int64), np.zeros((2, big), N.KP_DTYPE), np.zeros((2, big, 32), np.uint8), None, None),           # counts of the wrong type
+                (np.zeros(2, np.int32), np.zeros((2, big), N.KP_DTYPE), np.zeros((2, big, 32), np.uint8)[:, ::1, ::-1], None, None)):   # not contiguous
+        with pytest.raises(ValueError):
+            ex.wait(t1, bad)
+    assert t1 in ex._tickets
     r1 = ex.wait(t1)                                                       # sized by the ticket's own capacity, not by the current geometry's
     assert r1[1].shape[1] == cap1
     for i, f in enumerate(a):

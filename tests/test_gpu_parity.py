@@ -124,11 +124,13 @@ def test_stereo_golden_and_identical_views(gpu):
 
 @pytest.mark.parametrize("w,h,nfeat,scale", [(643, 481, 700, 1.2), (320, 200, 500, 1.2), (800, 600, 1500, 1.4), (1024, 400, 6000, 1.2),
                                               (97, 83, 300, 1.2), (2562, 1441, 3000, 1.2), (3840, 2160, 3000, 1.2), (4000, 3000, 3000, 1.4),
-                                              (4096, 64, 500, 1.2)])
+                                              (4096, 64, 500, 1.2), (4000, 3000, 2000, 1.2), (1280, 720, 1000, 1.2), (1352, 1014, 3000, 1.4)])
 def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
     """odd widths (byte-wise tile loads at level 0), levels too small for a FAST cell, the 1.4 'Imaging' profile,
     a wide frame with three root nodes and a quota above 1300, frames with ~3900 and ~8800 cells at level 0 (one and several gather rounds in the
-    quadtree kernel), the 4000x3000 documentation camera of BASELINE config 4 with the reference's 'Imaging' settings (3000 features, 1.4), a 64:1 strip (127 root nodes, capacity beyond the generic bound)."""
+    quadtree kernel), the 4000x3000 documentation camera of BASELINE config 4 with the reference's 'Imaging' settings (3000 features, 1.4), a 64:1 strip (127 root nodes, capacity beyond the generic bound); the same 4000x3000 camera at 1.2 / 2000 features
+    ("also run at 1.2"), and the reference's OWN camera geometries with their feature profiles: the ZED-mini SLAM camera 1280x720 / 1000 @1.2 and
+    the GoPro Imaging camera 2704x2028 at scale 0.5 = 1352x1014 / 3000 @1.4 (config/sample_primary_config_file.yaml:35-38,63-66, config/slam_feature_config.yaml:8-29)."""
     stage_parity(synth_image(40 + w, w, h), nfeat, scale)
 
 
@@ -244,6 +246,21 @@ def test_fast_kernel_variants_in_subprocess(gpu, env):
     e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fast_variant_check.py")], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("env", [{"HS_QT_SMALL": "1"}, {"HS_QT_SMALL": "1", "HS_QT_POINT_DOMAIN": "1"}, {"HS_QT_SMALL": "1", "HS_FAST_KEYS_MAX_BATCH": "100000"}])
+def test_quadtree_two_per_cu_instance(gpu, monkeypatch, env):
+    """k_quadtree<1024, 0> — the instance without points in LDS, two workgroups per CU, for launches of more than 256 workgroups (HS_QT_SMALL=1; off by default:
+    measured slower) — on 40 frames x 8 levels = 320 workgroups: count domain after a gather, the point-domain passes forced, and with the FAST kernel's keys"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    frames = [synth_image(300 + i, 416, 320) if i % 7 else np.random.default_rng(i).integers(0, 256, (320, 416), dtype=np.uint8) for i in range(40)]
+    ex = HS.ORBExtractor(settings(900))
+    kl, dl = ex.extract_batch(frames)
+    p = oracle.default_params(900)
+    for i, f in enumerate(frames):
+        ok, od = oracle.extract(p, f)
+        assert_same_features(kl[i], dl[i], ok, od)
 
 
 def test_fast_thresholds_other_than_the_references_20(gpu):
