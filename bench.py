@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md); issue-rate fractions are quoted against it
 W, H, NFEAT = 1920, 1080, 2000
-PROFILE_TAG = "r04"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
+PROFILE_TAG = "r05"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
+DEFAULT_PAIRS = 64             # stereo pairs per step; tools/pmc_traffic.py and tools/summarize_profiles.py read this constant (HS_PROFILE_PAIRS overrides)
 
 
 def parse_args():
@@ -40,7 +41,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 16 pairs = 0.11 s of GPU work at the default)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=DEFAULT_PAIRS,
+                    help="stereo pairs per step (= per call of the stereo front end) per GPU.  Default 64 since round 5 (16 until round 4): a launch's duration is a fixed part "
+                         "(launch floor, ramp-up, the tail of the persistent FAST waves) + a part per frame — FAST: 26 us + 4.1 us per frame — so larger calls amortise more; "
+                         "profiles/README.md lists 1 / 2 / 4 / 8 / 16 / 32 / 64 pairs per call for every round")
     ap.add_argument("--distinct", type=int, default=4,
                     help="distinct synthetic pairs generated per rank; the batch holds --pairs separate copies (pair i = distinct pair i %% distinct), "
                          "so no two frames of a step share an address")
@@ -465,7 +469,7 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["end_to_end"]["moved_bytes_per_pair"] = int(moved_pair)
     out["end_to_end"]["frac_on_moved_bytes"] = round(value / world * moved_pair / 1e9 / HBM_PEAK_GBS, 5)
     if world == 1 and args.pcie_seconds > 0:
-        out["pcie_inclusive"] = pcie_inclusive(HS, exs[0], sp, pairs, B, args.pcie_seconds)
+        out["pcie_inclusive"] = pcie_inclusive(HS, exs[0], sp, pairs, min(B, 16), args.pcie_seconds)      # 16 pairs per ticket (two tickets in flight), whatever the step's batch
     if world == 1 and args.call_site:
         cs = call_site()
         if cs is not None:

@@ -17,7 +17,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GIB = 1 << 30
-PAIRS = 16
+def _default_pairs():
+    import re
+    m = re.search(r'^DEFAULT_PAIRS = (\d+)', open(os.path.join(ROOT, 'bench.py')).read(), re.M)
+    return int(os.environ.get('HS_PROFILE_PAIRS', m.group(1) if m else 16))
+
+
+PAIRS = _default_pairs()      # bench.py's default batch: the counter passes profile the launch shapes the bench line reports
 LANES = 1            # one launch sequence of 16 pairs per step: the launch shapes of bench.py's default (one handle)
 
 

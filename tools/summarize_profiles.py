@@ -26,7 +26,9 @@ def stamp(kernel):
 
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
-PAIRS, HANDLES = 16, 1          # bench.py defaults: 16 pairs per step on one handle -> every launch sequence covers 32 frames
+import re as _re
+_m = _re.search(r'^DEFAULT_PAIRS = (\d+)', open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')).read(), _re.M)
+PAIRS, HANDLES = int(os.environ.get('HS_PROFILE_PAIRS', _m.group(1) if _m else 16)), 1          # bench.py's defaults: PAIRS pairs per step on one handle -> every launch sequence covers 2 * PAIRS frames
 
 
 def first(pattern):
@@ -42,7 +44,7 @@ f = first("stats/**/*kernel_stats.csv")
 rows = list(csv.reader(open(f)))
 with open("profiles/%s_kernel_stats.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0\n")
-    o.write("# bench.py default: 16 stereo pairs of 1920x1080 per step on one handle -> every launch sequence covers 32 frames; MI355X; tag %s\n" % tag)
+    o.write("# bench.py default: %d stereo pairs of 1920x1080 per step on one handle -> every launch sequence covers %d frames; MI355X; tag %s\n" % (PAIRS, 2 * PAIRS, tag))
     w = csv.writer(o)
     for r in rows:
         r[0] = short(r[0])[:60]
@@ -81,7 +83,7 @@ n_seq = max([len(next(iter(d.values()))) for k, d in agg.items() if k.startswith
 sq = {}
 with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
     o.write("# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0\n")
-    o.write("# per-launch averages; bench.py default (one handle, 16 pairs): 32 frames of 1920x1080 per launch; MI355X; tag %s\n" % tag)
+    o.write("# per-launch averages; bench.py default (one handle, %d pairs): %d frames of 1920x1080 per launch; MI355X; tag %s\n" % (PAIRS, 2 * PAIRS, tag))
     o.write("kernel,launches," + ",".join(names) + "\n")
     for k, d in agg.items():
         n = len(next(iter(d.values())))
@@ -91,7 +93,7 @@ with open("profiles/%s_sq_counters.csv" % rnd, "w") as o:
 json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0`; per-launch averages",
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
-for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs2", "bench_pairs4", "bench_pairs8", "bench_pairs32", "bench_pairs64", "bench_handles2", "bench_handles3", "bench_under_rocprof",
+for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs2", "bench_pairs4", "bench_pairs8", "bench_pairs16", "bench_pairs32", "bench_pairs64", "bench_pairs128", "bench_handles2", "bench_handles3", "bench_under_rocprof", "bench16_under_rocprof",
              "bench_density3", "adaptor"):
     p = os.path.join(src, name + ".json")
     try:
@@ -134,7 +136,8 @@ def timeline(d, out):
 with open("profiles/%s_kernel_timeline.txt" % rnd, "w") as o:
     o.write("# rocprofv3 --kernel-trace of bench.py without stage events (--profile-steps 0): one step of the timed loop, tag %s\n" % tag)
     o.write("## --pairs 1 (one stereo pair per call)\n"); timeline("kt1", o)
-    o.write("## default (16 stereo pairs per call)\n"); timeline("kt16", o)
+    o.write("## 16 stereo pairs per call (the bench default until round 4)\n"); timeline("kt16", o)
+    o.write("## default (%d stereo pairs per call)\n" % PAIRS); timeline("kt64", o)
 for name in ("qt_phase_1080p", "qt_phase_4000x3000"):
     try:
         body = open(os.path.join(src, name + ".txt")).read()      # read FIRST: a missing source (no HS_QT_PROFILE build on the box) must not truncate the committed file
@@ -153,5 +156,27 @@ for name, head in (("fast_b1_timeline", "# tools/fast_b1_timeline.py 2 (HS_FAST_
         open("profiles/%s_%s.txt" % (rnd, name), "w").write(head + body)
     except OSError:
         pass
+# the 16-pair launch shape (bench default until round 4) for comparison with r03 / r04: kernel stats and SQ counters of `bench.py --pairs 16`
+f16 = first("stats16/**/*kernel_stats.csv")
+if f16:
+    with open("profiles/%s_kernel_stats_pairs16.csv" % rnd, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --pairs 16 --steps 20 --warmup 3 --cpu-seconds 0: 32 frames per launch (the default shape of rounds 2-4); tag %s\n" % tag)
+        w = csv.writer(o)
+        for r in csv.reader(open(f16)):
+            r[0] = short(r[0])[:60]
+            w.writerow(r)
+s16 = first("sq16/**/*counter_collection.csv")
+if s16:
+    agg16 = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(s16)):
+        k = short(r["Kernel_Name"])
+        if k.startswith("k_"):
+            agg16[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    names16 = sorted({c for d in agg16.values() for c in d})
+    with open("profiles/%s_sq_counters_pairs16.csv" % rnd, "w") as o:
+        o.write("# rocprofv3 --pmc SQ_* -- python3 bench.py --pairs 16 --steps 4 --warmup 1: per-launch averages, 32 frames per launch (comparable with r03 / r04); tag %s\n" % tag)
+        o.write("kernel,launches," + ",".join(names16) + "\n")
+        for k, d in agg16.items():
+            o.write(k.replace(",", ";") + "," + str(len(next(iter(d.values())))) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names16) + "\n")
 b = summary["bench"]
 print("value", b["value"], b["stage_ms_per_step"], b["roofline"])
