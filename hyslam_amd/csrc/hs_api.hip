@@ -924,8 +924,11 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
     // Frames: the runtime's own pageable-memory path (measured: packing the rows into a pinned buffer on the calling thread first is SLOWER —
     // one core copies 2 MB frames at ~10 GB/s, the runtime's staged copy moves them at more than twice that)
     for (int i = 0; i < batch; i++) if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
-    for (int i = 0; i < batch; i++)
-        HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < batch; i++) {
+        // a frame whose rows are as far apart as the staging copy's (width a multiple of 64, no padding: 1920 x 1080) is ONE linear copy
+        if ((size_t)stride == pitch) HIP_TRY(h, hipMemcpyAsync(h->d_in + per_img * i, imgs[i], per_img, hipMemcpyHostToDevice, s));
+        else HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
+    }
     HsImg0 img0{ h->d_in, h->d_in, batch, (uint64_t)pitch, (uint64_t)per_img };
     HsOut out{ h->d_kps, h->d_desc, h->d_n, h->d_kps, h->d_desc, h->d_n, batch, cap };
     rc = run_extract(h, img0, batch, out, s);
