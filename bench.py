@@ -423,16 +423,8 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
         parity["ok"] = None if all(f == 2 for f in flags) else all(f != 0 for f in flags)
         parity["ranks_checked"] = sum(f != 2 for f in flags)
         parity["ranks_failed"] = [r for r, f in enumerate(flags) if f == 0]
-    rccl = None
-    if world > 1:
-        # evidence for the first multi-GPU run: a throw-away RCCL communicator over all ranks through the C ABI (hs_comm_*), AFTER the timed loop —
-        # C2 itself needs no collective — reporting what RCCL says about it (ncclCommCount per rank) and that a 16-byte all-gather moved bytes
-        try:
-            from hyslam_amd.distributed import rccl_probe
-            rccl = rccl_probe(ex, rank, world, dev)
-        except Exception as e:
-            rccl = {"error": str(e)[:200]}
     if rank != 0:
+        rccl_probe_guarded(None, ex, rank, world, dev)
         return
     px = pyramid_pixels(ex, W, H)
     per_stage, per_frame = algorithmic_bytes(px, NFEAT)
@@ -455,8 +447,6 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     out["parity_checksum"] = {k: v for k, v in parity.items() if k != "ok"}
     out["per_rank_pairs_per_s"] = {"min": round(min(per_rank), 1), "max": round(max(per_rank), 1)}
     out["timed_region_ms"] = round(elapsed * 1e3, 1)
-    if rccl is not None:
-        out["rccl"] = rccl
     out["roofline"] = rls[dom]
     out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
     out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
@@ -476,7 +466,46 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
             out["call_site"] = cs
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
+    if world > 1:
+        rccl_probe_guarded(out, ex, rank, world, dev)      # prints the line (with the `rccl` block) itself
+        return
     print(json.dumps(out), flush=True)
+
+
+def rccl_probe_guarded(out, ex, rank, world, dev, timeout_s=60.0):
+    """N > 1, AFTER everything else: evidence for the first multi-GPU run — a throw-away RCCL communicator over all ranks through the C ABI (hs_comm_*;
+    C2 itself needs no collective), reporting what RCCL says about it (ncclCommCount per rank, version) and that a 16-byte all-gather moved bytes.
+    The measurement is complete when this runs, so it must not be able to take the line down: ncclCommInitRank has never run with more than one rank
+    anywhere (no multi-GPU node was available to this build), and if it blocks, a watchdog prints the line with an error note and ends every rank with
+    exit code 0.  Rank 0 passes the finished line as `out` and prints it; the other ranks pass None."""
+    import threading
+    lock, state = threading.Lock(), {"printed": False}
+
+    def emit(info):
+        with lock:
+            if state["printed"]:
+                return
+            state["printed"] = True
+            if out is not None:
+                out["rccl"] = info
+                print(json.dumps(out), flush=True)
+
+    def watchdog():
+        time.sleep(timeout_s)
+        with lock:
+            late = not state["printed"]
+        if late:
+            emit({"error": "the RCCL probe did not finish within %.0f s (the timed measurement above is complete)" % timeout_s})
+            sys.stdout.flush()
+            os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        from hyslam_amd.distributed import rccl_probe
+        info = rccl_probe(ex, rank, world, dev)
+    except Exception as e:
+        info = {"error": str(e)[:200]}
+    emit(info)
 
 
 def parity_checksum(rank, args, N, cap, kL, dL, nL, kR, dR, nR, uR, depth):

@@ -181,3 +181,36 @@ def test_verify_exchange_counts(lie):
     assert res[0]["records_identical"] is True and res[0]["record_counts"] == [20, 23]
     assert res[0]["ranks_consistent"] is (lie == 0) and res[0]["counts_match"] is (lie == 0)
     assert res[0]["match_checksums"][0] != res[0]["match_checksums"][1]
+
+
+@pytest.mark.parametrize("mode", ["ok", "raises", "hangs"])
+def test_the_rccl_probe_cannot_take_the_bench_line_down(mode):
+    """bench.py at N > 1 ends with a throw-away RCCL communicator (evidence of how many ranks RCCL itself saw).  ncclCommInitRank has never run with more
+    than one rank anywhere, so the probe is guarded: whatever it does — returns, raises, or blocks for ever — rank 0 prints its finished line exactly once
+    and the process ends with exit code 0 (rccl_probe_guarded: a watchdog prints the line with an error note and leaves)."""
+    code = r'''
+import importlib.util, json, sys, time
+spec = importlib.util.spec_from_file_location("bench", %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+import hyslam_amd.distributed as D
+mode = %r
+def fake(ex, rank, world, dev):
+    if mode == "raises": raise RuntimeError("ncclCommInitRank: unhandled system error")
+    if mode == "hangs": time.sleep(3600)
+    return {"version": 22203, "ranks_seen_by_rccl": [2, 2], "consistent": True}
+D.rccl_probe = fake
+b.rccl_probe_guarded({"metric": "m", "value": 1.0}, None, 0, 2, None, timeout_s=1.5)
+print("after", flush=True)
+''' % (os.path.join(ROOT, "bench.py"), mode)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0
+    if mode == "ok":
+        assert d["rccl"]["ranks_seen_by_rccl"] == [2, 2] and "after" in r.stdout
+    elif mode == "raises":
+        assert "unhandled system error" in d["rccl"]["error"] and "after" in r.stdout
+    else:
+        assert "did not finish" in d["rccl"]["error"] and "after" not in r.stdout
