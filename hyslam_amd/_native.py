@@ -72,7 +72,7 @@ EXPORTS = [
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
     "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait", "hs_orb_cancel", "hs_ticket_frames_copied",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_set_split", "hs_orb_synchronize",
-    "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_frame_publish", "hs_frame_find", "hs_frame_release", "hs_frame_info", "hs_search_by_projection_frame", "hs_stereo_match_frames", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
+    "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_frame_publish", "hs_frame_find", "hs_frame_release", "hs_frame_info", "hs_frame_cache_clear", "hs_search_by_projection_frame", "hs_stereo_match_frames", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
     "hs_vocab_last_error", "hs_vocab_load", "hs_vocab_from_tree", "hs_vocab_save", "hs_vocab_destroy", "hs_vocab_get_tree", "hs_vocab_info",
     "hs_vocab_upload", "hs_vocab_dev_destroy", "hs_vocab_dev_groups", "hs_bow_transform_device", "hs_records_bow_match_device", "hs_bow_transform", "hs_hamming_knn2", "hs_hamming_knn2_device",
     "hs_record_bytes", "hs_record_offsets", "hs_records_knn2_device",

@@ -1413,6 +1413,28 @@ int hs_frame_release(int device, hs_frame_token token)
     return HS_ERR_INVALID;
 }
 
+int hs_frame_cache_clear(int device)
+{
+    std::lock_guard<std::mutex> g(g_frames_mu);
+    for (size_t i = 0; i < g_frames.size(); i++) {
+        FrameCache* c = g_frames[i];
+        if (c->device != device) continue;
+        for (const FrameSlot& sl : c->slot) if (sl.readers > 0) return HS_ERR_INVALID;      // a call is reading a slot: not now
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        for (FrameSlot& sl : c->slot) {
+            if (sl.ready) { (void)hipEventSynchronize(sl.ready); (void)hipEventDestroy(sl.ready); }
+            (void)hipFree(sl.d_kps); (void)hipFree(sl.d_desc);
+        }
+        if (cur >= 0) (void)hipSetDevice(cur);
+        delete c;
+        g_frames.erase(g_frames.begin() + (long)i);
+        return HS_OK;
+    }
+    return HS_OK;      // nothing was ever published on that device
+}
+
 int hs_frame_info(int device, hs_frame_token token, int32_t* n)
 {
     std::lock_guard<std::mutex> g(g_frames_mu);

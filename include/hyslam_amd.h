@@ -253,7 +253,7 @@ int  hs_search_by_projection_device(hs_orb* h, const hs_frame_view* F, const hs_
  *                      first).  kps[n] = the keypoints the call returned for that image (kept beside the slot to recognise the frame later).
  *   hs_frame_find      hySLAM has no field that could carry a token through FeatureViews / Frame: a frame is recognised by its keypoint array
  *                      (exact comparison of all n records).  HS_ERR_INVALID when no live slot of `device` holds it.
- *   hs_frame_release   optional: give a slot back early.      hs_frame_info: its keypoint count.
+ *   hs_frame_release   optional: give a slot back early.      hs_frame_info: its keypoint count.      hs_frame_cache_clear: free a device's cache.
  *   hs_search_by_projection_frame   hs_search_by_projection with F->kps / F->desc taken from the cache (both may be NULL in *F; F->n must equal the
  *                      published count; F->uR / F->kp_lm_obs are host arrays as before: they change between calls).
  *   hs_stereo_match_frames          hs_stereo_match on two published frames (left, right).
@@ -264,6 +264,8 @@ int  hs_frame_publish(hs_orb* h, int image, const hs_keypoint* kps, int n, hs_fr
 int  hs_frame_find(int device, const hs_keypoint* kps, int n, hs_frame_token* token);
 int  hs_frame_release(int device, hs_frame_token token);
 int  hs_frame_info(int device, hs_frame_token token, int32_t* n);
+int  hs_frame_cache_clear(int device);  /* frees a device's cache (every token of it becomes unknown); HS_ERR_INVALID while a call is reading a slot.  The cache
+                                            otherwise lives as long as the process: call this before unloading the library or resetting the device */
 int  hs_search_by_projection_frame(hs_orb* h, hs_frame_token frame, const hs_frame_view* F, const hs_landmark* lms, int L, const hs_proj_params* pp,
                                    int32_t* match_idx, float* match_dist, int32_t* n_matches);
 int  hs_stereo_match_frames(hs_orb* h, hs_frame_token left, hs_frame_token right, const hs_stereo_params* sp, float* uRight, float* depth);

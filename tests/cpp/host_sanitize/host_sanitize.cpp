@@ -153,6 +153,84 @@ int main(int argc, char** argv)
         td.join(); tb.join();
     }
 
+    // ---- the frame cache (hs_frame_*): publish after an extraction, find by keypoints, the *_frame(s) entry points, release, slot reuse after 16
+    //      publishes, refusals (no extraction to publish, unknown tokens, a count that disagrees); then publishers, finders and consumers on four threads
+    {
+        hs_orb_params p; hs_orb_default_params(&p); p.nfeatures = 300;
+        hs_orb *ex = nullptr, *mh = nullptr;
+        CHECK(hs_orb_create(&p, 0, &ex) == HS_OK && hs_orb_create(&p, 0, &mh) == HS_OK);
+        const int w = 320, h = 240;
+        std::vector<uint8_t> img((size_t)w * h);
+        for (auto& v : img) v = (uint8_t)rng();
+        CHECK(hs_orb_reserve(ex, w, h, 1) == HS_OK);
+        const int cap = hs_orb_max_keypoints(ex);
+        std::vector<hs_keypoint> k(cap); std::vector<uint8_t> d((size_t)cap * 32); int32_t n = 0;
+        hs_frame_token tok = 0;
+        CHECK(hs_frame_publish(ex, 0, k.data(), 10, &tok) != HS_OK && tok == 0);                 // nothing extracted yet
+        CHECK(hs_orb_extract(ex, img.data(), w, h, w, k.data(), d.data(), cap, &n) == HS_OK);
+        // (the stub runs no kernels: fabricate a result of 40 keypoints to publish)
+        const int nk = 40;
+        for (int i = 0; i < nk; i++) k[i] = hs_keypoint{ 20.f + i, 30.f + 2 * i, 31.f, (float)i, 50.f, 0 };
+        CHECK(hs_frame_publish(ex, 1, k.data(), nk, &tok) != HS_OK);                              // image index beyond the call's batch
+        CHECK(hs_frame_publish(ex, 0, k.data(), cap + 1, &tok) != HS_OK);                         // more keypoints than the call could have produced
+        CHECK(hs_frame_publish(ex, 0, k.data(), nk, &tok) == HS_OK && tok != 0);
+        int32_t ninfo = 0; hs_frame_token found = 0;
+        CHECK(hs_frame_info(0, tok, &ninfo) == HS_OK && ninfo == nk);
+        CHECK(hs_frame_find(0, k.data(), nk, &found) == HS_OK && found == tok);
+        CHECK(hs_frame_find(0, k.data(), nk - 1, &found) != HS_OK && found == 0);
+        CHECK(hs_frame_find(1, k.data(), nk, &found) != HS_OK);                                    // another device's cache
+        { std::vector<hs_keypoint> k2(k.begin(), k.begin() + nk); k2[7].response += 1.f; CHECK(hs_frame_find(0, k2.data(), nk, &found) != HS_OK); }
+        hs_frame_view F; memset(&F, 0, sizeof(F));
+        F.fx = F.fy = 300.f; F.cx = 160.f; F.cy = 120.f; F.max_x = (float)w; F.max_y = (float)h; F.size_ref = 31.f; F.n = nk; F.Rcw[0] = F.Rcw[4] = F.Rcw[8] = 1.f;
+        std::vector<hs_landmark> lm(25); memset(lm.data(), 0, lm.size() * sizeof(hs_landmark));
+        for (size_t i = 0; i < lm.size(); i++) { lm[i].pos[2] = 5.f; lm[i].size = 0.5f; lm[i].max_dist = 100.f; lm[i].assoc_kp = -1; }
+        hs_proj_params pp; memset(&pp, 0, sizeof(pp)); pp.th = 3.f; pp.score_threshold = 100.f; pp.second_best_ratio = 0.8f; pp.frac_smaller = 0.5f; pp.frac_larger = 1.5f;
+        std::vector<int32_t> mi(lm.size()); std::vector<float> md(lm.size()); int32_t nm = -1;
+        CHECK(hs_search_by_projection_frame(mh, tok, &F, lm.data(), (int)lm.size(), &pp, mi.data(), md.data(), &nm) == HS_OK);
+        F.n = nk - 1;
+        CHECK(hs_search_by_projection_frame(mh, tok, &F, lm.data(), (int)lm.size(), &pp, mi.data(), md.data(), &nm) != HS_OK);      // count disagrees with the published frame
+        F.n = nk;
+        CHECK(hs_search_by_projection_frame(mh, tok + 1000, &F, lm.data(), (int)lm.size(), &pp, mi.data(), md.data(), &nm) != HS_OK);
+        hs_stereo_params sp{ 300.f, 36.f, h, 100.f, 50.f, 31.f };
+        std::vector<float> ur(nk), dz(nk);
+        CHECK(hs_stereo_match_frames(mh, tok, tok, &sp, ur.data(), dz.data()) == HS_OK);
+        CHECK(hs_stereo_match_frames(mh, tok, 0, &sp, ur.data(), dz.data()) != HS_OK);
+        CHECK(hs_frame_release(0, tok) == HS_OK && hs_frame_release(0, tok) != HS_OK && hs_frame_info(0, tok, &ninfo) != HS_OK);
+        // slot reuse: 17 more publishes of frames of different sizes (the slots' buffers grow) push the oldest out
+        CHECK(hs_frame_publish(ex, 0, k.data(), nk, &tok) == HS_OK);
+        for (int r = 0; r < 17; r++) { hs_frame_token t2 = 0; k[0].x = 500.f + r; CHECK(hs_frame_publish(ex, 0, k.data(), 1 + (r * 37) % cap, &t2) == HS_OK && t2 > tok); }
+        CHECK(hs_frame_info(0, tok, &ninfo) != HS_OK);
+        // four threads: two extractors publishing, one finder, one consumer (ASan: a slot freed or refilled under a reader fails the run)
+        hs_orb* ex2 = nullptr;
+        CHECK(hs_orb_create(&p, 0, &ex2) == HS_OK && hs_orb_reserve(ex2, w, h, 1) == HS_OK);
+        std::vector<hs_keypoint> kb(cap); std::vector<uint8_t> db((size_t)cap * 32); int32_t nb2 = 0;
+        CHECK(hs_orb_extract(ex2, img.data(), w, h, w, kb.data(), db.data(), cap, &nb2) == HS_OK);
+        std::atomic<int> stop{0}, bad{0}; std::atomic<uint64_t> latest{0};
+        auto publisher = [&](hs_orb* hx, int salt) {
+            std::vector<hs_keypoint> kk(nk);
+            for (int it = 0; it < 400; it++) {
+                for (int i = 0; i < nk; i++) kk[i] = hs_keypoint{ (float)(salt + it), (float)i, 31.f, 0.f, 1.f, 0 };
+                hs_frame_token t = 0;
+                const int st = hs_frame_publish(hx, 0, kk.data(), 1 + (it * 7 + salt) % nk, &t);
+                if (st == HS_OK) latest.store(t); else if (st != HS_ERR_CAPACITY) bad++;
+            }
+        };
+        std::thread t1(publisher, ex, 1000), t2(publisher, ex2, 5000);
+        std::thread t3([&] { std::vector<hs_keypoint> kk(nk); while (!stop.load()) { for (int i = 0; i < nk; i++) kk[i] = hs_keypoint{ 1000.f + (float)(rng() % 400), (float)i, 31.f, 0.f, 1.f, 0 }; hs_frame_token t = 0; (void)hs_frame_find(0, kk.data(), 1 + (int)(rng() % nk), &t); } });
+        std::thread t4([&] {
+            hs_frame_view G = F; std::vector<int32_t> mi2(lm.size()); std::vector<float> md2(lm.size()); int32_t nm2 = 0;
+            while (!stop.load()) {
+                const hs_frame_token t = latest.load(); int32_t cnt = 0;
+                if (t && hs_frame_info(0, t, &cnt) == HS_OK) { G.n = cnt; const int st = hs_search_by_projection_frame(mh, t, &G, lm.data(), (int)lm.size(), &pp, mi2.data(), md2.data(), &nm2); if (st != HS_OK && st != HS_ERR_INVALID) bad++; }
+            }
+        });
+        t1.join(); t2.join(); stop.store(1); t3.join(); t4.join();
+        CHECK(bad.load() == 0);
+        hs_orb_destroy(ex); hs_orb_destroy(ex2); hs_orb_destroy(mh);
+        CHECK(hs_frame_cache_clear(0) == HS_OK && hs_frame_cache_clear(0) == HS_OK && hs_frame_cache_clear(3) == HS_OK);      // (LeakSanitizer: nothing of the cache may outlive this)
+        CHECK(hs_frame_info(0, latest.load(), &ninfo) != HS_OK);
+    }
+
     // ---- vocabulary files: valid round trips, then truncations and random corruptions of both formats
     char dir[] = "/tmp/hs_host_sanitize_XXXXXX";
     CHECK(mkdtemp(dir) != nullptr);
