@@ -209,7 +209,7 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
 void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/);
 int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kernel launches of one hs_launch_pyramid call
 int hs_fast_group_cells(int wcell, int ncols, int lc);   // cells per FAST work item for a level (0 when the level has no cells); lc = 6 / 5: wide / narrow tiles
-int hs_fast_max_cell_w(int lc);                          // widest FAST cell the kernel's tile holds (247 px wide tiles, 119 px narrow ones)
+int hs_fast_max_cell_w(int lc);                          // widest FAST cell the kernel's tile holds at any offset (247 px wide tiles, 119 px narrow ones)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
 #define HS_FAST_NQ_MAX 32          // work queues of the FAST kernel: 8, 16 or 32 (kernels_fast.hip: FastSched)
 #define HS_FAST_QUEUE_DWORDS (32 * HS_FAST_NQ_MAX)   // head of the FAST overflow buffer: FOUR rotating sets of up to 32 work-queue counters on 128-byte lines of their own

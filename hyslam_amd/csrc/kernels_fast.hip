@@ -8,7 +8,7 @@
 //     (cv::FAST zero-fills its score rows and never scores the 3 px frame of the Mat it is given);
 //   * score = max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1 over the 16 arcs of length 9.
 //
-// MI355X mapping (k_fast_rows).  The unit of work is a ROW GROUP: up to 8 horizontally adjacent cells of one cell row (<= 247 px of
+// MI355X mapping (k_fast_rows).  The unit of work is a ROW GROUP: up to 8 horizontally adjacent cells of one cell row (<= 250 px of
 // interior), one single-wave workgroup per item, persistent launch, 11 workgroups per CU (14 KB of LDS each).  With ~1 % corners a
 // single 31x31 cell leaves a wave's lanes mostly idle after the first pass and pays the per-cell bookkeeping 6342 times per frame;
 // measured on 32 frames of 1080p the first design (one wave per cell: 0.48 ms, ~1.26 issued instructions per pixel, issue-bound at
@@ -787,19 +787,35 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
 #endif
 }
 
-// cells per work item for a level: as many as fit the tile (interior <= 4*COLS - 9 px, <= FR_MAXG), spread evenly over the row
-// Tile width: LC = 6 (64 dwords: items of <= 8 cells / 247 px of interior; the throughput shape) or LC = 5 (32 dwords: <= 119 px, two half-waves
-// on different rows).  A handle keeps BOTH item lists; the launcher picks per call (hs_api.hip: narrow items for small batches, where the
-// launch lasts as long as its slowest wave and twice as many, half as long items are what shortens it).
-int hs_fast_max_cell_w(int lc) { return 4 * (1 << lc) - 9; }
+// Cells per work item for a level: as many as fit the tile (<= FR_MAXG), spread evenly over the row.  A tile row holds 4*COLS bytes starting at the
+// item's first column rounded DOWN to a dword (a0 = iniX & ~3: the staging loads are dword-aligned), so an item of n cells fits when
+//     (iniX & 3) + n * wcell + 6 <= 4*COLS        for every item of the row (iniX = HS_BORDER + first cell * wcell)
+// and its corners fit the score tile's 8-bit column (one spare column per cell: column = 1 + px + cell <= 255).  Round 5: the test is made with
+// the items' REAL offsets instead of the worst one (3): the standard geometry (cells of 31 px) takes 8 cells per item instead of 7 — 8 * 31 is
+// a multiple of 4, every item starts on a dword — which is 12 % fewer items per frame (861 instead of 975 at 1080p / 1.2), each scanning the
+// same 256 columns: the lanes of a scan block that hold interior pixels go from 86 % to 97 %.
+// Tile width: LC = 6 (64 dwords: the throughput shape) or LC = 5 (32 dwords, two half-waves on different rows).  A handle keeps BOTH item lists;
+// the launcher picks per call (hs_api.hip: narrow items for small batches, where the launch lasts as long as its slowest wave and twice as many,
+// half as long items are what shortens it).
+int hs_fast_max_cell_w(int lc) { return 4 * (1 << lc) - 9; }      // a single cell at the worst offset
 int hs_fast_group_cells(int wcell, int ncols, int lc)
 {
     if (wcell <= 0 || ncols <= 0) return 0;
-    const int iw_max = 4 * (1 << lc) - 9;
-    int gmax = std::min(FR_MAXG, iw_max / wcell);
-    if (gmax < 1) gmax = 1;                                   // cannot happen: configure() rejects wcell > hs_fast_max_cell_w(6) and builds no narrow list for wcell > hs_fast_max_cell_w(5)
-    const int ngroups = (ncols + gmax - 1) / gmax;
-    return (ncols + ngroups - 1) / ngroups;
+    const int tile_w = 4 * (1 << lc);
+    auto fits = [&](int g) {
+        if (g * wcell + g > 256) return false;                                   // score tile column 1 + px + cell of the last corner
+        for (int j0 = 0; j0 < ncols; j0 += g) {
+            const int n = std::min(g, ncols - j0);
+            if (((HS_BORDER + j0 * wcell) & 3) + n * wcell + 6 > tile_w) return false;
+        }
+        return true;
+    };
+    const int gcap = std::max(1, std::min(FR_MAXG, (tile_w - 6) / wcell));
+    for (int ngroups = (ncols + gcap - 1) / gcap; ngroups <= ncols; ngroups++) {
+        const int g = (ncols + ngroups - 1) / ngroups;                              // even spread over `ngroups` items
+        if (fits(g)) return g;
+    }
+    return 1;                                                                       // configure() rejects wcell > hs_fast_max_cell_w(6) and builds no narrow list for wcell > hs_fast_max_cell_w(5)
 }
 
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
@@ -881,7 +897,7 @@ static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs, int lc
     L.total = (o + 15) & ~15;
     c.per_cu = std::max(1, std::min(16, LDS_CU / ((L.total + GRAN - 1) / GRAN * GRAN)));
     if (knobs.wg_per_cu > 0) c.per_cu = std::max(1, std::min(c.per_cu, knobs.wg_per_cu));
-    c.ovf_stride = (uint32_t)((4 * cols - 9) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
+    c.ovf_stride = (uint32_t)((4 * cols - 6) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
     return c;
 }
 // workgroups of a launch over `total_work` items (non-decreasing in total_work)
