@@ -213,7 +213,7 @@ int hs_fast_max_cell_w(int lc);                          // widest FAST cell the
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
 #define HS_FAST_NQ_MAX 32          // work queues of the FAST kernel: 8, 16 or 32 (kernels_fast.hip: FastSched)
 #define HS_FAST_QUEUE_DWORDS (32 * HS_FAST_NQ_MAX)   // head of the FAST overflow buffer: FOUR rotating sets of up to 32 work-queue counters on 128-byte lines of their own
-struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b, image_major, nq, cols, narrow_max, no_fold; };   // HS_FAST_* test / tuning knobs, read once per handle
+struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b, image_major, nq, cols, narrow_max, no_fold, list_min; };   // HS_FAST_* test / tuning knobs, read once per handle
 HsFastKnobs hs_fast_read_knobs();
 bool hs_launch_fast(const HsLevel* d_lv, const HsFastItem* d_items, int nlevels, HsImg0 img0, int batch, int total_cells, int items_per_img, int fast_th,
                     uint2* cand /*{y<<16|x, score<<24|cell} per slot*/, int32_t* cell_count, uint64_t cand_img_stride,

@@ -134,7 +134,10 @@ __device__ __forceinline__ uint32_t fr_field_flags(us2 s, uint32_t ones)
     return r;
 }
 
-struct FastRowsLds { int32_t off_plist, off_pscore, off_cnt, pcap, total; };
+// LDS of a workgroup: [0, th * PITCH) the item's pixel tile (later its score tile) | the pixel list of THIS item — 2 bytes of position + 1 byte of score per
+// entry, as many entries as fit before the counters: an item of fewer rows than the tallest one of the launch has the longer list (round 5) | [off_cnt, total)
+// the per-cell counters.  pcap_max: tuning / test cap on the list length (HS_FAST_PCAP, HS_FAST_TEST_SMALL_LISTS).
+struct FastRowsLds { int32_t off_cnt, pcap_max, pcap_min, total; };
 
 struct RowGeom {            // wave-uniform description of one work item in one image
     int img;
@@ -275,8 +278,10 @@ __device__ __forceinline__ int wave_scan_incl(int x)
 // KEYS: the quadtree's geometric keys are produced by this launch (calls of <= 16 frames: hs_api.hip).  A template parameter, not a runtime
 // flag: the large-batch instantiation pays neither registers nor instructions for a path it never runs (round 4 carried it as a runtime
 // flag: 139 -> 147 VGPRs and +1 M wave-instructions per 32 frames for nothing).
+// Launch bounds: the narrow instances of the standard tile heights run 16 workgroups per CU, which 4 waves per SIMD = 128 VGPRs must allow (the
+// per-item list placement of round 5 took the keyed one to 132 without the hint: 12 per CU, +20 % at one pair per call); the others are bound by LDS.
 template <int LC, int TR, bool KEYS>
-__global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
+__global__ __launch_bounds__(64, (LC == 5 && TR <= 44 ? 4 : 1)) void k_fast_rows(const HsFastItem* __restrict__ items, HsImg0 img0, int fast_th,
                                                   uint2* __restrict__ cand,
                                                   int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
                                                   int total_cells, int items_per_img, int total_work, FastRowsLds lds, int force_scan_b,
@@ -295,8 +300,6 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const tile = smem;
     uint8_t* const score = smem;                                                 // the score tile REUSES the pixel tile once every corner is scored
-    uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + lds.off_plist);   // pixel entries: row<<8 | column (| 0x8000)
-    uint8_t* const pscore = smem + lds.off_pscore;                               // score of corner i of the list
     uint32_t* const cellcnt = reinterpret_cast<uint32_t*>(smem + lds.off_cnt);   // survivors per cell of the item
     uint32_t* const queue = overflow + (size_t)(epoch & 3) * HS_FAST_QUEUE_DWORDS;   // 8 work counters, 128 bytes apart
     if (blockIdx.x == 0 && threadIdx.x < HS_FAST_NQ_MAX) overflow[(size_t)((epoch + 2) & 3) * HS_FAST_QUEUE_DWORDS + threadIdx.x * 32] = 0u;
@@ -416,6 +419,11 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         FR_ACC(0, t0, t1);
         FR_W(1);
         const RowGeom cur = g;
+        // the item's pixel list starts where its tile ends (rows th .. TR of the tile region are not used by this item)
+        const int list_off = cur.th * PITCH;
+        const int pcap = min(lds.pcap_max, (int)((((uint32_t)(lds.off_cnt - list_off) * 43691u) >> 17) & ~15u));      // floor(bytes / 3) entries, a multiple of 16
+        uint16_t* const plist = reinterpret_cast<uint16_t*>(smem + list_off);        // pixel entries: row<<8 | column (| 0x8000)
+        uint8_t* const pscore = smem + list_off + 2 * pcap;                          // score of corner i of the list
         const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1;
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
         // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                 // iteration itself (whose lanes already cover the list end) and a full list run the second test in place.
                 const bool redoA = actA && dark_okA && bright_okA && !cornerA && !redo_darkA, redoB = actB && dark_okB && bright_okB && !cornerB && !redo_darkB;
                 if (__any(redoA || redoB)) {
-                    if (i0 + 128 < nend && nend + 128 <= lds.pcap) {
+                    if (i0 + 128 < nend && nend + 128 <= pcap) {
                         const int slotA = wave_append(redoA, nend);
                         if (redoA) plist[slotA] = (uint16_t)(codeA | 0x8000);
                         const int slotB = wave_append(redoB, nend);
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         // make room for `need` more scan codes: score what is pending (corners are ~1/3 of the codes); spill only if that is not enough
         auto make_room = [&](int need) {
             corners_and_scores();
-            if (npx + need > lds.pcap) spill_corners();
+            if (npx + need > pcap) spill_corners();
         };
 
         // ---- pixel list (score tile coordinates) -> strict 3x3 NMS -> the cells' slots, in no particular order (the quadtree kernel
@@ -611,8 +619,8 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
             const int incl = wave_scan_incl((int)__popc(M));
             const int total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0) return;
-            if (npx + total > lds.pcap) { if (scores) nms_and_emit(); else make_room(min(total, lds.pcap)); }
-            if (total <= lds.pcap) {
+            if (npx + total > pcap) { if (scores) nms_and_emit(); else make_room(min(total, pcap)); }
+            if (total <= pcap) {
                 int pos = npx + incl - (int)__popc(M);
                 while (M) {
                     const int b = __ffs((int)M) - 1;
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
                     uint32_t Mr = M & (scores ? (0xFu << (4 * r)) : (0x01010101u << r));
                     const int incl_r = wave_scan_incl((int)__popc(Mr));
                     const int total_r = __builtin_amdgcn_readlane(incl_r, 63);      // <= 256 <= pcap
-                    if (npx + total_r > lds.pcap) { if (scores) nms_and_emit(); else make_room(total_r); }
+                    if (npx + total_r > pcap) { if (scores) nms_and_emit(); else make_room(total_r); }
                     int pos = npx + incl_r - (int)__popc(Mr);
                     while (Mr) {
                         const int b = __ffs((int)Mr) - 1;
@@ -701,10 +709,13 @@ __global__ __launch_bounds__(64) void k_fast_rows(const HsFastItem* __restrict__
         if (FR_STOP <= 4) n_done = 0;
         // ---- the pixel tile is dead: its LDS becomes the dense score tile (rows 0..ih+1, zero except at the corners)
         if (FR_STOP > 4) {
-            if constexpr (TR <= 54) {                            // the whole tile region with compile-time offsets: 11 stores for TR = 40, no loop arithmetic
+            if constexpr (TR <= 54) {                            // rows 0 .. ih+1 = th-5 in chunks of 1 KB at compile-time offsets; never into the list, which starts at
+                const int zbytes = (cur.ih + 2) * PITCH;         // row th and is live here (wide tiles: a chunk is shorter than the four rows in between)
 #pragma unroll
-                for (int k = 0; k < (TR * PITCH + 1023) / 1024; k++)
-                    if (1024 * (k + 1) <= TR * PITCH || 1024 * k + 16 * tid < TR * PITCH) *reinterpret_cast<uint4*>(score + 1024 * k + 16 * tid) = make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < ((TR - 4) * PITCH + 1023) / 1024; k++) {
+                    if constexpr (4 * PITCH >= 1024) { if (1024 * k < zbytes) *reinterpret_cast<uint4*>(score + 1024 * k + 16 * tid) = make_uint4(0, 0, 0, 0); }          // wave-uniform test
+                    else { if (1024 * k + 16 * tid < zbytes) *reinterpret_cast<uint4*>(score + 1024 * k + 16 * tid) = make_uint4(0, 0, 0, 0); }                          // narrow tiles: four rows are less than a chunk
+                }
             } else {
                 for (int i = tid * 16; i < (cur.ih + 2) * PITCH; i += 64 * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
             }
@@ -851,7 +862,8 @@ void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
 HsFastKnobs hs_fast_read_knobs()
 {
     HsFastKnobs k{};
-    if (const char* e = getenv("HS_FAST_PCAP")) k.pcap = atoi(e);                         // tuning: list capacity
+    if (const char* e = getenv("HS_FAST_PCAP")) k.pcap = atoi(e);                         // tuning: cap on the list length
+    if (const char* e = getenv("HS_FAST_LIST_MIN")) k.list_min = atoi(e);                 // tuning: list entries the tallest item must keep (decides the workgroups per CU; 1024 = round 4's layout)
     if (const char* e = getenv("HS_FAST_TEST_SMALL_LISTS")) k.small_lists = atoi(e) != 0; // parity tests: force the spill paths
     if (const char* e = getenv("HS_FAST_WG_PER_CU")) k.wg_per_cu = atoi(e);               // tuning: workgroups per CU
     if (const char* e = getenv("HS_FAST_TEST_SCAN_B")) k.force_scan_b = atoi(e) != 0;     // parity tests: NMS from the score tile
@@ -870,31 +882,29 @@ static FastRowsCfg fast_rows_cfg(int max_hcell, const HsFastKnobs& knobs, int lc
     FastRowsCfg c;
     c.lc = lc;
     const int cols = 1 << c.lc, pitch = 4 * cols + FR_PAD;
-    // Tile rows = the tallest tile.  The last scan block of a lane may read up to 7 rows past it: that stays inside the workgroup's
-    // LDS (the lists follow) and those rows are masked out.  Template instances below.
+    // Tile rows = the tallest tile of the launch (template instances below).
     const int th_max = max_hcell + 6;
     c.tr = th_max <= 38 ? 38 : th_max <= 40 ? 40 : th_max <= 44 ? 44 : th_max <= 54 ? 54 : th_max <= 70 ? 70 : th_max <= 102 ? 102 : 134;
     FastRowsLds& L = c.lds;
-    // LDS is granted in 1280-byte granules on gfx950 (160 KB / 128): a workgroup of 13 216 bytes occupies 14 080, and a persistent grid
-    // sized for more workgroups per CU than really fit runs its surplus in a second round (measured: +25 % kernel time).  The list
-    // capacity takes whatever the last granule leaves.
+    // LDS is granted in 1280-byte granules on gfx950 (160 KB / 128), and a persistent grid sized for more workgroups per CU than really fit runs its
+    // surplus in a second round (measured: +25 % kernel time).  The kernel is latency-bound — measured at 6 / 8 / 11 workgroups per CU (wide items, 128
+    // frames): 0.801 / 0.661 / 0.546 ms = 0.240 + 3.37 / n — so a workgroup more per CU is worth more than a long list as long as the list of the
+    // TALLEST item keeps `min_entries` (a list of 624 instead of 1056 entries cost 4 % at equal occupancy, one of 800 1.6 %: shorter items, whose
+    // list starts where their tile ends, keep 800-900).  Wide tiles of 40 rows: 10 granules = 12 800 bytes = 12 per CU (round 4: 14 080 = 11).
     constexpr int GRAN = 1280, LDS_CU = 160 * 1024;
-    const int fixed = c.tr * pitch + 4 * FR_MAXG;             // pixel tile (later the score tile: rows 0..ih+1 <= th-4) + per-cell counters
-    const int floor_bytes = std::max(fixed + 3 * 1024, (c.tr + 8) * pitch);   // >= 1024 list entries; the over-read of the last scan block stays inside
-    int granules = (floor_bytes + GRAN - 1) / GRAN;
-    while (LDS_CU / (granules * GRAN) > 16 && LDS_CU / ((granules + 1) * GRAN) >= 16) granules++;      // at most 16 workgroups per CU anyway (narrow tiles): the list takes the LDS that would stay unused
-    L.pcap = ((granules * GRAN - fixed) / 3) & ~15;           // 2 bytes position + 1 byte score per entry; >= 4*cols (one tile row of pixels)
+    const int cnt_bytes = 4 * FR_MAXG;
+    const int rs = 64 / cols, blk_rows = 8 * rs;
+    const int over_rows = blk_rows * ((c.tr - 6 + blk_rows - 1) / blk_rows) + 6;      // the last scan block of a lane reads whole blocks: up to this many tile rows (the extra ones are masked out)
     // floor: one row step of a scan block (64 lanes x 4 pixels, whatever the tile width) must fit an empty list — the scored corners leave
     // their scores in `pscore` while the rest of the list is still being read, so the list may never run past its end
-    if (knobs.pcap > 0) L.pcap = std::max(256, knobs.pcap & ~15);
-    if (knobs.small_lists) L.pcap = 256;
-    int o = c.tr * pitch;
-    L.off_plist = o; o += L.pcap * 2;
-    L.off_pscore = o; o += L.pcap;
-    o = (o + 3) & ~3;
-    L.off_cnt = o; o += 4 * FR_MAXG;
-    o = std::max(o, (c.tr + 8) * pitch);
-    L.total = (o + 15) & ~15;
+    const int min_entries = std::max(256, knobs.list_min > 0 ? knobs.list_min : 608);
+    const int floor_bytes = std::max(c.tr * pitch + 3 * (min_entries + 16) + cnt_bytes, over_rows * pitch);
+    int granules = (floor_bytes + GRAN - 1) / GRAN;
+    while (LDS_CU / (granules * GRAN) > 16 && LDS_CU / ((granules + 1) * GRAN) >= 16) granules++;      // at most 16 workgroups per CU anyway (narrow tiles: 4 waves per SIMD by registers): the list takes the LDS that would stay unused
+    L.total = granules * GRAN;
+    L.off_cnt = L.total - cnt_bytes;
+    L.pcap_min = ((L.off_cnt - c.tr * pitch) / 3) & ~15;       // list entries of the tallest item (2 bytes position + 1 byte score each)
+    L.pcap_max = knobs.small_lists ? 256 : knobs.pcap > 0 ? std::max(256, knobs.pcap & ~15) : (1 << 20);
     c.per_cu = std::max(1, std::min(16, LDS_CU / ((L.total + GRAN - 1) / GRAN * GRAN)));
     if (knobs.wg_per_cu > 0) c.per_cu = std::max(1, std::min(c.per_cu, knobs.wg_per_cu));
     c.ovf_stride = (uint32_t)((4 * cols - 6) * std::max(max_hcell, 1));       // every interior pixel of an item a corner
