@@ -417,9 +417,11 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     HIP_TRY(h, hipMemcpy(h->d_lv, h->lv.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_lv + L, h->lv_n.data(), sizeof(HsLevel) * L, hipMemcpyHostToDevice));
     {
-        auto upload_items = [&](const std::vector<HsLevel>& lv, int n_items, HsFastItem** d_out) -> hipError_t {
+        bool items_fit = true;                                 // every item against the tile the kernel stages it into (hs_fast_item_fits: columns, score-tile column, cells)
+        auto upload_items = [&](const std::vector<HsLevel>& lv, int n_items, HsFastItem** d_out, int lc) -> hipError_t {
             std::vector<HsFastItem> fi(std::max(n_items, 1));
             hs_fast_build_items(lv.data(), L, fi.data());
+            for (int i = 0; i < n_items; i++) items_fit = items_fit && hs_fast_item_fits(fi[i], lc);
             if (h->fast_order == 2 && L > 2) {                 // experiment: the reduced levels interleaved in proportion (every stretch of the list has the same mix of levels), level 0 last
                 const int n_red = lv[0].item_begin;
                 std::vector<std::pair<double, int>> key(n_red);
@@ -435,8 +437,9 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
             if (e != hipSuccess) return e;
             return hipMemcpy(*d_out, fi.data(), fi.size() * sizeof(HsFastItem), hipMemcpyHostToDevice);
         };
-        HIP_TRY(h, upload_items(h->lv, items, &h->d_fast_items));
-        if (h->fast_items_n > 0) HIP_TRY(h, upload_items(h->lv_n, h->fast_items_n, &h->d_fast_items_n));
+        HIP_TRY(h, upload_items(h->lv, items, &h->d_fast_items, 6));
+        if (h->fast_items_n > 0) HIP_TRY(h, upload_items(h->lv_n, h->fast_items_n, &h->d_fast_items_n, 5));
+        if (!items_fit) return fail(h, HS_ERR_INVALID, "internal: a FAST work item does not fit its tile (hs_fast_group_cells); geometry refused");
         HIP_TRY(h, hipMalloc(&h->d_fast_ovf, std::max<size_t>(hs_fast_overflow_bytes(h->max_hcell, std::max(items, h->fast_items_n) * batch, h->fast_knobs), 256)));
         HIP_TRY(h, hipMemsetAsync(h->d_fast_ovf, 0, 4 * HS_FAST_QUEUE_DWORDS * 4, h->stream));       // all four work-queue counter sets start at zero (stream-ordered before the first launch)
     }

@@ -211,6 +211,7 @@ int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kerne
 int hs_fast_group_cells(int wcell, int ncols, int lc);   // cells per FAST work item for a level (0 when the level has no cells); lc = 6 / 5: wide / narrow tiles
 int hs_fast_max_cell_w(int lc);                          // widest FAST cell the kernel's tile holds at any offset (247 px wide tiles, 119 px narrow ones)
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out /*[sum ngroups*nrows]*/);
+bool hs_fast_item_fits(const HsFastItem& it, int lc);    // the item against the tile k_fast_rows<lc, ...> stages it into
 #define HS_FAST_NQ_MAX 32          // work queues of the FAST kernel: 8, 16 or 32 (kernels_fast.hip: FastSched)
 #define HS_FAST_QUEUE_DWORDS (32 * HS_FAST_NQ_MAX)   // head of the FAST overflow buffer: FOUR rotating sets of up to 32 work-queue counters on 128-byte lines of their own
 struct HsFastKnobs { int pcap, small_lists, wg_per_cu, force_scan_b, image_major, nq, cols, narrow_max, no_fold, list_min; };   // HS_FAST_* test / tuning knobs, read once per handle

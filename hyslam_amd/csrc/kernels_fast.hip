@@ -829,6 +829,15 @@ int hs_fast_group_cells(int wcell, int ncols, int lc)
     return 1;                                                                       // configure() rejects wcell > hs_fast_max_cell_w(6) and builds no narrow list for wcell > hs_fast_max_cell_w(5)
 }
 
+// what k_fast_rows assumes of an item: its tile row (offset + interior + 6 px of apron) inside the 4 << lc bytes of an LDS row, at most FR_MAXG cells, the last
+// corner's score-tile column (1 + px + cell) in 8 bits, at most 64 dwords per row.  Checked for every item when a geometry is configured (hs_api.hip).
+bool hs_fast_item_fits(const HsFastItem& it, int lc)
+{
+    if (it.th == 0) return true;                                                 // yields nothing; staged from (0, 0)
+    const int tile_w = 4 << lc;
+    return it.off < 4 && (int)it.off + (int)it.iw + 6 <= tile_w && (int)it.ndw * 4 <= tile_w && it.ncell >= 1 && it.ncell <= FR_MAXG && (int)it.iw + (int)it.ncell <= 256;
+}
+
 void hs_fast_build_items(const HsLevel* h_lv, int nlevels, HsFastItem* out)
 {
     for (int l = 0; l < nlevels; l++) {

@@ -35,6 +35,7 @@ static int geometry_case(int w, int h, int nfeat, float scale, int levels, int c
     if (st != HS_OK) return 0;                                   // rejected parameter combinations (quota > LDS list, ...) are fine: no crash is the point
     st = hs_orb_reserve(ex, w, h, batch);
     int ok = 0;
+    if (st != HS_OK && std::strstr(hs_orb_last_error(ex), "internal:")) { printf("reserve %dx%d: %s\n", w, h, hs_orb_last_error(ex)); return -1; }   // a refusal is fine, a failed self-check is not
     if (st == HS_OK) {
         ok = 1;
         int32_t plan[8]; hs_debug_plan_summary(ex, plan);
