@@ -153,6 +153,14 @@ def lib():
     L.hs_frame_grid.argtypes = [vp, C.POINTER(FrameView), vp]
     L.hs_search_by_projection.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
     L.hs_search_by_projection_device.argtypes = [vp, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp, vp]
+    u64 = C.c_uint64
+    L.hs_frame_publish.argtypes = [vp, C.c_int, vp, C.c_int, C.POINTER(u64)]
+    L.hs_frame_find.argtypes = [C.c_int, vp, C.c_int, C.POINTER(u64)]
+    L.hs_frame_release.argtypes = [C.c_int, u64]
+    L.hs_frame_info.argtypes = [C.c_int, u64, vp]
+    L.hs_frame_cache_clear.argtypes = [C.c_int]
+    L.hs_search_by_projection_frame.argtypes = [vp, u64, C.POINTER(FrameView), vp, C.c_int, C.POINTER(ProjParams), vp, vp, vp]
+    L.hs_stereo_match_frames.argtypes = [vp, u64, u64, C.POINTER(StereoParams), vp, vp]
     L.hs_search_by_projection_sim3.argtypes = [vp, C.POINTER(FrameView), vp, vp, C.c_int, C.c_int, f32, vp, vp, vp]
     L.hs_search_by_sim3.argtypes = [vp, C.POINTER(FrameView), vp, C.POINTER(FrameView), vp, f32, vp, vp, f32, f32, vp, vp]
     L.hs_search_by_bow.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,

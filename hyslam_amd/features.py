@@ -66,6 +66,7 @@ class ORBExtractor:
             self._h = C.c_void_p()
             raise HsError(st, self._lib.hs_status_string(st).decode())
         self.device = device
+        self.last_frame_tokens = []                        # of the last extract_batch(..., publish=True)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -119,7 +120,9 @@ class ORBExtractor:
         k, d = self.extract_batch([image])
         return k[0], d[0]
 
-    def extract_batch(self, images):
+    def extract_batch(self, images, publish=False):
+        """publish=True: every extracted frame also stays on the device (include/hyslam_amd.h "device-resident frames"); the tokens of the call are in
+        `last_frame_tokens` — what the C++ extractor adaptor does for hySLAM's FeatureViews (host/HipORBExtractor.h)."""
         # row-strided views (a cv::Mat ROI: unit pixel stride, row stride >= width) go to the C ABI as they are
         strided = lambda im: isinstance(im, np.ndarray) and im.ndim == 2 and im.dtype == np.uint8 and im.strides[1] == 1 and im.strides[0] >= im.shape[1]
         imgs = [im if strided(im) else np.ascontiguousarray(im) for im in images]
@@ -141,7 +144,25 @@ class ORBExtractor:
         N.check(self._h, self._lib.hs_orb_extract_batch(self._h, ptrs, b, w, h, imgs[0].strides[0],
                                                         kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap,
                                                         n.ctypes.data_as(C.c_void_p)))
+        self.last_frame_tokens = []
+        if publish:
+            for i in range(b):
+                tok = C.c_uint64(0)
+                if n[i] > 0:
+                    N.check(self._h, self._lib.hs_frame_publish(self._h, i, kps[i].ctypes.data_as(C.c_void_p), int(n[i]), C.byref(tok)))
+                self.last_frame_tokens.append(tok.value)
         return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
+
+    def find_frame(self, keypoints):
+        """token of the cached frame whose keypoint array equals `keypoints` bit for bit (0: none) — hs_frame_find, what the matcher adaptors do with a FeatureViews"""
+        k = np.ascontiguousarray(keypoints, KP_DTYPE)
+        tok = C.c_uint64(0)
+        if len(k) == 0 or self._lib.hs_frame_find(self.device, k.ctypes.data_as(C.c_void_p), len(k), C.byref(tok)) != N.HS_OK:
+            return 0
+        return tok.value
+
+    def release_frame(self, token):
+        return self._lib.hs_frame_release(self.device, C.c_uint64(token)) == N.HS_OK
 
     # ---- pipelined host ingest (hs_orb_submit_batch / hs_orb_wait): at most two tickets in flight, like the reference's frame queue
     # (System.cc:194-196).  The H2D copy of a submitted batch overlaps the kernels of the batch before it.
@@ -310,6 +331,16 @@ class Stereomatcher:
         nL, nR = len(self.mvKeys), len(self.mvKeysRight)
         self.mvuRight = np.full(nL, -1.0, np.float32)
         self.mvDepth = np.full(nL, -1.0, np.float32)
+        # both views still on the device (published by the extractor)?  Then only the results cross the bus (hs_stereo_match_frames).
+        self.frames_on_device = False
+        tl, tr = (ex.find_frame(self.mvKeys), ex.find_frame(self.mvKeysRight)) if nL > 0 and nR > 0 else (0, 0)
+        if tl and tr:
+            st = ex._lib.hs_stereo_match_frames(ex._h, C.c_uint64(tl), C.c_uint64(tr), C.byref(self.sp), self.mvuRight.ctypes.data_as(C.c_void_p), self.mvDepth.ctypes.data_as(C.c_void_p))
+            if st == N.HS_OK:
+                self.frames_on_device = True
+                return
+            if st != N.HS_ERR_INVALID:                       # (INVALID: a slot was reused between find and use — fall back to the host arrays)
+                N.check(ex._h, st)
         N.check(ex._h, ex._lib.hs_stereo_match(ex._h, self.mvKeys.ctypes.data_as(C.c_void_p), self.mDescriptors.ctypes.data_as(C.c_void_p), nL,
                                                self.mvKeysRight.ctypes.data_as(C.c_void_p), self.mDescriptorsRight.ctypes.data_as(C.c_void_p), nR,
                                                C.byref(self.sp), self.mvuRight.ctypes.data_as(C.c_void_p),
@@ -335,6 +366,17 @@ class FeatureMatcher:
         midx = np.full(L, -1, np.int32)
         mdist = np.full(L, -1, np.float32)
         n = C.c_int32()
+        self.frame_on_device = False
+        if frame.n > 0 and frame.kps:                          # the frame's keypoints / descriptors still on the device?  (hs_frame_find + hs_search_by_projection_frame)
+            tok = C.c_uint64(0)
+            if ex._lib.hs_frame_find(ex.device, frame.kps, frame.n, C.byref(tok)) == N.HS_OK and tok.value:
+                st = ex._lib.hs_search_by_projection_frame(ex._h, tok, C.byref(frame), lms.ctypes.data_as(C.c_void_p), L, C.byref(pp),
+                                                           midx.ctypes.data_as(C.c_void_p), mdist.ctypes.data_as(C.c_void_p), C.byref(n))
+                if st == N.HS_OK:
+                    self.frame_on_device = True
+                    return midx, mdist, n.value
+                if st != N.HS_ERR_INVALID:
+                    N.check(ex._h, st)
         N.check(ex._h, ex._lib.hs_search_by_projection(ex._h, C.byref(frame), lms.ctypes.data_as(C.c_void_p), L, C.byref(pp),
                                                        midx.ctypes.data_as(C.c_void_p), mdist.ctypes.data_as(C.c_void_p), C.byref(n)))
         return midx, mdist, n.value

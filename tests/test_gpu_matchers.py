@@ -285,3 +285,43 @@ def test_frame_grid(matcher):
     N.check(ex._h, ex._lib.hs_frame_grid(ex._h, C.byref(Fg), got.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(got.astype(np.int32), want)
     assert (want[:6] == -1).any() and (want >= -1).all() and want[:, 0].max() <= 63 and want[:, 1].max() <= 47
+
+
+def test_device_resident_frames_through_the_python_mirror(gpu):
+    """include/hyslam_amd.h "device-resident frames"  as the Python mirror uses it: an extraction published to the device's frame cache is
+    found again by its keypoint array, the stereo matcher and the projection search then run on the device copies — same bits as the host-pointer
+    calls and as the oracle; a released frame, or one whose keypoints differ in one bit, is not found and the calls fall back to the host arrays."""
+    from hyslam_amd.synth import synth_stereo_pair
+    sc = scenes.projection_scene(31, 640, 480, nfeat=1000, copies=3)
+    L, R = synth_stereo_pair(31, 640, 480)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=1000))
+    (kl, kr), (dl, dr) = ex.extract_batch([L, R], publish=True)
+    tl, tr = ex.last_frame_tokens
+    assert tl and tr and tl != tr
+    assert np.array_equal(kl, sc["kps"]) and np.array_equal(dl, sc["desc"])          # the premise: extraction is bit-exact
+    assert ex.find_frame(sc["kps"]) == tl and ex.find_frame(kr) == tr
+    off = kl.copy(); off["angle"][7] = np.nextafter(off["angle"][7], np.float32(400))
+    assert ex.find_frame(off) == 0 and ex.find_frame(kl[:-1]) == 0
+    # stereo matcher: device copies == host arrays
+    cam = HS.Camera(500.0, 500.0 * 0.12, 480.0)
+    sm = HS.Stereomatcher(kl, kr, dl, dr, cam, extractor=ex)
+    sm.computeStereoMatches()
+    assert sm.frames_on_device
+    u_dev, z_dev = [a.copy() for a in sm.getData()]
+    sm_host = HS.Stereomatcher(off, kr, dl, dr, cam, extractor=ex)                   # one bit off: not found -> host path (the angle is not read by the stereo matcher)
+    sm_host.computeStereoMatches()
+    assert not sm_host.frames_on_device
+    assert np.array_equal(u_dev, sm_host.getData()[0]) and np.array_equal(z_dev, sm_host.getData()[1]) and (u_dev >= 0).sum() > 50
+    # projection search on the cached frame == host-pointer call == oracle
+    m = HS.FeatureMatcher(HS.FeatureMatcherSettings(nnratio=0.8), ex)
+    Fo, keep_o = oracle.make_frame_view(oracle.FrameView, **sc["frame_args"])
+    Fg, keep_g = oracle.make_frame_view(N.FrameView, **sc["frame_args"])
+    oi, od, on = oracle.search_by_projection(Fo, sc["lms"], oracle.ProjParams(5.0, 100.0, 0.8, 0.5, 1.5, 1, 1, 0))
+    gi, gd, gn = m.SearchByProjection(Fg, sc["lms"], 5.0)
+    assert m.frame_on_device and on > 100 and gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert ex.release_frame(tl) and not ex.release_frame(tl) and ex.find_frame(kl) == 0
+    gi, gd, gn = m.SearchByProjection(Fg, sc["lms"], 5.0)
+    assert not m.frame_on_device and gn == on and np.array_equal(gi, oi) and np.array_equal(gd, od)
+    sm.computeStereoMatches()                                                         # the left view is gone from the cache: host arrays
+    assert not sm.frames_on_device and np.array_equal(sm.getData()[0], u_dev)
+    ex.release_frame(tr)
