@@ -250,9 +250,9 @@ def committed_counters(stage, pairs_per_step, frames_per_launch):
 
 
 def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches, pairs_per_step, moved_bytes=None):
-    """roofline of one stage (= `launches` kernel launches): algorithmic bytes / HIP-event time against the HBM peak, the measured traffic, and
-    the VALU issue fraction = VALU wave-instructions / (256 CUs x cycles of the launch at 2.4 GHz) — every big kernel of this path is bound
-    by instruction issue, not by HBM, so that is the axis that explains the time."""
+    """roofline of one stage (= `launches` kernel launches): algorithmic bytes / HIP-event time against the HBM peak (`bound` "hbm": the roof `frac`
+    is priced against — the path is integer / byte work, no MFMA), the measured traffic, and what the counters say limits the kernel (`limiter`):
+    VALU wave-instructions per busy CU cycle against the instruction-class ceilings of profiles/r05_valu_issue_rates.txt."""
     ms = stage_ms[stage]
     algo = per_stage_bytes[stage] * frames_per_launch
     achieved = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -267,18 +267,20 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
     if valu is not None and ms > 0:
         rl["valu_insts_per_launch"] = int(valu / launches)
         busy = sq.get("SQ_BUSY_CU_CYCLES")
-        if busy:      # counters of the same profiled launch: VALU wave-instructions per busy CU cycle (1 = a VALU instruction issued every cycle on
-            # every busy CU; the measured ceiling of this instruction mix is 0.8-0.9, profiles/*_valu_issue_rates.txt), no clock assumption
+        if busy:      # counters of the same profiled launch: VALU wave-instructions per busy CU cycle, no clock assumption (ceilings by instruction class
+            # and occupancy: 0.90-0.96 for everything but plain 32-bit ALU operations, 1.44-1.77 for those: profiles/r05_valu_issue_rates.txt)
             rl["valu_issue_frac"] = round(valu / busy, 4)
             if "SQ_LDS_IDX_ACTIVE" in sq:
                 rl["lds_active_frac"] = round(sq["SQ_LDS_IDX_ACTIVE"] / busy, 4)
                 rl["lds_conflict_frac"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / busy, 4)
         else:         # older counter files: against the nominal clock (the clock under load is lower: this understates the fraction)
             rl["valu_issue_frac"] = round(valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
-        # what the counters say bounds the kernel: at >= 0.7 VALU wave-instructions per busy CU cycle (the measured ceiling of this instruction mix
-        # is 0.8-0.9) it is instruction issue, not HBM; `frac` stays the HBM fraction of the algorithmic bytes either way
-        if rl["valu_issue_frac"] >= 0.7:
-            rl["bound"] = "valu_issue"
+        # what the counters say limits the kernel (`frac` stays the HBM fraction of the algorithmic bytes either way).  k_fast_rows: round 5 measured
+        # t = a + b / workgroups per CU with b / n more than half of the launch (profiles/r05_late_experiments.txt): latency at 3 waves per SIMD.
+        if stage == "fast_cells":
+            rl["limiter"] = "latency at 3 waves per SIMD (12 single-wave workgroups per CU by LDS); VALU issue %.2f per busy CU cycle of a mix-weighted ceiling ~1.1" % rl["valu_issue_frac"]
+        elif rl["valu_issue_frac"] >= 0.7:
+            rl["limiter"] = "VALU issue (%.2f per busy CU cycle; ceiling 0.90-0.96 for this instruction class)" % rl["valu_issue_frac"]
     return rl
 
 
