@@ -170,7 +170,17 @@ struct RowGeom {            // wave-uniform description of one work item in one 
 //           cheapest get the (cheap) second items and the heaviest items run alone; no counter, no look-ahead grab.  At one stereo pair per
 //           call the launch lasts as long as its slowest wave: with the look-ahead of the work queues the waves that started on the HEAVIEST
 //           items were the first to grab a second one (`tools/fast_b1_timeline.py`: 28.8 us span, the slowest waves all "level 7 + another")
-struct FastSched { int32_t nq_log, mode, par, par_log, per_q; };
+struct FastSched { int32_t nq_log, mode, par, par_log, per_q; uint32_t m_per_q, m_par, m_items; };     // m_x = ceil(2^32 / x): fast_div()
+// floor(a / d) for 0 <= a < 2^31 and d >= 1 with m = ceil(2^32 / d): the high product is floor(a / d) or one more (its error a * (m * d - 2^32) / (d * 2^32)
+// is below a / 2^32 < 1/2), one compare corrects it.  Wave-uniform operands: two scalar multiplies instead of the ~20-instruction v_rcp_iflag sequence
+// of an integer division, twice per work item on the critical path of every wave.
+__device__ __forceinline__ int fast_div(int a, int d, uint32_t m)
+{
+    int q = (int)__umulhi((uint32_t)a, m);
+    if (d == 1) q = a;                                          // (ceil(2^32 / 1) does not fit 32 bits)
+    if (q * d > a) q--;
+    return q;
+}
 __device__ __forceinline__ int fast_queue_size(const FastSched& S, int qq, int total_work, int items_per_img)
 {
     if (S.mode == 1) return S.per_q;
@@ -178,30 +188,42 @@ __device__ __forceinline__ int fast_queue_size(const FastSched& S, int qq, int t
     if (S.mode == 3) return (total_work - qq + (1 << S.nq_log) - 1) >> S.nq_log;
     return min(max(total_work - qq * S.per_q, 0), S.per_q);
 }
-__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, const FastSched& S, int w)
+// work unit w -> (item of the launch's item list, image)
+__device__ __forceinline__ int unit_decode(int items_per_img, const FastSched& S, int w, int* img)
 {
-    RowGeom g;
+    struct { int img; } g;
     int item;
     if (S.mode == 1) {
-        const int q = w / S.per_q, u = w - q * S.per_q;
-        item = u / S.par;
+        const int q = fast_div(w, S.per_q, S.m_per_q), u = w - q * S.per_q;
+        item = fast_div(u, S.par, S.m_par);
         g.img = q * S.par + (u - item * S.par);
     } else if (S.mode == 2) {
-        const int q = w / S.per_q, u = w - q * S.per_q;
+        const int q = fast_div(w, S.per_q, S.m_per_q), u = w - q * S.per_q;
         g.img = q >> S.par_log;
         item = (u << S.par_log) + (q & (S.par - 1));
     } else if (S.mode == 3) {
-        const int q = w / S.per_q, u = w - q * S.per_q, gidx = (u << S.nq_log) + q;      // position in the item-major list of all S.par images
-        item = gidx / S.par;
+        const int q = fast_div(w, S.per_q, S.m_per_q), u = w - q * S.per_q, gidx = (u << S.nq_log) + q;      // position in the item-major list of all S.par images
+        item = fast_div(gidx, S.par, S.m_par);
         g.img = gidx - item * S.par;
     } else if (S.mode == 4) {
-        item = w / S.par;                                            // w = position in the item-major list of all S.par images
+        item = fast_div(w, S.par, S.m_par);                          // w = position in the item-major list of all S.par images
         g.img = w - item * S.par;
     } else {
-        g.img = w / items_per_img;
+        g.img = fast_div(w, items_per_img, S.m_items);
         item = w - g.img * items_per_img;
     }
-    const HsFastItem it = items[item];                           // one s_load_dwordx16 (`items` already points at the launch's first item)
+    *img = g.img;
+    return item;
+}
+// An item's record as ONE 64-byte scalar load.  Read field by field (`items[i]`) the compiler fetches the dword-sized fields with scalar loads and the
+// byte / half-word ones (off, ndw, ...) with a VECTOR load whose round trip through L2 the wave then waits for — once per work item, on its critical path.
+typedef uint32_t hs_u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ HsFastItem fast_item_load(const HsFastItem* p) { return __builtin_bit_cast(HsFastItem, hs_cload<hs_u32x16>(p)); }
+// the item's record (`items` already points at the launch's first item) + the image -> geometry
+__device__ __forceinline__ RowGeom geom_of(const HsFastItem& it, const HsImg0& img0, int img)
+{
+    RowGeom g;
+    g.img = img;
     g.ncell = it.ncell; g.c0 = it.c0; g.gcell0 = it.gcell0; g.slot0 = it.slot0; g.ccap = it.ccap;
     g.inv_w = it.inv_w; g.inv_w1 = it.inv_w1;
     g.xoff = it.xoff; g.yoff = it.yoff;
@@ -215,6 +237,12 @@ __device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items
     g.aligned = (((uintptr_t)base | g.pitch) & 3) == 0;
     g.rows = base + (size_t)it.iniY * g.pitch + it.a0;
     return g;
+}
+__device__ __forceinline__ RowGeom row_geom(const HsFastItem* __restrict__ items, const HsImg0& img0, int items_per_img, const FastSched& S, int w)
+{
+    int img;
+    const int item = unit_decode(items_per_img, S, w, &img);
+    return geom_of(fast_item_load(items + item), img0, img);
 }
 
 // One wave per workgroup: its LDS instructions execute in issue order, so a later read sees an earlier write without any wait;
@@ -408,8 +436,15 @@ __global__ __launch_bounds__(64, (LC == 5 && TR <= 44 ? 4 : 1)) void k_fast_rows
             if (w >= 0) { g = row_geom(items, img0, items_per_img, S, w); prefetch(g); if (dynamic) raw_next = grab_async(q); }
             continue;
         }
-        // ---- stage the tile
+        const RowGeom cur = g;
+        // The next work unit: its queue counter value was requested an item ago and arrives with the tile loads the staging below waits for anyway;
+        // its item record (one 64-byte scalar load) is requested BEFORE the staging stores, so that it is there when they are done.
         FR_T(t0);
+        const int w_next = resolve(raw_next);
+        int img_next = 0;
+        const int item_next = w_next >= 0 ? unit_decode(items_per_img, S, w_next, &img_next) : 0;
+        const HsFastItem it_next = fast_item_load(items + item_next);      // (no next unit: item 0's record, unused)
+        // ---- stage the tile
 #pragma unroll
         for (int k = 0; k < NL; k++)
             if (RPL * (k + 1) <= TR || RPL * k + ld_row < TR)
@@ -418,7 +453,6 @@ __global__ __launch_bounds__(64, (LC == 5 && TR <= 44 ? 4 : 1)) void k_fast_rows
         FR_T(t1);
         FR_ACC(0, t0, t1);
         FR_W(1);
-        const RowGeom cur = g;
         // the item's pixel list starts where its tile ends (rows th .. TR of the tile region are not used by this item)
         const int list_off = cur.th * PITCH;
         const int pcap = min(lds.pcap_max, (int)((((uint32_t)(lds.off_cnt - list_off) * 43691u) >> 17) & ~15u));      // floor(bytes / 3) entries, a multiple of 16
@@ -426,9 +460,8 @@ __global__ __launch_bounds__(64, (LC == 5 && TR <= 44 ? 4 : 1)) void k_fast_rows
         uint8_t* const pscore = smem + list_off + 2 * pcap;                          // score of corner i of the list
         const int inv_w = cur.inv_w, inv_w1 = cur.inv_w1;
         const size_t slot_base = (size_t)cur.img * cand_img_stride + cur.slot0;
-        // the staging above waited for every outstanding vector-memory operation, the grab included: its value is here
-        const int w_next = resolve(raw_next);
-        if (w_next >= 0) { g = row_geom(items, img0, items_per_img, S, w_next); prefetch(g); if (dynamic) raw_next = grab_async(q); }   // in flight during the passes
+        const RowGeom g_next = geom_of(it_next, img0, img_next);       // (unconditional: a use inside the branch would sink the record's load below the staging stores)
+        if (w_next >= 0) { g = g_next; prefetch(g); if (dynamic) raw_next = grab_async(q); }   // the next tile: in flight during the passes
         FR_T(t2);
         FR_ACC(1, t1, t2);
         FR_W(2);
@@ -927,7 +960,7 @@ static int fast_rows_grid(const FastRowsCfg& c, int total_work)
     return nblk;
 }
 // queue count and unit order of a launch over `batch` images with `nblk` workgroups (see FastSched)
-static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& knobs, int nblk)
+static FastSched fast_sched_plan(int batch, int items_per_img, const HsFastKnobs& knobs, int nblk)
 {
     FastSched S{};
     if (!knobs.no_fold && !knobs.image_major && batch > 0 && (long long)items_per_img * batch <= 2LL * nblk) {
@@ -946,6 +979,13 @@ static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& kno
         S.per_q = (items_per_img + S.par - 1) / S.par;
     } else if (!knobs.image_major && batch > 0) { S.mode = 3; S.par = batch; S.per_q = (items_per_img * batch + nq - 1) / nq; }
     else { S.mode = 0; S.per_q = (items_per_img * batch + nq - 1) / nq; }
+    return S;
+}
+static FastSched fast_sched(int batch, int items_per_img, const HsFastKnobs& knobs, int nblk)
+{
+    FastSched S = fast_sched_plan(batch, items_per_img, knobs, nblk);
+    auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };       // ceil(2^32 / d); d <= 1: unused (fast_div)
+    S.m_per_q = magic(S.per_q); S.m_par = magic(S.par); S.m_items = magic(items_per_img);
     return S;
 }
 size_t hs_fast_overflow_bytes(int max_hcell, int total_work_max, const HsFastKnobs& knobs)
