@@ -276,9 +276,9 @@ def roofline_block(stage, stage_ms, per_stage_bytes, frames_per_launch, launches
         else:         # older counter files: against the nominal clock (the clock under load is lower: this understates the fraction)
             rl["valu_issue_frac"] = round(valu / (256.0 * ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
         # what the counters say limits the kernel (`frac` stays the HBM fraction of the algorithmic bytes either way).  k_fast_rows: round 5 measured
-        # t = a + b / workgroups per CU with b / n more than half of the launch (profiles/r05_late_experiments.txt): latency at 3 waves per SIMD.
+        # t = a + b / workgroups per CU with b / n more than half of the launch (profiles/r05_late_experiments.txt).
         if stage == "fast_cells":
-            rl["limiter"] = "latency at 3 waves per SIMD (12 single-wave workgroups per CU by LDS); VALU issue %.2f per busy CU cycle of a mix-weighted ceiling ~1.1" % rl["valu_issue_frac"]
+            rl["limiter"] = "half SIMD throughput, half per-wave issue at 3 waves per SIMD (12 single-wave workgroups per CU by LDS; t = a + b / n); VALU issue %.2f per busy CU cycle of a mix-weighted ceiling ~1.1" % rl["valu_issue_frac"]
         elif rl["valu_issue_frac"] >= 0.7:
             rl["limiter"] = "VALU issue (%.2f per busy CU cycle; ceiling 0.90-0.96 for this instruction class)" % rl["valu_issue_frac"]
     return rl
