@@ -301,8 +301,18 @@ private:
         std::vector<hs_landmark> out(std::max<size_t>(lms.size(), 1));
         std::memset(out.data(), 0, out.size() * sizeof(hs_landmark));
         // geometry of landmarks [a, b): position (+ normal: only Fuse's viewing-angle criterion reads it), size, distance range, associations
+        // The landmarks are separate heap objects visited in address order of their POINTERS' set, i.e. in no order the hardware prefetcher can follow:
+        // the first cache lines of the object a few entries ahead are requested by hand (a MapPoint's position, distances and descriptor header sit in
+        // its first few hundred bytes; nothing is assumed about its layout beyond that).
+        constexpr size_t PF_AHEAD = 8;
+        auto prefetch_object = [](const void* p) {
+            if (!p) return;
+            const char* c = static_cast<const char*>(p);
+            __builtin_prefetch(c); __builtin_prefetch(c + 64); __builtin_prefetch(c + 128); __builtin_prefetch(c + 192);
+        };
         auto fill_geometry = [&](size_t a, size_t b) {
             for (size_t i = a; i < b; i++) {
+                if (i + PF_AHEAD < b) prefetch_object(lms[i + PF_AHEAD]);
                 hs_landmark& L = out[i];
                 MapPoint* lm = lms[i];
                 L.assoc_kp = -1;
@@ -319,6 +329,7 @@ private:
         };
         auto fill_descriptors = [&](size_t a, size_t b) {      // walks DOWN: the geometry helpers walk up through the same records (one cache line each) — meet once, not at every record
             for (size_t i = b; i-- > a;) {
+                if (i >= a + PF_AHEAD) prefetch_object(lms[i - PF_AHEAD]);
                 if (!lms[i]) continue;
                 const cv::Mat row = lms[i]->GetDescriptor().rawDescriptor();
                 std::memcpy(out[i].desc, row.ptr(0), HS_DESC_BYTES);

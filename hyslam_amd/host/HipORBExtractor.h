@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <future>
@@ -29,6 +30,10 @@
 #include <string>
 #include <vector>
 #include "../../include/hyslam_amd.h"
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 // helper threads of an extractor's descriptor scatter (0 = the calling thread alone; the environment variable HYSLAM_AMD_SCATTER_THREADS overrides).
 // Default 0: measured on the GPU box (2 x 2000 descriptors, two extractors side by side) 0 / 1 / 2 helpers = 0.145 / 0.144 / 0.145 ms — every
@@ -63,6 +68,39 @@ inline hs_orb* thread_handle(int device, const char* who) {
 // A helper thread that lives as long as its owner: run(f) hands it one job, wait() blocks until that job is done.  (std::async starts a new thread per
 // call: ~35 us to create it, and a fresh thread allocates from a fresh malloc arena whose pages are touched for the first time — for the ~60 us of
 // FeatureDescriptor constructions an extractor call hands out, that overhead was most of the helper's time.)
+// The CPUs that share a last-level cache with `cpu` (Linux sysfs), restricted to the CPUs this process may use; empty when unknown.  A helper that the
+// scheduler drops on the other socket of a two-socket host reads every MapPoint the caller allocated across the socket link: on the GPU box (2 x EPYC
+// 9575F, 256 CPUs, no affinity set) TrackLocalMap's landmark gather took 3.7-4.4 ms with free placement and 2.1 ms with caller and helpers in one L3
+// domain (tools/experiments/r5_adaptor_runs.sh).  A helper therefore follows its caller: before a job it is confined to the caller's L3 domain
+// (re-done only when the caller has moved to another domain).  Best effort: any failure leaves the thread where it is; HYSLAM_AMD_PIN_HELPERS=0 disables it.
+inline bool l3_domain_of(int cpu, cpu_set_t* out) {
+#if defined(__linux__)
+    char path[128];
+    std::snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    std::FILE* f = std::fopen(path, "r");
+    if (!f) return false;
+    char buf[1024];
+    const bool got = std::fgets(buf, sizeof(buf), f) != nullptr;
+    std::fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    CPU_ZERO(out);
+    for (const char* q = buf; *q && *q != '\n';) {              // "0-7,128-135"
+        char* e = nullptr;
+        const long a = std::strtol(q, &e, 10);
+        if (e == q) break;
+        long b = a;
+        q = e;
+        if (*q == '-') { b = std::strtol(q + 1, &e, 10); if (e == q + 1) break; q = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, out);
+        if (*q == ',') q++;
+    }
+    return CPU_COUNT(out) > 0;
+#else
+    (void)cpu; (void)out; return false;
+#endif
+}
 class Worker {
 public:
     Worker() = default;
@@ -76,12 +114,25 @@ public:
     template <class F> void run(F&& f) {
         std::unique_lock<std::mutex> g(mu);
         if (!th.joinable()) th = std::thread([this] { loop(); });
+        follow_caller();
         job = std::forward<F>(f); busy = true;
         g.unlock();
         cv.notify_all();
     }
     void wait() { std::unique_lock<std::mutex> g(mu); done_cv.wait(g, [this] { return !busy; }); if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); } }
 private:
+    // keep the helper in the calling thread's L3 domain (see l3_domain_of): one sched_getcpu() per job, a sysfs read + setaffinity only when the domain changed
+    void follow_caller() {
+#if defined(__linux__)
+        static const bool enabled = [] { const char* e = std::getenv("HYSLAM_AMD_PIN_HELPERS"); return !e || std::atoi(e) != 0; }();
+        if (!enabled) return;
+        const int cpu = sched_getcpu();
+        if (cpu < 0 || (have_domain && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &domain))) return;
+        cpu_set_t d;
+        if (!l3_domain_of(cpu, &d)) return;
+        if (pthread_setaffinity_np(th.native_handle(), sizeof(d), &d) == 0) { domain = d; have_domain = true; }
+#endif
+    }
     void loop() {
         std::unique_lock<std::mutex> g(mu);
         for (;;) {
@@ -97,6 +148,9 @@ private:
         }
     }
     std::mutex mu; std::condition_variable cv, done_cv; std::thread th; std::function<void()> job; bool busy = false, quit = false; std::exception_ptr err;
+#if defined(__linux__)
+    cpu_set_t domain; bool have_domain = false;
+#endif
 };
 // two helpers per CALLING thread, for adaptors that are short-lived objects themselves (a FeatureMatcher is made per call: FeatureFactory.cpp:7-9)
 inline Worker* thread_workers() { static thread_local Worker w[2]; return w; }
