@@ -548,6 +548,18 @@ def call_site():
             fl, fr = os.path.join(td, "L.raw"), os.path.join(td, "R.raw")
             L.tofile(fl); R.tofile(fr)
             r = subprocess.run([exe, str(W), str(H), fl, fr, "20", "50000"], capture_output=True, timeout=180)
+            # the same with the whole child confined to ONE last-level-cache domain: on a multi-socket host the application's own threads (hySLAM creates its
+            # left-extractor thread per frame) otherwise wander between the sockets (profiles/r05_late_experiments.txt); a deployment choice, reported beside
+            confined = None
+            try:
+                cpus = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % sorted(os.sched_getaffinity(0))[0]).read().strip()
+                rc = subprocess.run(["taskset", "-c", cpus, exe, str(W), str(H), fl, fr, "20", "50000"], capture_output=True, timeout=180)
+                if rc.returncode == 0:
+                    dc = json.loads(rc.stdout.decode())
+                    confined = {"cpus": cpus, "how": "taskset -c", "TrackLocalMap_ms": dc["TrackLocalMap_SearchByProjection_ms"]["total"],
+                                "ProcessStereoImage_ms_per_pair": dc["ProcessStereoImage_ms"]["total"], "HipStereoFrontend_pipelined_ms_per_pair": dc["HipStereoFrontend_ms"]["pipelined_per_pair"]}
+            except Exception:
+                confined = None
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr).decode(errors="replace")[-200:]}
         d = json.loads(r.stdout.decode())
@@ -563,7 +575,8 @@ def call_site():
                                                 "FeatureViews_ctor": p["FeatureViews_ctor"], "stereo_gather": p["stereo_gather"], "stereo_c_abi": p["stereo_c_abi"], "getData": p["getData"],
                                                 "stereo_frames_on_device": p.get("stereo_frames_on_device")},
                 "HipStereoFrontend_ms_per_pair": f["process_total"], "HipStereoFrontend_split_ms": {"submit_plus_wait": f["submit_plus_wait"], "FeatureViews_build": f["FeatureViews_build"]},
-                "HipStereoFrontend_pipelined_ms_per_pair": f["pipelined_per_pair"], "keypoints": d["keypoints"], "stereo_matches": d["stereo_matches"]}
+                "HipStereoFrontend_pipelined_ms_per_pair": f["pipelined_per_pair"], "keypoints": d["keypoints"], "stereo_matches": d["stereo_matches"],
+                "thread_placement": "free (the scheduler's); the adaptor's own helper threads follow their caller's L3 domain", "confined_to_one_L3_domain": confined}
     except Exception as e:      # a secondary figure must never take the headline down
         return {"error": str(e)[:200]}
 
