@@ -36,11 +36,13 @@
 #endif
 
 // helper threads of an extractor's descriptor scatter (0 = the calling thread alone; the environment variable HYSLAM_AMD_SCATTER_THREADS overrides).
-// Default 0: measured on the GPU box (2 x 2000 descriptors, two extractors side by side) 0 / 1 / 2 helpers = 0.145 / 0.144 / 0.145 ms — every
-// FeatureDescriptor construction copies the ONE shared_ptr<DescriptorDistance> all descriptors of an extractor share (FeatureDescriptor.cpp:6-10), and
-// with more than one thread that reference count bounces between cores: what the split saves, the contention costs.
+// Every FeatureDescriptor construction copies the ONE shared_ptr<DescriptorDistance> all descriptors of an extractor share (FeatureDescriptor.cpp:6-10),
+// so with more than one thread that reference count bounces between cores.  With helpers wherever the scheduler put them (two sockets) that cost what
+// the split saved: 0 / 1 / 2 helpers = 0.145 / 0.144 / 0.145 ms (2 x 2000 descriptors, two extractors side by side).  With the helper in its caller's
+// L3 domain (Worker::follow_caller) the bounce is an L3 hit: 0.095 -> 0.070 ms with one helper when hySLAM runs confined to one domain
+// (ProcessStereoImage 0.535 -> 0.50 ms), nothing lost with free placement (0.588 / 0.589); a second helper adds nothing.  Default 1.
 #ifndef HYSLAM_AMD_SCATTER_HELPERS
-#define HYSLAM_AMD_SCATTER_HELPERS 0
+#define HYSLAM_AMD_SCATTER_HELPERS 1
 #endif
 
 namespace HYSLAM {
@@ -73,7 +75,27 @@ inline hs_orb* thread_handle(int device, const char* who) {
 // 9575F, 256 CPUs, no affinity set) TrackLocalMap's landmark gather took 3.7-4.4 ms with free placement and 2.1 ms with caller and helpers in one L3
 // domain (tools/experiments/r5_adaptor_runs.sh).  A helper therefore follows its caller: before a job it is confined to the caller's L3 domain
 // (re-done only when the caller has moved to another domain).  Best effort: any failure leaves the thread where it is; HYSLAM_AMD_PIN_HELPERS=0 disables it.
+inline bool l3_domain_read(int cpu, cpu_set_t* out);
+// cached per CPU (the topology does not change; the process's affinity mask is taken as it is at the first question about a CPU)
 inline bool l3_domain_of(int cpu, cpu_set_t* out) {
+#if defined(__linux__)
+    struct Cache { std::mutex mu; std::map<int, cpu_set_t> by_cpu; };
+    static Cache c;
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.by_cpu.find(cpu);
+    if (it == c.by_cpu.end()) {
+        cpu_set_t d; CPU_ZERO(&d);
+        if (!l3_domain_read(cpu, &d)) CPU_ZERO(&d);
+        for (int k = 0; k < CPU_SETSIZE; k++) if (CPU_ISSET(k, &d)) c.by_cpu[k] = d;      // every CPU of the domain at once
+        it = c.by_cpu.insert({ cpu, d }).first;
+    }
+    *out = it->second;
+    return CPU_COUNT(out) > 0;
+#else
+    (void)cpu; (void)out; return false;
+#endif
+}
+inline bool l3_domain_read(int cpu, cpu_set_t* out) {
 #if defined(__linux__)
     char path[128];
     std::snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
@@ -209,8 +231,8 @@ public:
         _keypoints.resize(n);
         const size_t d0 = descriptors.size();
         descriptors.resize(d0 + n);                          // appended, like the reference (ORBExtractor.cpp:558-561)
-        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is 40 % of this call's wall time.  Helper threads
-        // (HYSLAM_AMD_SCATTER_HELPERS) do not shorten it — see the note at that macro — so by default the calling thread does it alone.
+        // Building 2000 FeatureDescriptors (a cv::Mat clone each: the reference's own object model) is 40 % of this call's wall time; one helper thread
+        // kept in the caller's L3 domain takes half of them (HYSLAM_AMD_SCATTER_HELPERS: see the note at that macro).
         auto fill = [&](int a, int b) {
             for (int i = a; i < b; i++) {
                 cv::KeyPoint& k = _keypoints[i];
