@@ -67,9 +67,6 @@ inline hs_orb* thread_handle(int device, const char* who) {
     o.by_device[device] = h;
     return h;
 }
-// A helper thread that lives as long as its owner: run(f) hands it one job, wait() blocks until that job is done.  (std::async starts a new thread per
-// call: ~35 us to create it, and a fresh thread allocates from a fresh malloc arena whose pages are touched for the first time — for the ~60 us of
-// FeatureDescriptor constructions an extractor call hands out, that overhead was most of the helper's time.)
 // The CPUs that share a last-level cache with `cpu` (Linux sysfs), restricted to the CPUs this process may use; empty when unknown.  A helper that the
 // scheduler drops on the other socket of a two-socket host reads every MapPoint the caller allocated across the socket link: on the GPU box (2 x EPYC
 // 9575F, 256 CPUs, no affinity set) TrackLocalMap's landmark gather took 3.7-4.4 ms with free placement and 2.1 ms with caller and helpers in one L3
@@ -123,6 +120,9 @@ inline bool l3_domain_read(int cpu, cpu_set_t* out) {
     (void)cpu; (void)out; return false;
 #endif
 }
+// A helper thread that lives as long as its owner: run(f) hands it one job, wait() blocks until that job is done.  (std::async starts a new thread per
+// call: ~35 us to create it, and a fresh thread allocates from a fresh malloc arena whose pages are touched for the first time — for the ~60 us of
+// FeatureDescriptor constructions an extractor call hands out, that overhead was most of the helper's time.)
 class Worker {
 public:
     Worker() = default;
