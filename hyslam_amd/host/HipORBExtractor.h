@@ -404,18 +404,24 @@ public:
         timing.abi_ms = hip_detail::ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         std::vector<cv::KeyPoint> keys[2]; std::vector<FeatureDescriptor> descs[2];
-        // (a helper thread for the right view was measured twice: growing vectors inside the helper 0.32 -> 1.08 ms — a fresh thread's allocator arena, freed by the
-        //  caller —, pre-sized vectors filled in parallel 0.32-0.40 -> 0.38 ms: no gain, the FeatureViews constructor's copies dominate; serial it stays)
-        for (int s = 0; s < 2; s++) {
-            keys[s].reserve(n[s]); descs[s].reserve(n[s]);
+        // The right view is filled by a helper thread kept in this thread's L3 domain (Worker::follow_caller), into vectors sized here.  (Measured twice
+        // before the helpers followed their caller: growing vectors inside the helper 0.32 -> 1.08 ms — a fresh thread's allocator arena, freed by the
+        // caller —, pre-sized vectors filled by a helper wherever the scheduler had put it 0.32-0.40 -> 0.38 ms: no gain.)
+        auto fill = [&](int s) {
             for (int i = 0; i < n[s]; i++) {
                 const hs_keypoint& q = kps[(size_t)s * cap + i];
-                cv::KeyPoint k;
+                cv::KeyPoint& k = keys[s][i];
                 k.pt.x = q.x; k.pt.y = q.y; k.size = q.size; k.angle = q.angle; k.response = q.response; k.octave = q.octave; k.class_id = -1;
-                keys[s].push_back(k);
-                descs[s].push_back(FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + ((size_t)s * cap + i) * HS_DESC_BYTES, HS_DESC_BYTES), dist_func));
+                descs[s][i] = FeatureDescriptor(cv::Mat(1, HS_DESC_BYTES, CV_8UC1, desc.data() + ((size_t)s * cap + i) * HS_DESC_BYTES, HS_DESC_BYTES), dist_func);
             }
-        }
+        };
+        for (int s = 0; s < 2; s++) { keys[s].resize(n[s]); descs[s].resize(n[s]); }
+        static const bool parallel = [] { const char* e = std::getenv("HYSLAM_AMD_SCATTER_THREADS"); return !e || std::atoi(e) != 0; }();
+        if (parallel && n[1] >= 512) {
+            helper.run([&fill] { fill(1); });
+            try { fill(0); } catch (...) { try { helper.wait(); } catch (...) {} throw; }      // the helper holds references to this frame
+            helper.wait();
+        } else { fill(0); fill(1); }
         FeatureViews views(keys[0], keys[1], std::vector<float>(uR.begin(), uR.begin() + n[0]), std::vector<float>(depth.begin(), depth.begin() + n[0]),
                            descs[0], descs[1], views_params);
         timing.scatter_ms = hip_detail::ms_since(t1);
@@ -430,6 +436,7 @@ private:
     std::shared_ptr<DescriptorDistance> dist_func;
     FeatureExtractorSettings orb_params, views_params;     // views_params: default-constructed, like ImageProcessing.cpp:85
     std::vector<hs_keypoint> kps; std::vector<uint8_t> desc; std::vector<float> uR, depth;
+    hip_detail::Worker helper;        // fills the right view's objects in collect()
 };
 
 }  // namespace HYSLAM
