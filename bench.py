@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--call-site", type=int, choices=[0, 1], default=1,
                     help="c2, N = 1: also run tests/cpp/_build/bench_adaptor (when __graft_entry__.build() has made it) AFTER the timed loop and report, as "
                          "`call_site`, what hySLAM's own call sites would see through the drop-in C++ classes (ProcessStereoImage ms per pair, split gather / C ABI / scatter)")
+    ap.add_argument("--copy-gib", type=float, default=2.0,
+                    help="c2: GiB of the device-to-device copy that measures this box's own HBM copy bandwidth (hipMemcpyAsync and a 16-byte-per-lane kernel), "
+                         "printed as roofline.peak_measured_copy beside the vendor peak (0 = skip)")
+    ap.add_argument("--latency-calls", type=int, default=400, help="c2, N = 1: calls of the one-pair-per-call latency leg after the timed loop (0 = skip)")
     ap.add_argument("--pcie-seconds", type=float, default=1.5, help="c2, N = 1: budget of the host-fed (PCIe-inclusive) secondary measurement (0 = skip)")
     ap.add_argument("--c4-split", type=int, choices=[0, 1], default=1,
                     help="c4: hs_orb_set_split(1) on both camera handles (level 0's FAST + quadtree on a second stream beside the pyramid); 0 = the library default")
@@ -413,21 +417,24 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     value = world * B * args.steps * args.inner_repeats / elapsed
     n_left = nL.cpu().numpy()
     n_match = int((depth.view(B, cap)[0] > 0).sum().item())
-    # what the timed loop left in pair 0's output buffers, hashed like tools/make_golden.py hashed the oracle's outputs for the same seeded pair
-    # (tests/golden/bench_c2_seed1000.json: data only); every rank checks its own pair, the line carries the conjunction
+    # what the timed loop left in EVERY pair's output buffers, hashed like tools/make_golden.py hashed the oracle's outputs for the same seeded pairs
+    # (tests/golden/bench_c2_seed1000.json: data only); every rank checks its own pairs, the line carries the conjunction
     parity = parity_checksum(rank, args, N, cap, kL, dL, nL, kR, dR, nR, uR, depth)
     per_rank = [B * args.steps * args.inner_repeats / args.local_elapsed]
     if world > 1:
-        t = torch.tensor([1 if parity["ok"] else (0 if parity["ok"] is False else 2), int(per_rank[0])], dtype=torch.int64, device=dev)
-        allt = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        t = torch.tensor([1 if parity["ok"] else (0 if parity["ok"] is False else 2), int(per_rank[0]), parity["pairs_checked"]], dtype=torch.int64, device=dev)
+        allt = torch.empty((world, 3), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allt.view(-1), t)
         flags, per_rank = allt[:, 0].tolist(), [float(v) for v in allt[:, 1].tolist()]
+        parity["pairs_checked_per_rank"] = allt[:, 2].tolist()
         parity["ok"] = None if all(f == 2 for f in flags) else all(f != 0 for f in flags)
         parity["ranks_checked"] = sum(f != 2 for f in flags)
         parity["ranks_failed"] = [r for r, f in enumerate(flags) if f == 0]
     if rank != 0:
         rccl_probe_guarded(None, ex, rank, world, dev)
         return
+    copy_peak = measured_copy_peak(ex, torch, dev) if args.copy_gib > 0 else None
+    lat1 = one_pair_latency(HS, N, torch, dev, local_rank, pairs[0], sp) if (world == 1 and args.latency_calls > 0) else None
     px = pyramid_pixels(ex, W, H)
     per_stage, per_frame = algorithmic_bytes(px, NFEAT)
     frames_per_launch = 2 * max(b - a for a, b in parts) // lanes     # every launch sequence covers its own share of the pairs
@@ -446,11 +453,20 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
                      "sharding": "pairs sharded over ranks, no collective",
                      "keypoints_left_frame0": int(n_left[0]), "stereo_matches_frame0": n_match}
     out["parity_checksum_ok"] = parity["ok"]
+    out["pairs_checked"] = parity["pairs_checked"]          # of rank 0's `pairs_per_pass` (N > 1: parity_checksum.pairs_checked_per_rank)
     out["parity_checksum"] = {k: v for k, v in parity.items() if k != "ok"}
     out["per_rank_pairs_per_s"] = {"min": round(min(per_rank), 1), "max": round(max(per_rank), 1)}
     out["timed_region_ms"] = round(elapsed * 1e3, 1)
+    if copy_peak is not None:         # both peaks beside each other: the vendor's 8 TB/s and this box's own device-to-device copy
+        out["measured_copy_peak"] = copy_peak
+        for rl in rls.values():
+            rl["peak_measured_copy"] = copy_peak.get("GBps")
+            rl["frac_of_measured"] = round(rl["achieved"] / copy_peak["GBps"], 5) if copy_peak.get("GBps") else None
     out["roofline"] = rls[dom]
     out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
+    if lat1 is not None:
+        out["latency_one_pair_ms"] = lat1.get("back_to_back_ms")
+        out["latency_one_pair"] = lat1
     out["stage_ms_per_step"] = {s: round(v, 5) for s, v in stage_ms.items()}
     out["profiled_steps"] = profiled_steps(args)      # the first of the timed steps; the others record no events
     pair_bytes = 2 * per_frame
@@ -460,13 +476,17 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
     moved_pair = pair_bytes - 2 * 2 * sum(px)             # without the blur's read + write of every level
     out["end_to_end"]["moved_bytes_per_pair"] = int(moved_pair)
     out["end_to_end"]["frac_on_moved_bytes"] = round(value / world * moved_pair / 1e9 / HBM_PEAK_GBS, 5)
+    if copy_peak is not None and copy_peak.get("GBps"):
+        out["end_to_end"]["peak_measured_copy"] = copy_peak["GBps"]
+        out["end_to_end"]["frac_of_measured"] = round(value / world * pair_bytes / 1e9 / copy_peak["GBps"], 5)
+        out["end_to_end"]["frac_of_measured_on_moved_bytes"] = round(value / world * moved_pair / 1e9 / copy_peak["GBps"], 5)
     if world == 1 and args.pcie_seconds > 0:
         out["pcie_inclusive"] = pcie_inclusive(HS, exs[0], sp, pairs, min(B, 16), args.pcie_seconds)      # 16 pairs per ticket (two tickets in flight), whatever the step's batch
     if world == 1 and args.call_site:
         cs = call_site()
         if cs is not None:
             out["call_site"] = cs
-    if world == 1 and args.cpu_seconds > 0:
+    if world == 1 and args.cpu_seconds > 0 and not under_profiler():
         out["cpu_baseline"] = cpu_baseline(pairs, args.cpu_seconds)
     if world > 1:
         rccl_probe_guarded(out, ex, rank, world, dev)      # prints the line (with the `rccl` block) itself
@@ -511,26 +531,138 @@ def rccl_probe_guarded(out, ex, rank, world, dev, timeout_s=60.0):
 
 
 def parity_checksum(rank, args, N, cap, kL, dL, nL, kR, dR, nR, uR, depth):
-    """sha256 of pair 0's outputs (keypoints L, descriptors L, keypoints R, descriptors R, uRight, depth — the valid prefixes) against the committed
-    oracle checksum of the same seeded pair.  ok = True / False, or None when no committed checksum applies (--density 3, rank > 7)."""
+    """sha256 of EVERY pair's outputs in the timed loop's buffers (keypoints L, descriptors L, keypoints R, descriptors R, uRight, depth — the valid
+    prefixes) against the committed oracle checksums of the rank's distinct seeded pairs (pair j of a step = distinct pair j % distinct;
+    tests/golden/bench_c2_seed1000.json holds 4 per rank).  ok = True / False, or None when no committed checksum applies (--density 3, rank > 7);
+    `pairs_checked` = how many of the step's pairs were compared, `pairs_failed` = their indices."""
     import hashlib
-    res = {"ok": None, "fixture": "tests/golden/bench_c2_seed1000.json", "rank0_outputs_sha256": None}
+    B = int(nL.numel())
+    nd = max(1, min(args.distinct, B))
+    res = {"ok": None, "fixture": "tests/golden/bench_c2_seed1000.json", "rank0_outputs_sha256": None, "pairs_per_pass": B, "pairs_checked": 0, "pairs_failed": []}
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_c2_seed1000.json")))["ranks"].get(str(rank))
     except Exception:
         gold = None
-    n_l, n_r = int(nL[0].item()), int(nR[0].item())
+    applies = gold is not None and args.density == 1 and (W, H, NFEAT) == (1920, 1080, 2000)
+    gp = (gold.get("pairs") or [gold]) if gold is not None else []
     kb = N.KP_DTYPE.itemsize
-    h = hashlib.sha256()
-    for buf, n, item in ((kL, n_l, kb), (dL, n_l, 32), (kR, n_r, kb), (dR, n_r, 32)):
-        h.update(buf[:n * item].cpu().numpy().tobytes())
-    h.update(uR[:n_l].cpu().numpy().tobytes())
-    h.update(depth[:n_l].cpu().numpy().tobytes())
-    res["rank0_outputs_sha256"] = h.hexdigest()
-    if gold is not None and args.density == 1 and (W, H, NFEAT) == (1920, 1080, 2000):
-        res["ok"] = (h.hexdigest() == gold["outputs_sha256"]) and n_l == gold["nL"] and n_r == gold["nR"]
-        res["expected_sha256"] = gold["outputs_sha256"]
+    n_l, n_r = nL.cpu().numpy(), nR.cpu().numpy()
+    h_kL, h_kR = kL.cpu().numpy().reshape(B, cap * kb), kR.cpu().numpy().reshape(B, cap * kb)
+    h_dL, h_dR = dL.cpu().numpy().reshape(B, cap * 32), dR.cpu().numpy().reshape(B, cap * 32)
+    h_uR, h_dp = uR.cpu().numpy().reshape(B, cap), depth.cpu().numpy().reshape(B, cap)
+    distinct_hashes = {}
+    for j in range(B):
+        a, b = int(n_l[j]), int(n_r[j])
+        h = hashlib.sha256()
+        if 0 <= a <= cap and 0 <= b <= cap:
+            for row, n, item in ((h_kL[j], a, kb), (h_dL[j], a, 32), (h_kR[j], b, kb), (h_dR[j], b, 32)):
+                h.update(row[:n * item].tobytes())
+            h.update(h_uR[j, :a].tobytes())
+            h.update(h_dp[j, :a].tobytes())
+        hx = h.hexdigest()
+        if j == 0:
+            res["rank0_outputs_sha256"] = hx
+        distinct_hashes.setdefault(j % nd, set()).add(hx)
+        if applies and (j % nd) < len(gp):
+            g = gp[j % nd]
+            res["pairs_checked"] += 1
+            if not (hx == g["outputs_sha256"] and a == g["nL"] and b == g["nR"]):
+                res["pairs_failed"].append(j)
+    res["copies_identical"] = all(len(v) == 1 for v in distinct_hashes.values())      # every copy of a distinct pair gave the same bytes (holds with or without a fixture)
+    if applies:
+        res["ok"] = res["pairs_checked"] > 0 and not res["pairs_failed"] and res["copies_identical"]
+        res["expected_sha256"] = gp[0]["outputs_sha256"]
     return res
+
+
+def measured_copy_peak(ex, torch, dev, gib=2.0, reps=6):
+    """the HBM roofline is quoted against the vendor peak AND against what a device-to-device copy reaches on THIS box, timed in this
+    run: `gib` GiB (>= 2: eight times the 256 MiB Infinity Cache) copied (a) by hipMemcpyAsync device-to-device and (b) by the library's 16-byte-per-lane
+    grid-stride copy kernel (hs_debug_stream_copy: the access width of this library's own streaming loads).  GB/s counts read + written bytes.
+    torch.cuda.Event on torch's current stream, on which both copies are enqueued."""
+    import ctypes as C
+    try:
+        n = int(gib * (1 << 30)) // 4096 * 4096
+        src = torch.empty(n, dtype=torch.uint8, device=dev)
+        dst = torch.empty(n, dtype=torch.uint8, device=dev)
+        src.view(torch.int32).random_(0, 1 << 30)         # not zeros: zero pages can be special-cased by the memory system
+        dst.zero_()
+        st = torch.cuda.current_stream()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+        def run(fn):
+            fn(); fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            e1.synchronize()
+            return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+        def memcpy():
+            rc = hip.hipMemcpyAsync(dst.data_ptr(), src.data_ptr(), n, 3, st.cuda_stream)        # 3 = hipMemcpyDeviceToDevice
+            if rc:
+                raise RuntimeError("hipMemcpyAsync -> %d" % rc)
+
+        def kernel():
+            ex.debug_stream_copy(dst.data_ptr(), src.data_ptr(), n, 16, st.cuda_stream)
+
+        g_memcpy = run(memcpy)
+        g_kernel = run(kernel)
+        same = bool(torch.equal(dst[:1 << 20], src[:1 << 20]) and torch.equal(dst[-(1 << 20):], src[-(1 << 20):]))
+        del src, dst
+        torch.cuda.empty_cache()
+        return {"GBps": round(max(g_memcpy, g_kernel), 1), "hipMemcpyAsync_d2d_GBps": round(g_memcpy, 1), "copy_kernel_16B_per_lane_GBps": round(g_kernel, 1),
+                "bytes_copied": n, "reps": reps, "counts": "read + written bytes", "copy_verified": same}
+    except Exception as e:      # a secondary figure must never take the headline down
+        return {"GBps": None, "error": str(e)[:200]}
+
+
+def one_pair_latency(HS, N, torch, dev, local_rank, pair, sp, calls=400):
+    """What a SLAM front end lives on: ONE 1080p pair per call of hs_stereo_frontend_batch_device on a handle of its own (the small-batch launch plan).
+    `back_to_back_ms` = calls enqueued without waiting (the device time a pair occupies the GPU: 1 / throughput at one pair per call);
+    `synchronous_ms` = enqueue + hs_orb_synchronize per call (what a caller that needs the result before its next step waits for; host launch cost included)."""
+    try:
+        ex1 = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NFEAT), device=local_rank)
+        cap = ex1.max_keypoints()
+        kb = N.KP_DTYPE.itemsize
+        L, R = torch.from_numpy(pair[0]).to(dev), torch.from_numpy(pair[1]).to(dev)
+        mk = lambda n, dt=torch.uint8: torch.zeros(n, dtype=dt, device=dev)
+        kL, kR, dL, dR, nL, nR = mk(cap * kb), mk(cap * kb), mk(cap * 32), mk(cap * 32), mk(1, torch.int32), mk(1, torch.int32)
+        uR, depth = mk(cap, torch.float32), mk(cap, torch.float32)
+        ex1.reserve(W, H, 2)
+
+        def call():
+            ex1.stereo_frontend_batch_device(L.data_ptr(), R.data_ptr(), 1, W, H, W, W * H, kL.data_ptr(), dL.data_ptr(), nL.data_ptr(),
+                                             kR.data_ptr(), dR.data_ptr(), nR.data_ptr(), cap, sp, uR.data_ptr(), depth.data_ptr(), 0)
+        for _ in range(20):
+            call()
+        ex1.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call()
+        ex1.synchronize()
+        b2b = (time.perf_counter() - t0) / calls * 1e3
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            call()
+            ex1.synchronize()
+        syn = (time.perf_counter() - t0) / calls * 1e3
+        return {"back_to_back_ms": round(b2b, 4), "synchronous_ms": round(syn, 4), "calls": calls, "keypoints_left": int(nL.item()),
+                "launches_per_call": sum(max(1, ex1._lib.hs_orb_stage_launches(ex1._h, st)) for st in range(6))}
+    except Exception as e:
+        return {"back_to_back_ms": None, "error": str(e)[:200]}
+
+
+def under_profiler():
+    """True when a profiler's preloaded library rides along (rocprofv3 sets LD_PRELOAD / ROCPROF* / ROCP_*): it initialises the GPU in every child
+    process it is inherited by, so the secondary legs that start children (call_site, cpu_baseline) are skipped under it."""
+    e = os.environ
+    pre = e.get("LD_PRELOAD", "")
+    return ("rocprof" in pre or "roctracer" in pre or "rocprofiler" in pre
+            or any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) for k in e))
 
 
 def call_site():
@@ -538,7 +670,7 @@ def call_site():
     __graft_entry__.build(); INTEGRATION.md §6): ImageProcessing::ProcessStereoImage with two HipORBExtractor threads + HipStereomatcher, and the
     optional one-call HipStereoFrontend, in ms per 1080p pair, split into gather / C ABI / scatter.  A child process, run after the timed loop."""
     exe = os.path.join(ROOT, "tests", "cpp", "_build", "bench_adaptor")
-    if not os.path.exists(exe):
+    if not os.path.exists(exe) or under_profiler():
         return None
     import tempfile
     from hyslam_amd.synth import synth_stereo_pair
@@ -553,10 +685,10 @@ def call_site():
             confined = None
             try:
                 cpus = open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % sorted(os.sched_getaffinity(0))[0]).read().strip()
-                rc = subprocess.run(["taskset", "-c", cpus, exe, str(W), str(H), fl, fr, "20", "50000"], capture_output=True, timeout=180)
+                rc = subprocess.run([exe, str(W), str(H), fl, fr, "20", "50000", cpus], capture_output=True, timeout=180)      # the child confines ITSELF (sched_setaffinity before its first HIP call): no re-exec'ing launcher in between
                 if rc.returncode == 0:
                     dc = json.loads(rc.stdout.decode())
-                    confined = {"cpus": cpus, "how": "taskset -c", "TrackLocalMap_ms": dc["TrackLocalMap_SearchByProjection_ms"]["total"],
+                    confined = {"cpus": cpus, "how": "sched_setaffinity at the top of the child's main (before any HIP call)", "TrackLocalMap_ms": dc["TrackLocalMap_SearchByProjection_ms"]["total"],
                                 "ProcessStereoImage_ms_per_pair": dc["ProcessStereoImage_ms"]["total"], "HipStereoFrontend_pipelined_ms_per_pair": dc["HipStereoFrontend_ms"]["pipelined_per_pair"]}
             except Exception:
                 confined = None

@@ -89,6 +89,7 @@ struct hs_orb {
     // hs_orb_extract_batch (host-pointer call): one pinned block the three outputs come back into
     uint8_t* h_pin_out = nullptr; size_t pin_out_bytes = 0;
     int last_batch = 0; HsImg0 last_img0{};
+    int last_pyr_launches = 0;         // kernel launches the pyramid stage of the last call really enqueued (hs_launch_pyramid's return value)
     int last_stereo_launches = 2;      // launches of stage 4 in the last stereo call: strips + match (run_stereo) or match only (the front end with the strips inside the describe launch)
     // where the last host-pointer extraction (hs_orb_extract[_batch], hs_orb_wait) left its results on the DEVICE: what hs_frame_publish keeps
     const hs_keypoint* pub_kps = nullptr; const uint8_t* pub_desc = nullptr; int pub_cap = 0, pub_batch = 0;
@@ -583,14 +584,14 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
         if (rc != HS_OK) return rc;
         quadtree(0, 1, h->s_aux);
         HIP_TRY(h, hipEventRecord(h->ev_sjoin, h->s_aux));
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
+        h->last_pyr_launches = hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
         rc = fast(0, n_items - items0, 0, s);
         if (rc != HS_OK) return rc;
         quadtree(1, L - 1, s);
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_sjoin, 0));
     } else {
         mark(h, 0, s);
-        hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
+        h->last_pyr_launches = hs_launch_pyramid(h->d_lv, h->lv.data(), h->pyr_fuse.data(), h->pyr_chain.data(), L, img0, batch, s, deep);
         mark(h, 1, s);
         const int rc = fast(0, n_items, 0, s);
         if (rc != HS_OK) return rc;
@@ -1365,12 +1366,19 @@ int hs_frame_publish(hs_orb* h, int image, const hs_keypoint* kps, int n, hs_fra
     if (!token || !kps || n < 1 || n > 65535 || image < 0) return fail(h, HS_ERR_INVALID, "bad argument");
     if (!h->pub_kps || image >= h->pub_batch || n > h->pub_cap) return fail(h, HS_ERR_INVALID, "hs_frame_publish: no host-pointer extraction result of this handle to publish (call right after hs_orb_extract / hs_orb_extract_batch / hs_orb_wait)");
     HIP_TRY(h, hipSetDevice(h->device));
-    std::lock_guard<std::mutex> g(g_frames_mu);
-    FrameCache* c = frame_cache_of(h->device, true);
+    // The slot is picked and RESERVED under the process-wide lock (readers = -1: neither a publisher nor a reader nor hs_frame_cache_clear touches it),
+    // the HIP calls (event wait, a possible free + allocation, two copy enqueues) run without it — hs_frame_find / frame_acquire / hs_frame_release of other
+    // threads (the tracking thread's SearchByProjection) never wait behind an extractor thread's allocation — and the slot is published under the lock again.
     FrameSlot* sl = nullptr;
-    for (FrameSlot& q : c->slot) if (q.readers == 0 && (!sl || (q.token == 0 && sl->token != 0) || ((q.token == 0) == (sl->token == 0) && q.stamp < sl->stamp))) sl = &q;
-    if (!sl) return fail(h, HS_ERR_CAPACITY, "hs_frame_publish: every cache slot is being read");
-    sl->token = 0;
+    {
+        std::lock_guard<std::mutex> g(g_frames_mu);
+        FrameCache* c = frame_cache_of(h->device, true);
+        for (FrameSlot& q : c->slot) if (q.readers == 0 && (!sl || (q.token == 0 && sl->token != 0) || ((q.token == 0) == (sl->token == 0) && q.stamp < sl->stamp))) sl = &q;
+        if (!sl) return fail(h, HS_ERR_CAPACITY, "hs_frame_publish: every cache slot is being read");
+        sl->token = 0;
+        sl->readers = -1;
+    }
+    struct Unreserve { FrameSlot* s; ~Unreserve() { if (s) { std::lock_guard<std::mutex> g(g_frames_mu); s->readers = 0; } } } unreserve{sl};      // failure paths: the slot is empty (token 0) and free again
     if (!sl->ready) HIP_TRY(h, hipEventCreateWithFlags(&sl->ready, hipEventDisableTiming));
     if (n > sl->cap) {
         HIP_TRY(h, hipEventSynchronize(sl->ready));      // (a never-recorded event is complete)
@@ -1385,9 +1393,14 @@ int hs_frame_publish(hs_orb* h, int image, const hs_keypoint* kps, int n, hs_fra
     HIP_TRY(h, hipMemcpyAsync(sl->d_kps, h->pub_kps + (size_t)image * h->pub_cap, (size_t)n * sizeof(hs_keypoint), hipMemcpyDeviceToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(sl->d_desc, h->pub_desc + (size_t)image * h->pub_cap * HS_DESC_BYTES, (size_t)n * HS_DESC_BYTES, hipMemcpyDeviceToDevice, s));
     HIP_TRY(h, hipEventRecord(sl->ready, s));
-    sl->h_kps.assign(kps, kps + n);
-    sl->n = n; sl->stamp = ++g_frame_serial; sl->token = sl->stamp;
-    *token = sl->token;
+    sl->h_kps.assign(kps, kps + n);                      // (the slot is reserved: nobody compares against h_kps while token == 0)
+    {
+        std::lock_guard<std::mutex> g(g_frames_mu);
+        unreserve.s = nullptr;
+        sl->readers = 0;
+        sl->n = n; sl->stamp = ++g_frame_serial; sl->token = sl->stamp;
+        *token = sl->token;
+    }
     return HS_OK;
 }
 
@@ -1422,7 +1435,7 @@ int hs_frame_cache_clear(int device)
     for (size_t i = 0; i < g_frames.size(); i++) {
         FrameCache* c = g_frames[i];
         if (c->device != device) continue;
-        for (const FrameSlot& sl : c->slot) if (sl.readers > 0) return HS_ERR_INVALID;      // a call is reading a slot: not now
+        for (const FrameSlot& sl : c->slot) if (sl.readers != 0) return HS_ERR_INVALID;      // a call is reading a slot (> 0) or a publisher is filling one (-1): not now
         int cur = -1;
         (void)hipGetDevice(&cur);
         (void)hipSetDevice(device);
@@ -1915,6 +1928,7 @@ int hs_orb_stage_launches(const hs_orb* h, int stage)
     // batch (calls of <= deep_max_batch frames run the small-batch plan: one launch at 1080p instead of three), the stereo stage on the entry point
     if (!h || stage < 0 || stage >= HS_NUM_STAGES) return 0;
     if (stage == 0) {
+        if (h->last_pyr_launches > 0) return h->last_pyr_launches;      // counted by the launcher itself: a per-level fallback (caller-frame alignment, no big LDS) is included
         if (h->lv.empty()) return std::max(h->p.nlevels - 1, 0);
         if (h->last_batch > 0 && h->last_batch <= h->deep_max_batch && !h->pyr_deep.empty()) { int32_t o[8]; hs_debug_plan_summary(h, o); return o[1]; }
         return hs_pyramid_launch_count(h->lv.data(), h->p.nlevels);

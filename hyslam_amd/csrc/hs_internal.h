@@ -196,8 +196,8 @@ struct HsStripFuse { int32_t enabled, n_rows, n_strips, _r; float size_ref; int3
 inline int hs_stereo_strips(int n_rows) { return (n_rows > 0 ? ((n_rows - 1) >> 5) : 0) + 1; }
 
 // kernels_*.hip launchers (all asynchronous on `s`)
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s,
-                       const HsPyrChain* deep = nullptr /*[nlevels], host: the small-batch plan (long chains); used where deep[l].valid*/);
+int  hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse /*[nlevels], host*/, const HsPyrChain* chain /*[nlevels], host*/, int nlevels, HsImg0 img0, int batch, hipStream_t s,
+                       const HsPyrChain* deep = nullptr /*[nlevels], host: the small-batch plan (long chains); used where deep[l].valid*/);      // returns the kernel launches it enqueued
 // plans a chain over levels [first, first + n) (2 <= n <= HS_PYR_CHAIN_MAX): tile tables appended to `blob` (offsets until relocated); C.valid = 0 when the
 // geometry does not fit `lds_max` bytes of LDS
 void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,

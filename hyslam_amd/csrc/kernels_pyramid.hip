@@ -761,7 +761,7 @@ static int pyr_nw8_wg_per_cu()
     static int v = [] { const char* e = getenv("HS_PYRAMID_NW8"); return e ? atoi(e) : 3; }();
     return v;
 }
-void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s, const HsPyrChain* deep)
+int hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse* fuse, const HsPyrChain* chain, int nlevels, HsImg0 img0, int batch, hipStream_t s, const HsPyrChain* deep)
 {
     // the deep chains of small batches may want more than the default 64 KB of dynamic LDS (gfx950: 160 KB per CU).  Function attributes are PER DEVICE:
     // the raise is done once for every device a launch sequence is enqueued on (a handle on a second GPU of the process gets its own), and a device
@@ -778,7 +778,8 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse
         state[dev].store(ok ? 1 : 2, std::memory_order_release);
         return ok;
     }();
-    for (int l = 1; l < nlevels; l++) {
+    int n_launches = 0;      // what this call really enqueued (the plan can fall back per level: caller-frame alignment, LDS attribute refused)
+    for (int l = 1; l < nlevels; l++, n_launches++) {
         const HsLevel& D = h_lv[l];
         if (deep && deep[l].valid && l + deep[l].nstage <= nlevels) {
             bool vec16 = true;
@@ -846,6 +847,7 @@ void hs_launch_pyramid(const HsLevel* d_lv, const HsLevel* h_lv, const HsPyrFuse
         if (aligned) hipLaunchKernelGGL(k_resize_level<true>, grid, block, 0, s, d_lv, l, img0);
         else hipLaunchKernelGGL(k_resize_level<false>, grid, block, 0, s, d_lv, l, img0);
     }
+    return n_launches;
 }
 
 // launches of one hs_launch_pyramid call when every eligible pair is fused (the caller-frame alignment fallback adds one)

@@ -252,6 +252,10 @@ class ORBExtractor:
                                                                    d_kpsL, d_descL, d_nL, d_kpsR, d_descR, d_nR, cap,
                                                                    C.byref(sp), d_uRight, d_depth, stream or None))
 
+    def debug_stream_copy(self, d_dst, d_src, nbytes, width=16, stream=0):
+        """measurement utility (hs_debug_stream_copy): a grid-stride copy kernel of `width` (4 or 16) bytes per lane — known HBM traffic"""
+        N.check(self._h, self._lib.hs_debug_stream_copy(self._h, d_dst, d_src, nbytes, width, stream or None))
+
     def set_lanes(self, lanes):
         """1 or 2 internal launch sequences for the batched device entry points (hs_orb_set_lanes)."""
         N.check(self._h, self._lib.hs_orb_set_lanes(self._h, int(lanes)))

@@ -349,8 +349,13 @@ private:
         if (helpers_n == 0) { fill_geometry(0, n); fill_descriptors(0, n); return out; }
         hip_detail::Worker* const helpers = hip_detail::thread_workers();      // persistent per calling thread (HipORBExtractor.h)
         const size_t chunk = (n + helpers_n - 1) / helpers_n;
-        for (unsigned w = 0; w < helpers_n; w++) { const size_t a = std::min(n, w * chunk), b = std::min(n, (w + 1) * chunk); helpers[w].run([&fill_geometry, a, b] { fill_geometry(a, b); }); }
-        try { fill_descriptors(0, n); } catch (...) { for (unsigned w = 0; w < helpers_n; w++) { try { helpers[w].wait(); } catch (...) {} } throw; }
+        // a helper that has started references this frame's locals: whatever throws from here on (thread creation inside run() included) first waits for
+        // every helper that was started
+        unsigned started = 0;
+        try {
+            for (; started < helpers_n; started++) { const size_t a = std::min(n, started * chunk), b = std::min(n, (started + 1) * chunk); helpers[started].run([&fill_geometry, a, b] { fill_geometry(a, b); }); }
+            fill_descriptors(0, n);
+        } catch (...) { for (unsigned w = 0; w < started; w++) { try { helpers[w].wait(); } catch (...) {} } throw; }
         for (unsigned w = 0; w < helpers_n; w++) helpers[w].wait();
         return out;
     }

@@ -152,6 +152,8 @@ private:
         if (cpu < 0 || (have_domain && cpu < CPU_SETSIZE && CPU_ISSET(cpu, &domain))) return;
         cpu_set_t d;
         if (!l3_domain_of(cpu, &d)) return;
+        // a caller pinned to ONE CPU (domain ∩ its affinity mask = that CPU): a helper pinned beside it would run serially with it — leave the helper where it is
+        if (CPU_COUNT(&d) < 2) return;
         if (pthread_setaffinity_np(th.native_handle(), sizeof(d), &d) == 0) { domain = d; have_domain = true; }
 #endif
     }
@@ -244,9 +246,12 @@ public:
         static const int n_helpers = [] { const char* e = std::getenv("HYSLAM_AMD_SCATTER_THREADS"); const int v = e ? std::atoi(e) : -1; return v >= 0 ? std::min(v, 2) : HYSLAM_AMD_SCATTER_HELPERS; }();
         if (n >= 512 && n_helpers > 0) {
             const int parts = n_helpers + 1, a = n / parts, b = n_helpers > 1 ? 2 * n / parts : n;
-            helpers[0].run([&fill, a, b] { fill(a, b); });
-            if (n_helpers > 1) helpers[1].run([&fill, b, n] { fill(b, n); });
-            try { fill(0, a); } catch (...) { try { helpers[0].wait(); } catch (...) {} if (n_helpers > 1) { try { helpers[1].wait(); } catch (...) {} } throw; }      // the helpers hold references to this frame
+            int started = 0;
+            try {
+                helpers[0].run([&fill, a, b] { fill(a, b); }); started = 1;
+                if (n_helpers > 1) { helpers[1].run([&fill, b, n] { fill(b, n); }); started = 2; }
+                fill(0, a);
+            } catch (...) { for (int w = 0; w < started; w++) { try { helpers[w].wait(); } catch (...) {} } throw; }      // the helpers hold references to this frame (run() itself can throw: thread creation)
             helpers[0].wait(); if (n_helpers > 1) helpers[1].wait();
         } else fill(0, n);
         timing.scatter_ms = hip_detail::ms_since(t1);

@@ -42,7 +42,21 @@ static void extractFeatures(FeatureExtractor* ex, cv::Mat& img, std::vector<cv::
 
 int main(int argc, char** argv)
 {
-    if (argc < 5) { printf("usage: bench_adaptor W H left.raw right.raw [reps] [n_landmarks]\n"); return 2; }
+    if (argc < 5) { printf("usage: bench_adaptor W H left.raw right.raw [reps] [n_landmarks] [cpu-list e.g. 0-7,128-135]\n"); return 2; }
+    // optional confinement to a CPU list (one last-level-cache domain): applied HERE, before the first HIP call, so that no launcher that re-execs
+    // (taskset, numactl) has to sit between a profiler's preloaded library and this program
+    if (argc > 7 && argv[7][0]) {
+        cpu_set_t set; CPU_ZERO(&set); int n_set = 0;
+        for (const char* p = argv[7]; *p;) {
+            char* e; long a = strtol(p, &e, 10), b = a;
+            if (e == p) break;
+            if (*e == '-') { const char* q = e + 1; b = strtol(q, &e, 10); if (e == q) break; }
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) { CPU_SET((int)c, &set); n_set++; }
+            p = (*e == ',') ? e + 1 : e;
+            if (*e && *e != ',') break;
+        }
+        if (n_set == 0 || sched_setaffinity(0, sizeof set, &set) != 0) { printf("cannot confine to cpu list '%s'\n", argv[7]); return 4; }
+    }
     const int w = atoi(argv[1]), h = atoi(argv[2]);
     const int reps = argc > 5 ? atoi(argv[5]) : 30, n_lm = argc > 6 ? atoi(argv[6]) : 50000;
     std::vector<uint8_t> rawL, rawR;

@@ -44,25 +44,29 @@ def stereo(name, seed, w, h, nfeat, fx):
     print(name, len(kL), len(kR), int((depth > 0).sum()))
 
 
-def bench_c2(name, ranks=8, w=1920, h=1080, nfeat=2000):
-    """bench.py's own workload (BASELINE C2): sha256 of the oracle's outputs for pair 0 of every rank 0..7 (`synth_stereo_pair(1000 + 97 * rank,
-    1920, 1080)`, fx = 1050, mbf = fx * 0.12).  bench.py hashes what ITS timed loop left in the output buffers of pair 0 the same way and prints
-    `parity_checksum_ok` — data only: the oracle never travels into the bench's measured path."""
+def bench_c2(name, ranks=8, distinct=4, w=1920, h=1080, nfeat=2000):
+    """bench.py's own workload (BASELINE C2): sha256 of the oracle's outputs for EVERY distinct pair of every rank 0..7 (pair i of rank r =
+    `synth_stereo_pair(1000 + 97 * r + i, 1920, 1080)`, i = 0..3, fx = 1050, mbf = fx * 0.12).  bench.py hashes what ITS timed loop left in the
+    output buffers of all `--pairs` pairs the same way (pair j of a step is a copy of distinct pair j % 4) and prints `parity_checksum_ok` +
+    `pairs_checked` — data only: the oracle never travels into the bench's measured path.  The rank's top-level fields are pair 0's (round 1-5 layout)."""
     import json
     p = oracle.default_params(nfeat)
     sp = oracle.stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=h)
-    out = {"workload": "bench.py C2, pair 0 of rank r = synth_stereo_pair(1000 + 97 r, %d, %d), %d features, fx 1050, mbf 126" % (w, h, nfeat),
+    out = {"workload": "bench.py C2, pair i of rank r = synth_stereo_pair(1000 + 97 r + i, %d, %d), i = 0..%d, %d features, fx 1050, mbf 126" % (w, h, distinct - 1, nfeat),
            "hash": "sha256 over kL[:nL].tobytes() + dL[:nL] + kR[:nR] + dR[:nR] + uRight[:nL] + depth[:nL] (hs_keypoint records, uint8 descriptors, float32)",
            "ranks": {}}
     for r in range(ranks):
-        L, R = synth_stereo_pair(1000 + 97 * r, w, h)
-        kL, dL, kR, dR, uR, depth = oracle.stereo_frontend(p, sp, L, R)
-        hsh = hashlib.sha256()
-        for a in (kL, dL, kR, dR, uR, depth):
-            hsh.update(np.ascontiguousarray(a).tobytes())
-        out["ranks"][str(r)] = {"seed": 1000 + 97 * r, "left_sha256": sha(L), "nL": len(kL), "nR": len(kR), "stereo_matches": int((depth > 0).sum()),
-                                "outputs_sha256": hsh.hexdigest()}
-        print(name, r, len(kL), len(kR), int((depth > 0).sum()))
+        per_pair = []
+        for i in range(distinct):
+            L, R = synth_stereo_pair(1000 + 97 * r + i, w, h)
+            kL, dL, kR, dR, uR, depth = oracle.stereo_frontend(p, sp, L, R)
+            hsh = hashlib.sha256()
+            for a in (kL, dL, kR, dR, uR, depth):
+                hsh.update(np.ascontiguousarray(a).tobytes())
+            per_pair.append({"seed": 1000 + 97 * r + i, "left_sha256": sha(L), "nL": len(kL), "nR": len(kR), "stereo_matches": int((depth > 0).sum()),
+                             "outputs_sha256": hsh.hexdigest()})
+            print(name, r, i, len(kL), len(kR), int((depth > 0).sum()))
+        out["ranks"][str(r)] = dict(per_pair[0], pairs=per_pair)
     json.dump(out, open(os.path.join(OUT, name + ".json"), "w"), indent=1)
 
 
