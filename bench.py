@@ -587,7 +587,7 @@ def measured_copy_peak(ex, torch, dev, gib=2.0, reps=6):
         dst = torch.empty(n, dtype=torch.uint8, device=dev)
         src.view(torch.int32).random_(0, 1 << 30)         # not zeros: zero pages can be special-cased by the memory system
         dst.zero_()
-        st = torch.cuda.current_stream()
+        st = torch.cuda.Stream()                           # an explicit stream: both copies and both events are enqueued on it (stream 0 would mean "the handle's own stream" to the library)
         hip = C.CDLL("libamdhip64.so")
         hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 
@@ -609,8 +609,12 @@ def measured_copy_peak(ex, torch, dev, gib=2.0, reps=6):
         def kernel():
             ex.debug_stream_copy(dst.data_ptr(), src.data_ptr(), n, 16, st.cuda_stream)
 
+        torch.cuda.synchronize()
         g_memcpy = run(memcpy)
+        dst.zero_()
+        torch.cuda.synchronize()
         g_kernel = run(kernel)
+        torch.cuda.synchronize()
         same = bool(torch.equal(dst[:1 << 20], src[:1 << 20]) and torch.equal(dst[-(1 << 20):], src[-(1 << 20):]))
         del src, dst
         torch.cuda.empty_cache()
@@ -1072,13 +1076,20 @@ def cpu_baseline(pairs, budget_s):
         w = min(2 * w, max(1, nproc // 2))
     workers = best_w
     total, el_all, per_worker, note = leg(workers, True, budget_s)
-    all_cores = {"value": round(sum(per_worker), 2) if per_worker else None, "threads": 2 * workers, "nproc": nproc, "workers": workers,
+    final_v = sum(per_worker) if per_worker else None
+    probe_v = probe.get(str(workers))
+    # the all-cores figure is the BEST the box showed at this worker count (the 2-s probe leg or the full-budget leg: the job's CPU quota is throttled in
+    # bursts, and in round 5 the two disagreed by 25 % at the same worker count); both are printed, with their spread
+    best_v = max([v for v in (final_v, probe_v) if v is not None], default=None)
+    all_cores = {"value": round(best_v, 2) if best_v is not None else None, "full_budget_leg": round(final_v, 2) if final_v is not None else None, "probe_leg": probe_v,
+                 "spread_between_legs": round(abs(final_v - probe_v) / max(final_v, probe_v), 3) if (final_v and probe_v) else None,
+                 "threads": 2 * workers, "nproc": nproc, "workers": workers,
                  "cpus_available_to_this_job": cores_hint, "cpus_available_how": how, "scaling_probe_pairs_per_s_by_workers": probe,
                  "kind": "worker processes, 2 threads each, pinned to 2 logical CPUs each; worker count = the best point of the scaling probe",
                  "per_worker_pairs_per_s": {"min": round(min(per_worker), 3), "median": round(float(np.median(per_worker)), 3), "max": round(max(per_worker), 3)} if per_worker else None,
                  "sample": "%d pairs in %.1f s" % (total, el_all)}
-    if per_worker and ref:
-        all_cores["speedup_over_ref_structure"] = round(sum(per_worker) / ref, 1)
+    if best_v and ref:
+        all_cores["speedup_over_ref_structure"] = round(best_v / ref, 1)
     if note:
         all_cores["note"] = note
     out = {"value": None if ref is None else round(ref, 3), "unit": "stereo_pairs/s", "cores": 2, "kind": "port",

@@ -61,6 +61,8 @@ struct hs_orb {
     uint32_t* d_qhist = nullptr; unsigned long long* d_qbest = nullptr; uint32_t qhist_stride = 0, qbest_stride = 0;
     int fast_keys_levels = HS_MAX_LEVELS;   // HS_FAST_KEYS_LEVELS (read once; tuning): only the levels 0 .. n-1 get keys
     int fast_keys_max_batch = 16;      // HS_FAST_KEYS_MAX_BATCH (read once): calls of more frames than this run without the keys (see run_extract)
+    bool qt_large = false;             // a level's quota + 8 exceeds HS_QT_MAX_NODES (up to HS_QT_LARGE_NODES): the quadtree kernel's large-list instance, rectangles in d_qt_rects
+    uint8_t* d_qt_rects = nullptr;     // qt_large: batch_cap * nlevels * hs_quadtree_large_scratch_bytes()
     bool qt_small_ok = false;          // every level's list (quota + 8 nodes) fits the quadtree kernel's small instance (two workgroups per CU; HS_QT_SMALL=0 switches it off, read once)
     bool keys_dirty = false;           // a keyed call was enqueued and did not reach its end (any error return of run_extract): d_qhist / d_qbest may hold stale keys -> zeroed before the next call
     bool fast_keys = true;             // HS_FAST_KEYS=0 (read once): the quadtree kernel gathers the candidates and computes the keys itself (the scheme until round 3)
@@ -148,6 +150,7 @@ void free_geometry(hs_orb* h)
     hipFree(h->d_fast_items); h->d_fast_items = nullptr;
     hipFree(h->d_fast_items_n); h->d_fast_items_n = nullptr; h->fast_items_n = 0;
     hipFree(h->d_fast_ovf); h->d_fast_ovf = nullptr;
+    hipFree(h->d_qt_rects); h->d_qt_rects = nullptr;
     hipFree(h->d_cand); hipFree(h->d_pts_xy); hipFree(h->d_pts_sk); hipFree(h->d_pt_node); hipFree(h->d_cell_count);
     h->d_cand = nullptr; h->d_pts_xy = h->d_pts_sk = nullptr; h->d_pt_node = nullptr; h->d_cell_count = nullptr;
     hipFree(h->d_cand_count); hipFree(h->d_sel_count); h->d_cand_count = h->d_sel_count = nullptr;
@@ -205,7 +208,8 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
         V.qt_w = maxBX - minB; V.qt_h = maxBY - minB;
         V.n_ini = (V.qt_w > 0 && V.qt_h > 0) ? (int)roundf((float)V.qt_w / (float)V.qt_h) : 0;
         if (V.ncols > 0 && V.n_ini < 1) return fail(h, HS_ERR_INVALID, "aspect ratio w/h < 0.5 is undefined behaviour in the reference (nIni == 0)");
-        if (V.n_ini > HS_QT_MAX_NODES / 4) return fail(h, HS_ERR_INVALID, "aspect ratio too wide");
+        if (V.ncols < 1) V.n_ini = 0;      // a level without a FAST cell has no keypoints (D4) and no tree: its aspect ratio refuses nothing (until round 6 a 560 x 33 level 7 did: 528 roots)
+        if (V.n_ini > (h->qt_large ? HS_QT_LARGE_NODES : HS_QT_MAX_NODES) / 4) return fail(h, HS_ERR_INVALID, "aspect ratio too wide");
         V.hx = V.n_ini > 0 ? (float)V.qt_w / V.n_ini : 1.f;
         V.quota = h->quota[l];
         V.cand_cap = V.ncols * V.nrows * hs_cell_cap(V.wcell, V.hcell);
@@ -272,6 +276,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     HIP_TRY(h, hipMalloc(&h->d_pts_xy, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_pts_sk, ce * 4));
     HIP_TRY(h, hipMalloc(&h->d_pt_node, ce * 2));
+    if (h->qt_large) HIP_TRY(h, hipMalloc(&h->d_qt_rects, (size_t)batch * L * hs_quadtree_large_scratch_bytes()));
     HIP_TRY(h, hipMalloc(&h->d_cell_count, std::max<size_t>((size_t)cells * batch * 4, 64)));
     HIP_TRY(h, hipMalloc(&h->d_cand_count, (size_t)batch * L * 4));
     HIP_TRY(h, hipMalloc(&h->d_sel_count, (size_t)batch * L * 4));
@@ -570,7 +575,7 @@ int run_extract(hs_orb* h, HsImg0 img0, int batch, HsOut out, hipStream_t s, con
         hs_launch_quadtree(d_lv, L, batch, h->total_cells, h->d_cand, h->d_cell_count, h->cand_img_stride,
                            h->d_pts_xy, h->d_pts_sk, h->d_pt_node, h->d_cand_count, h->d_sel, h->d_sel_count, h->sel_img_stride, h->d_sel_perm, h->qt_point_domain ? 1 : 0,
                            level_first, level_count, use_keys ? h->d_qhist : nullptr, h->d_qbest, h->qhist_stride, h->qbest_stride, h->keep_points ? 1 : 0,
-                           h->qt_small_ok ? 1 : 0, st);
+                           h->qt_large ? 2 : (h->qt_small_ok ? 1 : 0), h->d_qt_rects, st);
     };
     if (split) {
         if (!h->s_aux) {
@@ -762,7 +767,8 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     for (int l = 0; l < L - 1; l++) { h->quota[l] = cv_round_f(nDesired); sum += h->quota[l]; nDesired *= factor; }
     h->quota[L - 1] = std::max(p->nfeatures - sum, 0);
     for (int l = 0; l < L; l++)
-        if (h->quota[l] + 8 > HS_QT_MAX_NODES) { delete h; return HS_ERR_INVALID; }
+        if (h->quota[l] + 8 > HS_QT_LARGE_NODES) { delete h; return HS_ERR_INVALID; }      // (a level's quota above 3320: nFeatures beyond ~11 600 @1.4 / ~15 300 @1.2 with 8 levels)
+    for (int l = 0; l < L; l++) if (h->quota[l] + 8 > HS_QT_MAX_NODES) h->qt_large = true;
     h->qt_small_ok = true;
     for (int l = 0; l < L; l++) if (h->quota[l] + 8 > hs_quadtree_small_nodes()) h->qt_small_ok = false;
     // ... and only on request (HS_QT_SMALL=1, read once): measured at 32 / 64 pairs per call the two-per-CU instance is SLOWER (quadtree 0.0631 against 0.0606 ms,

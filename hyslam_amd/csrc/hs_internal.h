@@ -12,7 +12,8 @@
 #define HS_EDGE 19                 // EDGE_THRESHOLD, ORBExtractor.cpp:74
 #define HS_BORDER 16               // minBorderX = EDGE_THRESHOLD-3, ORBExtractor.cpp:413
 #define HS_MAX_CELL_H 125           // tallest FAST cell (the FAST kernel's LDS tile holds hcell + 6 rows; list entries keep the row in 7 bits)
-#define HS_QT_MAX_NODES 2048       // quadtree list capacity in LDS (>= largest per-level quota + 8)
+#define HS_QT_MAX_NODES 2048       // quadtree list capacity in LDS of the general instance (>= largest per-level quota + 8)
+#define HS_QT_LARGE_NODES 3328     // ... of the large-list instance (rectangles in global scratch, no points in LDS: 161.9 KB of the CU's 160 KiB); quotas up to 3320 per level
 #define HS_QT_THREADS 1024
 
 // Per-level geometry and buffers; lives in device memory, read through scalar loads.
@@ -232,8 +233,11 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm /*spatial order per (image, level)*/, int force_point_domain, int level_first, int level_count,
                         uint32_t* qhist /*nullptr: the FAST launch left no keys — gather*/, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
                         int keep_points /*debug: gather the candidates into pts_* even when the keys make it unnecessary*/,
-                        int small_lists_ok /*every level's quota + 8 <= hs_quadtree_small_nodes(): launches of > 256 workgroups may use the two-per-CU instance*/, hipStream_t s);
+                        int list_mode /*0: the general instance; 1: every level's quota + 8 <= hs_quadtree_small_nodes(), launches of > 256 workgroups may use the two-per-CU instance;
+                                        2: a quota + 8 > HS_QT_MAX_NODES: the large-list instance (needs rect_scratch)*/,
+                        uint8_t* rect_scratch /*list_mode 2: batch * nlevels * hs_quadtree_large_scratch_bytes(), indexed by (image, level)*/, hipStream_t s);
 int hs_quadtree_small_nodes();
+size_t hs_quadtree_large_scratch_bytes();
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,
                         const uint32_t* sel_xys, const int32_t* sel_count, const uint16_t* sel_perm, int sel_img_stride, int max_sel,
                         const uint16_t* taps7, HsOut out, hipStream_t s, bool fast_taps, HsStripFuse strips);

@@ -124,7 +124,7 @@ extern "C" void hs_debug_qt_profile(unsigned long long* out128) { (void)hipDevic
 #else
 #define QT_MARK(tag)
 #endif
-template <int QT_M, int QT_PTS>
+template <int QT_M, int QT_PTS, bool RECT_GLOBAL>
 __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ lv, int nlevels, int total_cells,
                                                    const uint2* __restrict__ cand,
                                                    const int32_t* __restrict__ cell_count, uint64_t cand_img_stride,
@@ -133,11 +133,13 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
                                                    uint32_t* __restrict__ sel_xys, int32_t* __restrict__ sel_count, int sel_img_stride,
                                                    uint16_t* __restrict__ sel_perm, int force_point_domain, int level_first,
                                                    uint32_t* __restrict__ qhist, unsigned long long* __restrict__ qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride,
-                                                   int keep_points)
+                                                   int keep_points, uint8_t* __restrict__ rect_scratch)
 {
-    // point domain: node rectangles; count domain: the histogram pyramid (u16) — sized for the larger of the two
-    __shared__ alignas(16) uint8_t s_r1[qt_cmax(2 * (int)sizeof(QtRects<QT_M>), QT_HPYR * 2)];
-    QtRects<QT_M>* const s_rect = reinterpret_cast<QtRects<QT_M>*>(s_r1);
+    // point domain: node rectangles; count domain: the histogram pyramid (u16) — sized for the larger of the two.  RECT_GLOBAL (the large-list
+    // instance): the rectangles live in a per-workgroup piece of global scratch instead and the LDS only holds the pyramid
+    __shared__ alignas(16) uint8_t s_r1[RECT_GLOBAL ? QT_HPYR * 2 : qt_cmax(2 * (int)sizeof(QtRects<QT_M>), QT_HPYR * 2)];
+    QtRects<QT_M>* const s_rect = reinterpret_cast<QtRects<QT_M>*>(s_r1);      // (as the pyramid's base address only when RECT_GLOBAL)
+    QtRects<QT_M>* const rect_base = RECT_GLOBAL ? reinterpret_cast<QtRects<QT_M>*>(rect_scratch + ((size_t)blockIdx.y * nlevels + level_first + blockIdx.x) * 2 * sizeof(QtRects<QT_M>)) : s_rect;
     __shared__ uint32_t s_cnt[2][QT_M];            // points per node
     __shared__ uint16_t s_ekey[2][QT_M];           // count domain: depth << 13 | cell index at that depth (root * 4^depth + path)
     // child counts, indexed 4*rank + child; also: the marks (u16 per pyramid entry), the sort keys of phase 2 (<= 8 bytes per node), and at the
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(QT_T) void k_quadtree(const HsLevel* __restrict__ l
     uint16_t* pnode = pt_node_all + (size_t)img * cand_img_stride + L.cand_off;
     uint32_t* out = sel_xys + ((size_t)img * sel_img_stride + L.sel_off) * 3;
     int32_t* out_n = &sel_count[img * nlevels + level];
-    auto view = [&](int c) { QtNodes v; v.x0 = s_rect[c].x0; v.x1 = s_rect[c].x1; v.y0 = s_rect[c].y0; v.y1 = s_rect[c].y1; v.cnt = s_cnt[c]; v.ekey = s_ekey[c]; return v; };
+    auto view = [&](int c) { QtNodes v; v.x0 = rect_base[c].x0; v.x1 = rect_base[c].x1; v.y0 = rect_base[c].y0; v.y1 = rect_base[c].y1; v.cnt = s_cnt[c]; v.ekey = s_ekey[c]; return v; };
 
     const int nIni = L.n_ini;
     const float hX = L.hx;
@@ -1002,21 +1004,28 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         const uint2* cand, const int32_t* cell_count, uint64_t cand_img_stride,
                         uint32_t* pts_xy, uint32_t* pts_sk, uint16_t* pt_node, int32_t* cand_count,
                         uint32_t* sel_xys, int32_t* sel_count, int sel_img_stride, uint16_t* sel_perm, int force_point_domain, int level_first, int level_count,
-                        uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, int keep_points, int small_lists_ok, hipStream_t s)
+                        uint32_t* qhist, unsigned long long* qbest, uint32_t qhist_img_stride, uint32_t qbest_img_stride, int keep_points, int list_mode, uint8_t* rect_scratch, hipStream_t s)
 {
     if (level_count <= 0) return;
     dim3 grid(level_count, batch, 1);
     // more workgroups than CUs and every list fits the small instance: two workgroups per CU (77 KB of LDS each) instead of rounds of 256
-    const bool small = small_lists_ok && (long long)level_count * batch > 256;
-    if (small)
-        hipLaunchKernelGGL((k_quadtree<QT_M_SMALL, 0>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
+    const bool small = list_mode == 1 && (long long)level_count * batch > 256;
+    if (list_mode == 2)      // a quota above HS_QT_MAX_NODES - 8 (the reference's init extractor of its "Imaging" camera: 9000 features @1.4 -> 2758 on level 0)
+        hipLaunchKernelGGL((k_quadtree<HS_QT_LARGE_NODES, 0, true>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
                            pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
-                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
+                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points, rect_scratch);
+    else if (small)
+        hipLaunchKernelGGL((k_quadtree<QT_M_SMALL, 0, false>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
+                           pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
+                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points, nullptr);
     else
-        hipLaunchKernelGGL((k_quadtree<HS_QT_MAX_NODES, QT_PTS_BIG>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
+        hipLaunchKernelGGL((k_quadtree<HS_QT_MAX_NODES, QT_PTS_BIG, false>), grid, dim3(QT_T), 0, s, d_lv, nlevels, total_cells, cand, cell_count, cand_img_stride,
                            pts_xy, pts_sk, pt_node, cand_count, sel_xys, sel_count, sel_img_stride, sel_perm, force_point_domain, level_first,
-                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points);
+                           qhist, qbest, qhist_img_stride, qbest_img_stride, keep_points, nullptr);
 }
+
+// bytes of global scratch ONE workgroup (one (image, level)) of the large-list instance needs for its two rectangle buffers
+size_t hs_quadtree_large_scratch_bytes() { return 2 * sizeof(QtRects<HS_QT_LARGE_NODES>); }
 
 // largest list the small instance holds (hs_api.hip: every level's quota + 8 must fit)
 int hs_quadtree_small_nodes() { return QT_M_SMALL; }

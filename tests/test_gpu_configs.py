@@ -339,6 +339,48 @@ def test_stereo_front_end_nine_pairs_one_call(gpu, fuse, monkeypatch):
     assert run(dl.ptr + 3 * W * H, dr.ptr + 3 * W * H, 2, ref[3:5]) > 100
 
 
+def test_bench_launch_shape_64_pairs_1080p(gpu):
+    """bench.py's own default step, in full: 64 stereo pairs (128 frames of 1920x1080, separate copies in HBM of the 4 distinct pairs of rank 0 —
+    synth_stereo_pair(1000 + i), pair j = distinct pair j % 4) through ONE hs_stereo_frontend_batch_device call at 2000 features, fx 1050, mbf 126.
+    Every one of the 64 pairs' keypoints, descriptors, uRight and depth against oracle.stereo_frontend (4 oracle runs; the other 60 must equal their
+    copy's), twice on the same handle, and the committed checksums bench.py verifies itself against (tests/golden/bench_c2_seed1000.json)."""
+    import hashlib, json, os
+    W, H, B, ND, NF = 1920, 1080, 64, 4, 2000
+    pairs = [synth_stereo_pair(1000 + i, W, H) for i in range(ND)]
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=NF))
+    ex.reserve(W, H, 2 * B)
+    cap = ex.max_keypoints()
+    dl = hipmem.DevBuf.from_numpy(np.stack([pairs[j % ND][0] for j in range(B)]))
+    dr = hipmem.DevBuf.from_numpy(np.stack([pairs[j % ND][1] for j in range(B)]))
+    kb, db = cap * KB, cap * 32
+    dk = [hipmem.DevBuf(B * kb) for _ in range(2)]; dd = [hipmem.DevBuf(B * db) for _ in range(2)]; dn = [hipmem.DevBuf(B * 4) for _ in range(2)]
+    du, dz = hipmem.DevBuf(B * cap * 4), hipmem.DevBuf(B * cap * 4)
+    sp = HS.stereo_params(HS.Camera(fx=1050.0, mbf=1050.0 * 0.12, mnMaxY=float(H)))
+    p = oracle.default_params(NF)
+    osp = oracle.stereo_params(fx=1050.0, mbf=1050.0 * 0.12, n_rows=H)
+    ref = [oracle.stereo_frontend(p, osp, L, R) for L, R in pairs]
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_c2_seed1000.json")))["ranks"]["0"]["pairs"]
+    for rep in range(2):
+        ex.stereo_frontend_batch_device(dl.ptr, dr.ptr, B, W, H, W, W * H, dk[0].ptr, dd[0].ptr, dn[0].ptr, dk[1].ptr, dd[1].ptr, dn[1].ptr, cap, sp, du.ptr, dz.ptr, 0)
+        ex.synchronize()
+        nL, nR = dn[0].to_numpy(np.int32, B), dn[1].to_numpy(np.int32, B)
+        kL = dk[0].to_numpy(N.KP_DTYPE, B * cap).reshape(B, cap); kR = dk[1].to_numpy(N.KP_DTYPE, B * cap).reshape(B, cap)
+        dL = dd[0].to_numpy(np.uint8, B * db).reshape(B, cap, 32); dR = dd[1].to_numpy(np.uint8, B * db).reshape(B, cap, 32)
+        u, z = du.to_numpy(np.float32, B * cap).reshape(B, cap), dz.to_numpy(np.float32, B * cap).reshape(B, cap)
+        for j in range(B):
+            okL, odL, okR, odR, ou, oz = ref[j % ND]
+            assert nL[j] == len(okL) and nR[j] == len(okR), (rep, j)
+            assert kL[j, :nL[j]].tobytes() == okL.tobytes() and kR[j, :nR[j]].tobytes() == okR.tobytes(), (rep, j)
+            assert np.array_equal(dL[j, :nL[j]], odL) and np.array_equal(dR[j, :nR[j]], odR), (rep, j)
+            assert np.array_equal(u[j, :nL[j]], ou) and np.array_equal(z[j, :nL[j]], oz), (rep, j)
+            assert (oz > 0).sum() > 300, j
+            h = hashlib.sha256()
+            for a in (kL[j, :nL[j]], dL[j, :nL[j]], kR[j, :nR[j]], dR[j, :nR[j]], u[j, :nL[j]], z[j, :nL[j]]):
+                h.update(np.ascontiguousarray(a).tobytes())
+            g = gold[j % ND]
+            assert h.hexdigest() == g["outputs_sha256"] and nL[j] == g["nL"] and nR[j] == g["nR"], (rep, j)
+
+
 def test_reserve_failure_leaves_handle_usable(gpu):
     """a failed configure() (absurd batch: allocation failure, or an unsupported geometry) must not leave stale geometry behind: the next
     small extract on the same handle still matches the oracle"""

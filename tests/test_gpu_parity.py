@@ -134,6 +134,36 @@ def test_ragged_sizes_and_profiles(gpu, w, h, nfeat, scale):
     stage_parity(synth_image(40 + w, w, h), nfeat, scale)
 
 
+@pytest.mark.parametrize("w,h,nfeat,scale,density", [(1352, 1014, 9000, 1.4, 1), (1352, 1014, 9000, 1.4, 4), (1280, 720, 3000, 1.2, 1),
+                                                      (4000, 3000, 9000, 1.4, 1), (1920, 1080, 10800, 1.4, 4), (1920, 1080, 15000, 1.2, 4)])
+def test_init_extractors_quota_above_2040(gpu, w, h, nfeat, scale, density):
+    """The reference builds, per camera, a third extractor with THREE TIMES the camera's feature count for the frames it sees while initialising
+    (ImageProcessing.cpp:34-36, :51-53).  For its own "Imaging" camera (3000 features @1.4, config/slam_feature_config.yaml:22-29; 2704x2028 at scale 0.5)
+    that is 9000 features @1.4: a level-0 quota of 2758, above the 2040 the quadtree kernel's general instance lists in LDS — until round 6 the library
+    REFUSED to create that extractor.  The large-list instance (<3328, no points in LDS, rectangles in global scratch>) takes quotas up to 3320 per level.
+    Stage-wise parity on the reference's own camera sizes, on a scene dense enough to FILL the quota (lists of more than 2048 nodes), at the SLAM camera's
+    init profile (3000 @1.2: the general instance), on the 4000x3000 camera, and at the largest quotas the instance holds (@1.4 and @1.2)."""
+    img = synth_image(60 + w + nfeat, w, h, density * max(40, (w * h) // 800))
+    ex, gk, gd = stage_parity(img, nfeat, scale)
+    q = ex.GetFeaturesPerLevel()
+    per_level = np.bincount(gk["octave"], minlength=8)
+    if density > 1:
+        assert per_level[0] >= q[0] and (q[0] <= 2040 or per_level[0] > 2040), (q, per_level)      # the quota was reached: the list really grew past the general instance's capacity
+    # the same handle on two frames in one call (both workgroups of a level index their own scratch)
+    img2 = synth_image(61 + w + nfeat, w, h, density * max(40, (w * h) // 800))
+    (k1, k2), (d1, d2) = ex.extract_batch([img, img2])
+    p = oracle.default_params(nfeat, scale)
+    ok2, od2 = oracle.extract(p, img2)
+    assert_same_features(k1, d1, gk, gd)
+    assert_same_features(k2, d2, ok2, od2)
+
+
+def test_quota_beyond_the_large_instance_is_refused_cleanly(gpu):
+    """a level quota above 3320 (here 20 000 features @1.2: 4342 on level 0) is still refused at create — with a status, not a crash"""
+    with pytest.raises(Exception):
+        HS.ORBExtractor(settings(20000, 1.2))
+
+
 def test_random_geometries(gpu):
     """seeded sweep over frame sizes, scale factors, level counts, cell sizes and quotas (cell rows with a single-cell last group, levels
     without cells, tiles of every height class, 4-level pyramids): full feature parity for each"""

@@ -93,6 +93,55 @@ def diagnose(ex, view, img, p, ok, od, gk, gd, big):
 STRESS = False                                  # --stress: big and saturated frames, tiny and huge quotas, banded frames, several frames per call
 
 
+REFUSALS = {}          # reason -> [count, of which the reference itself has no defined behaviour]
+
+
+def refusal_reason(where, err, w, h, nfeat, scale, levels, cell):
+    """Classifies a refusal and checks it against an INDEPENDENT statement of the rules: returns (reason, expected).  A configuration the
+    library refuses although no rule says so is a FAILURE of the campaign — the reference handles it, the drop-in does not.
+    `reference-undefined`: the reference divides by zero / indexes an empty vector / asserts there; `library-limit`: the reference would run."""
+    f32 = np.float32
+    sc = [f32(1)]
+    for _ in range(1, levels):
+        sc.append(f32(np.float64(sc[-1]) * np.float64(f32(scale))))
+    sizes = [(int(np.rint(f32(w) * (f32(1) / s))), int(np.rint(f32(h) * (f32(1) / s)))) for s in sc]
+    factor = f32(np.float64(1.0) / np.float64(f32(scale)))
+    nd = f32(nfeat) * (f32(1) - factor) / (f32(1) - f32(np.float64(factor) ** levels))
+    quota, tot = [], 0
+    for _ in range(levels - 1):
+        q = int(np.rint(nd)); quota.append(q); tot += q; nd = nd * factor
+    quota.append(max(nfeat - tot, 0))
+    rules = []
+    if max(quota) + 8 > 3328:
+        rules.append(("library-limit: a level quota above 3320 (quadtree list capacity)", False))
+    for (lw, lh) in sizes:
+        if lw < 1 or lh < 1:
+            rules.append(("reference-undefined: a pyramid level collapses to zero size (cv::resize asserts)", True)); break
+    for (lw, lh) in sizes:
+        qw, qh = lw - 32, lh - 32                 # minBorder = EDGE_THRESHOLD - 3 = 16 on both sides (ORBExtractor.cpp:413-416)
+        ncols, nrows = (int(f32(qw) / f32(cell)) if qw > 0 else 0), (int(f32(qh) / f32(cell)) if qh > 0 else 0)
+        if ncols < 1 or nrows < 1:
+            continue
+        wc, hc = int(np.ceil(f32(qw) / f32(ncols))), int(np.ceil(f32(qh) / f32(nrows)))
+        if wc > 247 or hc > 125:
+            rules.append(("library-limit: FAST cell wider than 247 px or taller than 125 px", False))
+        n_ini = int(np.round(f32(qw) / f32(qh)))
+        if n_ini < 1:
+            rules.append(("reference-undefined: aspect ratio w/h < 0.5 (nIni == 0: division by zero, ORBExtractor.cpp:183)", True))
+        elif n_ini > (3328 if max(quota) + 8 > 2048 else 2048) // 4:
+            rules.append(("library-limit: more than %d root nodes" % ((3328 if max(quota) + 8 > 2048 else 2048) // 4), False))
+    if where == "create":                       # hs_orb_create looks at the parameters and the quotas only (the geometry is checked at the first frame)
+        rules = [r for r in rules if "quota" in r[0]]
+        if levels < 1 or levels > 16 or not scale > 1.0 or nfeat < 1 or cell < 8:
+            rules.insert(0, ("library-limit: parameters out of range (levels outside 1..16, scale <= 1, cell < 8 px)", False))
+    if not rules:
+        reason, undefined, expected = "UNEXPECTED (%s): %s" % (where, err), False, False
+    else:
+        reason, undefined, expected = rules[0][0], rules[0][1], True
+    c = REFUSALS.setdefault(reason, [0, 0]); c[0] += 1; c[1] += int(undefined)
+    return reason, expected
+
+
 def one_case(rng, i):
     if STRESS:
         kind = ["checker", "checker", "checker", "noise", "cluster", "band", "band", "scene"][int(rng.integers(0, 8))]
@@ -112,7 +161,7 @@ def one_case(rng, i):
     scale = float(np.float32(rng.choice([1.1, 1.2, 1.2, 1.25, 1.3, 1.4, 1.5, 2.0])))
     levels = int(rng.choice([1, 2, 4, 6, 8, 8, 8, 10, 12]))
     if levels <= 2:
-        nfeat = min(nfeat, int(rng.integers(20, 2000)))      # a level's quota is limited to 2040 (quadtree list in LDS)
+        nfeat = min(nfeat, int(rng.integers(20, 3300)))      # a level's quota is limited to 3320 (quadtree list in LDS; 2040 until round 6)
     seed = int(rng.integers(0, 1 << 30))
     cell, fth = 30, 20
     if STRESS and rng.random() < 0.4:           # parameters the reference never varies but the C ABI accepts: the cell edge (N_CELLS) and the FAST threshold
@@ -130,8 +179,9 @@ def one_case(rng, i):
         desc += " taps %s" % taps
     try:
         ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=nfeat, fScaleFactor=scale, nLevels=levels, N_CELLS=cell), blur_taps=taps, fast_threshold=fth)
-    except Exception as e:                      # configuration the library refuses (too many levels for the size etc.): must be refused cleanly
-        return desc + "  -> refused at create: %s" % str(e)[:60], True
+    except Exception as e:                      # configuration the library refuses: must be refused cleanly AND for a stated reason
+        reason, expected = refusal_reason("create", str(e)[:60], w, h, nfeat, scale, levels, cell)
+        return desc + "  -> refused at create [%s]: %s" % (reason, str(e)[:60]), expected
     img = make_image(rng, kind, w, h, seed)
     pad = int(rng.choice([0, 0, 1, 3, 16, 61]))
     if pad:                                     # a row stride larger than the width (odd strides take the unaligned load path)
@@ -143,7 +193,8 @@ def one_case(rng, i):
     try:
         gk, gd = ex(view)
     except Exception as e:
-        return desc + "  -> refused at extract: %s" % str(e)[:80], True
+        reason, expected = refusal_reason("extract", str(e)[:80], w, h, nfeat, scale, levels, cell)
+        return desc + "  -> refused at extract [%s]: %s" % (reason, str(e)[:80]), expected
     p = oracle.default_params(nfeat, scale, levels)
     p.cell_px, p.fast_threshold = cell, fth
     if taps is not None:
@@ -250,7 +301,10 @@ def main():
         bad += not good
         if not good or time.time() - t0 > a.seconds:
             break
-    print("fuzz: %d cases, %d mismatches, %.0f s" % (i + 1, bad, time.time() - t0))
+    for reason, (cnt, undef) in sorted(REFUSALS.items(), key=lambda kv: -kv[1][0]):
+        print("refusals: %4d  %s" % (cnt, reason), flush=True)
+    print("fuzz: %d cases, %d mismatches or unexpected refusals, %d refused (%d of them where the reference itself is undefined), %.0f s"
+          % (i + 1, bad, sum(c for c, _ in REFUSALS.values()), sum(u for _, u in REFUSALS.values()), time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
