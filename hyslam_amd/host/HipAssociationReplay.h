@@ -39,6 +39,7 @@
 #include "cv_compat.h"
 #endif
 #include <algorithm>
+#include <cstring>
 #include <cstdint>
 #include <vector>
 

@@ -32,6 +32,7 @@
 #include "cv_compat.h"
 #endif
 #include <algorithm>
+#include <cstring>
 #include <cstdlib>
 #include <future>
 #include <set>

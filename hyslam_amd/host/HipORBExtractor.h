@@ -17,6 +17,7 @@
 #include "cv_compat.h"
 #endif
 #include <atomic>
+#include <cstring>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>

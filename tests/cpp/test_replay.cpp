@@ -1,5 +1,5 @@
-// test_replay — hyslam_amd/host/HipAssociationReplay.h against the real LandMarkMatches (host/cv_compat.h restates src/core/LandMarkMatches.cpp:6-51;
-// inside hySLAM it is the reference's own struct): after plan_replay + the selected associateLandMark calls, views_to_landmarks, outliers and
+// test_replay — hyslam_amd/host/HipAssociationReplay.h against host/cv_compat.h's RESTATEMENT of LandMarkMatches (src/core/LandMarkMatches.cpp:6-51 restated
+// in cv_compat.h:160-183, not the reference's own translation unit: OpenCV is absent here; inside hySLAM the adaptor meets the reference's own struct): after plan_replay + the selected associateLandMark calls, views_to_landmarks, outliers and
 // n_matches must equal what the reference's loop (FeatureMatcher.cc:113-118: one call per match, address order) leaves behind.
 // Host only: no GPU, no C ABI.   usage: test_replay [cases] [seed]     prints "REPLAY OK ..." on success
 #include <cstdio>

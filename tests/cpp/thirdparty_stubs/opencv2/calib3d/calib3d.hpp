@@ -1,0 +1,3 @@
+#pragma once
+// declaration-only stand-in (tests/cpp/thirdparty_stubs/opencv2/core/core.hpp explains)
+#include <opencv2/core/core.hpp>
