@@ -1921,7 +1921,7 @@ int hs_records_knn2_device(hs_orb* h, const uint8_t* d_records, size_t record_st
 int hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes, int width, void* stream)
 {
     if (!h) return HS_ERR_INVALID;
-    if (!d_dst || !d_src || (width != 4 && width != 16) || bytes % 16) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (!d_dst || !d_src || (width != 4 && width != 16 && width != 64) || bytes % 16) return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     hs_launch_stream_copy(d_dst, d_src, bytes, width, stream ? (hipStream_t)stream : h->stream);
     HIP_TRY(h, hipGetLastError());

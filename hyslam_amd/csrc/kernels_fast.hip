@@ -9,10 +9,10 @@
 //   * score = max(t, max_arc min(v-ring), max_arc min(ring-v)) - 1 over the 16 arcs of length 9.
 //
 // MI355X mapping (k_fast_rows).  The unit of work is a ROW GROUP: up to 8 horizontally adjacent cells of one cell row (<= 250 px of
-// interior), one single-wave workgroup per item, persistent launch, 11 workgroups per CU (14 KB of LDS each).  With ~1 % corners a
-// single 31x31 cell leaves a wave's lanes mostly idle after the first pass and pays the per-cell bookkeeping 6342 times per frame;
-// measured on 32 frames of 1080p the first design (one wave per cell: 0.48 ms, ~1.26 issued instructions per pixel, issue-bound at
-// ~1 instruction/cycle/CU) became 0.24 ms.
+// interior), one single-wave workgroup per item, persistent launch, 12 workgroups per CU (wide tiles of <= 40 rows: 12 800 bytes of LDS each = the
+// item's tile + its list; narrow tiles 16 per CU).  With ~1 % corners a single 31x31 cell leaves a wave's lanes mostly idle after the first pass and
+// pays the per-cell bookkeeping 6342 times per frame; measured on 32 frames of 1080p the first design (one wave per cell: 0.48 ms) became 0.24 ms in
+// round 2 and 0.143 ms in round 5.
 //   stage   the item's tile (interior + 3 px apron, <= 256 x 70 px) is fetched with 16-byte loads into registers while the PREVIOUS
 //           item is processed, then written to LDS; the only HBM traffic of the kernel is this one read of each level
 //   scan A  quick reject on the four compass points, 4 pixel columns x 8 rows per lane and block: 14 tile rows in registers, reduced to 6
@@ -36,8 +36,14 @@
 //   cand[slot] = { y<<16 | x,  score<<24 | cell }   (coordinates relative to (16,16), as in vToDistributeKeys; cell = row-major cell index
 //                                                    of the level); one 8-byte store per survivor, ~20 records = two cache lines per item
 //   cell_count[image][first global cell of the item] = number of slots used (the entries of the item's other cells are not written).
-// Bound: VALU issue (SQ_ACTIVE_INST_VALU: 77 % of the four SIMDs' issue slots, with 11 single-wave workgroups per CU — 10 -> 11 workgroups
-// buys 2 %, so more occupancy would not help); HBM bytes = P per frame.
+// Bound (rounds 5-6): half by SIMD throughput and half by what ONE wave can issue, at 3 waves per SIMD — 12 single-wave workgroups per CU
+// is what BOTH the LDS (12 800 bytes) and the registers (142 VGPRs) allow; t = 0.240 + 3.37 / n ms per 128 frames for n workgroups per CU, so occupancy is
+// the lever and every added instruction costs.  VALU 0.87 per busy CU cycle of a mix-weighted ceiling ~1.1.  LDS: 49 % of the busy cycles active, 18.5 % in
+// bank conflicts, 78 % of THOSE in the corner pass (tools/fast_lds_conflicts.sh: the 34 ds_read_u8 ring gathers of two candidates per lane at random tile
+// positions — 2.0 conflict cycles per LDS instruction, the birthday rate of 32 lanes on 32 banks; that phase keeps the LDS busy 74 % of its time).  Wider
+// reads do not help: gfx950 executes a ds_read_b32 / b64 at a byte-unaligned address ~6 x slower than an aligned one (tools/micro/lds_gather.hip: 7
+// unaligned ds_read_b64 per ring 2 250 ns against 17 ds_read_u8 600 ns per wave-iteration at 12 waves per CU), and aligned chunks need two reads + a
+// per-lane byte shift per ring row.  HBM bytes = P per frame, read once (measured 1.05-1.06 x).
 #include "hs_internal.h"
 #include <algorithm>
 #include <cstdlib>

@@ -867,8 +867,23 @@ __global__ __launch_bounds__(256) void k_copy_u128(uint4* __restrict__ d, const 
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
 }
+// four 16-byte vectors per lane in flight (each wave-instruction still covers 1 KiB of contiguous bytes): what a streaming copy needs to approach the
+// memory system's rate — the figure bench.py prints as the measured copy peak
+__global__ __launch_bounds__(256) void k_copy_u128x4(uint4* __restrict__ d_, const uint4* __restrict__ s_, size_t n)
+{
+    hs_u32x4* const d = reinterpret_cast<hs_u32x4*>(d_);
+    const hs_u32x4* const s = reinterpret_cast<const hs_u32x4*>(s_);
+    const size_t stride = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n; i += stride) {
+        const hs_u32x4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + 256), c = __builtin_nontemporal_load(s + i + 512), e = __builtin_nontemporal_load(s + i + 768);
+        __builtin_nontemporal_store(a, d + i); __builtin_nontemporal_store(b, d + i + 256); __builtin_nontemporal_store(c, d + i + 512); __builtin_nontemporal_store(e, d + i + 768);
+    }
+    for (int k = 0; k < 4; k++) if (i + 256 * k < n) d[i + 256 * k] = s[i + 256 * k];      // the ragged tail of the last pass
+}
 void hs_launch_stream_copy(void* d_dst, const void* d_src, size_t bytes, int width, hipStream_t s)
 {
+    if (width == 64) { hipLaunchKernelGGL(k_copy_u128x4, dim3(4096), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)d_src, bytes / 16); return; }
     if (width == 4) hipLaunchKernelGGL(k_copy_u32, dim3(2048), dim3(256), 0, s, (uint32_t*)d_dst, (const uint32_t*)d_src, bytes / 4);
     else hipLaunchKernelGGL(k_copy_u128, dim3(2048), dim3(256), 0, s, (uint4*)d_dst, (const uint4*)d_src, bytes / 16);
 }

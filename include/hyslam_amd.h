@@ -448,7 +448,7 @@ int  hs_orb_profile_begin(hs_orb* h);
 int  hs_orb_profile_pause(hs_orb* h);
 int  hs_orb_profile_end(hs_orb* h, double* ms, int32_t* launches);
 
-/* Measurement utility: streams `bytes` from d_src to d_dst with `width` (4 or 16) bytes per lane — a kernel of KNOWN HBM traffic
+/* Measurement utility: streams `bytes` from d_src to d_dst with `width` (4 or 16; 64 = four 16-byte vectors in flight per lane, non-temporal) bytes per lane — a kernel of KNOWN HBM traffic
  * in this library's own access widths, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/pmc_traffic.py). */
 int  hs_debug_stream_copy(hs_orb* h, void* d_dst, const void* d_src, size_t bytes, int width, void* stream);
 
