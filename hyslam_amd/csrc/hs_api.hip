@@ -82,6 +82,7 @@ struct hs_orb {
     uint16_t* d_taps = nullptr;
     // staging for the host-pointer entry points
     uint8_t* d_in = nullptr; size_t in_bytes = 0; size_t in_pitch = 0;
+    uint8_t* d_raw = nullptr; size_t raw_bytes = 0;      // hs_orb_extract_camera_batch: the camera's frames as uploaded (before PreProcessImg on the device)
     hs_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_n = nullptr; int out_cap = 0, out_batch = 0;
     float *d_ur = nullptr, *d_depth = nullptr; int32_t* d_bd = nullptr; size_t st_entries = 0;
     int32_t* d_strip_count = nullptr; void* d_strip_list = nullptr; size_t strip_count_entries = 0, strip_list_entries = 0;
@@ -814,7 +815,7 @@ static void orb_destroy_now(hs_orb* h)
     if (h->ev_sjoin) hipEventDestroy(h->ev_sjoin);
     if (h->stream) hipStreamSynchronize(h->stream);
     free_geometry(h);
-    hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in);
+    hipFree(h->d_lv); hipFree(h->d_taps); hipFree(h->d_in); hipFree(h->d_raw);
     hipFree(h->d_n);                     // the output block (counts, keypoints, descriptors)
     hipFree(h->d_ur); hipFree(h->d_depth); hipFree(h->d_bd); hipFree(h->d_scratch); hipFree(h->d_strip_count); hipFree(h->d_strip_list);
     hipFree(h->d_sm_kps); hipFree(h->d_sm_desc); hipFree(h->d_sm_n);
@@ -909,19 +910,21 @@ int hs_orb_extract_batch_device(hs_orb* h, const uint8_t* d_imgs, int batch, int
     return run_extract(h, img0, batch, out, s);
 }
 
-int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride,
-                         hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n)
+// the host-pointer extraction, shared by hs_orb_extract_batch (grey frames) and hs_orb_extract_camera_batch (pp != nullptr: the frames are what the camera
+// delivers — 1 / 3 / 4 channels at its own size — and ImageProcessing::PreProcessImg runs on the device between the upload and the pyramid)
+namespace {
+int extract_host_frames(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t stride, const hs_preprocess_params* pp,
+                        hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n, uint8_t* grey_out)
 {
-    if (!h) return HS_ERR_INVALID;
-    if (!n || batch < 1) return fail(h, HS_ERR_INVALID, "bad argument");
-    if (w == 0 || h_px == 0 || !imgs) { for (int i = 0; i < batch; i++) n[i] = 0; return HS_OK; }   // ORBExtractor.cpp:499-500
-    if (!kps || !desc || stride < w || cap < 1 || cap > 65535) return fail(h, HS_ERR_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     h->pub_kps = nullptr; h->pub_desc = nullptr; h->pub_batch = 0;
-    int rc = configure(h, w, h_px, batch);
+    int gw = w, gh = h_px;                                   // size of the grey level 0
+    if (pp) hs_preprocess_out_size(w, h_px, pp->scale, &gw, &gh);
+    if (gw < 1 || gh < 1) return fail(h, HS_ERR_INVALID, "the camera scale reduces the frame to nothing (cv::resize asserts on an empty size)");
+    int rc = configure(h, gw, gh, batch);
     if (rc != HS_OK) return rc;
     if (cap < h->max_kp) return fail(h, HS_ERR_CAPACITY, "cap < keypoints this frame size can produce; see hs_orb_max_keypoints");
-    const size_t pitch = ((size_t)w + 63) & ~(size_t)63, per_img = pitch * h_px;
+    const size_t pitch = ((size_t)gw + 63) & ~(size_t)63, per_img = pitch * gh;
     if (per_img * batch > h->in_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         hipFree(h->d_in); h->d_in = nullptr;
@@ -931,13 +934,30 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
     rc = ensure_outputs(h, batch, cap);
     if (rc != HS_OK) return rc;
     hipStream_t s = h->stream;
-    // Frames: the runtime's own pageable-memory path (measured: packing the rows into a pinned buffer on the calling thread first is SLOWER —
-    // one core copies 2 MB frames at ~10 GB/s, the runtime's staged copy moves them at more than twice that)
     for (int i = 0; i < batch; i++) if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
-    for (int i = 0; i < batch; i++) {
-        // a frame whose rows are as far apart as the staging copy's (width a multiple of 64, no padding: 1920 x 1080) is ONE linear copy
-        if ((size_t)stride == pitch) HIP_TRY(h, hipMemcpyAsync(h->d_in + per_img * i, imgs[i], per_img, hipMemcpyHostToDevice, s));
-        else HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
+    if (!pp) {
+        // Frames: the runtime's own pageable-memory path (measured: packing the rows into a pinned buffer on the calling thread first is SLOWER —
+        // one core copies 2 MB frames at ~10 GB/s, the runtime's staged copy moves them at more than twice that)
+        for (int i = 0; i < batch; i++) {
+            // a frame whose rows are as far apart as the staging copy's (width a multiple of 64, no padding: 1920 x 1080) is ONE linear copy
+            if (stride == pitch) HIP_TRY(h, hipMemcpyAsync(h->d_in + per_img * i, imgs[i], per_img, hipMemcpyHostToDevice, s));
+            else HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
+        }
+    } else {
+        // the camera's frames cross PCIe as they are (once), rows packed to a multiple of 4 bytes; PreProcessImg runs between the copy and the pyramid
+        const size_t row_bytes = (size_t)w * pp->channels, rpitch = (row_bytes + 3) & ~(size_t)3, raw_img = rpitch * h_px;
+        if (raw_img * batch > h->raw_bytes) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            hipFree(h->d_raw); h->d_raw = nullptr; h->raw_bytes = 0;
+            HIP_TRY(h, hipMalloc(&h->d_raw, raw_img * batch));
+            h->raw_bytes = raw_img * batch;
+        }
+        for (int i = 0; i < batch; i++) {
+            if (stride == rpitch) HIP_TRY(h, hipMemcpyAsync(h->d_raw + raw_img * i, imgs[i], raw_img, hipMemcpyHostToDevice, s));
+            else HIP_TRY(h, hipMemcpy2DAsync(h->d_raw + raw_img * i, rpitch, imgs[i], stride, row_bytes, h_px, hipMemcpyHostToDevice, s));
+        }
+        hs_launch_preprocess(h->d_raw, w, h_px, rpitch, raw_img, pp->channels, pp->rgb, pp->scale, h->d_in, gw, gh, pitch, per_img, 1, batch, s);
+        HIP_TRY(h, hipGetLastError());
     }
     HsImg0 img0{ h->d_in, h->d_in, batch, (uint64_t)pitch, (uint64_t)per_img };
     HsOut out{ h->d_kps, h->d_desc, h->d_n, h->d_kps, h->d_desc, h->d_n, batch, cap };
@@ -949,6 +969,8 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
     rc = ensure_pinned(h, &h->h_pin_out, &h->pin_out_bytes, out_bytes);
     if (rc != HS_OK) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_pin_out, h->d_n, out_bytes, hipMemcpyDeviceToHost, s));
+    // the grey frame the reference keeps beside the features (track_data.image = mImGray, ImageProcessing.cpp:60,108): tight rows, on request
+    if (grey_out) HIP_TRY(h, hipMemcpy2DAsync(grey_out, (size_t)gw, h->d_in, pitch, (size_t)gw, (size_t)gh * batch, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     memcpy(n, h->h_pin_out, (size_t)batch * 4);
     for (int i = 0; i < batch; i++) {            // only the keypoints that exist are copied; the rest of the caller's arrays is left untouched
@@ -958,6 +980,58 @@ int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w
     }
     h->pub_kps = h->d_kps; h->pub_desc = h->d_desc; h->pub_cap = cap; h->pub_batch = batch;
     return HS_OK;
+}
+}  // namespace
+
+int hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride,
+                         hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!n || batch < 1) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (w == 0 || h_px == 0 || !imgs) { for (int i = 0; i < batch; i++) n[i] = 0; return HS_OK; }   // ORBExtractor.cpp:499-500
+    if (!kps || !desc || stride < w || cap < 1 || cap > 65535) return fail(h, HS_ERR_INVALID, "bad argument");
+    return extract_host_frames(h, imgs, batch, w, h_px, (size_t)stride, nullptr, kps, desc, cap, n, nullptr);
+}
+
+void hs_preprocess_size(int w, int h_px, float scale, int32_t* ow, int32_t* oh)
+{
+    int a = 0, b = 0;
+    hs_preprocess_out_size(w, h_px, scale, &a, &b);
+    if (ow) *ow = a;
+    if (oh) *oh = b;
+}
+
+static bool preprocess_params_ok(const hs_preprocess_params* pp)
+{
+    return pp && (pp->channels == 1 || pp->channels == 3 || pp->channels == 4) && pp->scale > 0.f && pp->scale <= 16.f;
+}
+
+int hs_preprocess_device(hs_orb* h, const uint8_t* d_src, int w, int h_px, size_t row_stride, size_t image_stride, int batch, const hs_preprocess_params* pp,
+                         uint8_t* d_grey, size_t grey_row_stride, size_t grey_image_stride, void* stream)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!preprocess_params_ok(pp) || !d_src || !d_grey || w < 1 || h_px < 1 || w > 32768 || h_px > 32768 || batch < 1 || row_stride < (size_t)w * pp->channels)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    int gw, gh;
+    hs_preprocess_out_size(w, h_px, pp->scale, &gw, &gh);
+    if (gw < 1 || gh < 1 || gw > 16384 || gh > 16384) return fail(h, HS_ERR_INVALID, "the scaled frame is empty or larger than 16384 px");
+    if (grey_row_stride < (size_t)gw) return fail(h, HS_ERR_INVALID, "grey_row_stride < scaled width");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hs_launch_preprocess(d_src, w, h_px, row_stride, image_stride, pp->channels, pp->rgb, pp->scale, d_grey, gw, gh, grey_row_stride, grey_image_stride, 0, batch,
+                         stream ? (hipStream_t)stream : h->stream);
+    HIP_TRY(h, hipGetLastError());
+    return HS_OK;
+}
+
+int hs_orb_extract_camera_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t row_stride, const hs_preprocess_params* pp,
+                                hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n, uint8_t* grey_out)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!n || batch < 1) return fail(h, HS_ERR_INVALID, "bad argument");
+    if (w == 0 || h_px == 0 || !imgs) { for (int i = 0; i < batch; i++) n[i] = 0; return HS_OK; }   // ORBExtractor.cpp:499-500
+    if (!preprocess_params_ok(pp) || !kps || !desc || w < 0 || h_px < 0 || w > 32768 || h_px > 32768 || row_stride < (size_t)w * pp->channels || cap < 1 || cap > 65535)
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    return extract_host_frames(h, imgs, batch, w, h_px, row_stride, pp, kps, desc, cap, n, grey_out);
 }
 
 int hs_orb_extract(hs_orb* h, const uint8_t* img, int w, int h_px, int stride,

@@ -236,6 +236,12 @@ void hs_launch_quadtree(const HsLevel* d_lv, int nlevels, int batch, int total_c
                         int list_mode /*0: the general instance; 1: every level's quota + 8 <= hs_quadtree_small_nodes(), launches of > 256 workgroups may use the two-per-CU instance;
                                         2: a quota + 8 > HS_QT_MAX_NODES: the large-list instance (needs rect_scratch)*/,
                         uint8_t* rect_scratch /*list_mode 2: batch * nlevels * hs_quadtree_large_scratch_bytes(), indexed by (image, level)*/, hipStream_t s);
+// kernels_preprocess.hip: ImageProcessing::PreProcessImg (camera scale + grey) between the upload and the pyramid
+void hs_preprocess_out_size(int w, int h, float fscale, int* ow, int* oh);
+int  hs_preprocess_mode(int w, int h, int ow, int oh, float fscale);      // 0 copy, 1 the 2x2 area path (scale exactly 0.5), 2 bilinear
+void hs_launch_preprocess(const uint8_t* d_src, int sw, int sh, size_t src_row_stride, size_t src_img_stride, int channels, int rgb, float fscale,
+                          uint8_t* d_dst, int dw, int dh, size_t dst_row_stride, size_t dst_img_stride, int dst_may_pad /*rows may be written up to the next multiple of 4 columns*/,
+                          int batch, hipStream_t s);
 int hs_quadtree_small_nodes();
 size_t hs_quadtree_large_scratch_bytes();
 void hs_launch_describe(const HsLevel* d_lv, int nlevels, HsImg0 img0, int batch,

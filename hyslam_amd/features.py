@@ -153,6 +153,40 @@ class ORBExtractor:
                 self.last_frame_tokens.append(tok.value)
         return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
 
+    def extract_camera_batch(self, frames, rgb, scale, want_grey=False):
+        """ImageProcessing::PreProcessImg + the extractor call in one (src/main/ImageProcessing.cpp:44,55 / :76-77,82-83; hs_orb_extract_camera_batch): `frames`
+        as the camera delivers them — (h, w) or (h, w, 3 | 4) uint8, equal sizes — cross PCIe as they are, are scaled by the camera's `scale` and turned to grey on
+        the device (`rgb`: the camera's RGB key) and extracted.  Returns (keypoints per frame, descriptors per frame[, grey frames])."""
+        imgs = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        for im in imgs:
+            if im.ndim not in (2, 3) or (im.ndim == 3 and im.shape[2] not in (3, 4)) or im.shape != imgs[0].shape:
+                raise TypeError("camera frames must be equal-sized (h, w) or (h, w, 3 | 4) uint8 arrays")
+        b = len(imgs)
+        h, w = imgs[0].shape[:2]
+        cn = 1 if imgs[0].ndim == 2 else imgs[0].shape[2]
+        pp = N.PreprocessParams(cn, int(bool(rgb)), float(scale), 0)
+        ow, oh = C.c_int32(), C.c_int32()
+        self._lib.hs_preprocess_size(w, h, C.c_float(scale), C.byref(ow), C.byref(oh))
+        if ow.value < 1 or oh.value < 1:
+            raise N.HsError(N.HS_ERR_INVALID, "the camera scale reduces the frame to nothing")
+        self.reserve(ow.value, oh.value, b)
+        cap = self.max_keypoints()
+        kps = np.zeros((b, cap), KP_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        grey = np.zeros((b, oh.value, ow.value), np.uint8) if want_grey else None
+        ptrs = (C.c_void_p * b)(*[im.ctypes.data for im in imgs])
+        N.check(self._h, self._lib.hs_orb_extract_camera_batch(self._h, ptrs, b, w, h, imgs[0].strides[0], C.byref(pp),
+                                                               kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, n.ctypes.data_as(C.c_void_p),
+                                                               grey.ctypes.data_as(C.c_void_p) if want_grey else None))
+        out = ([kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)])
+        return out + ([grey[i] for i in range(b)],) if want_grey else out
+
+    def preprocess_device(self, d_src, w, h, row_stride, image_stride, batch, channels, rgb, scale, d_grey, grey_row_stride, grey_image_stride, stream=0):
+        """hs_preprocess_device: device frames -> device grey frames of the scaled size (asynchronous)"""
+        pp = N.PreprocessParams(int(channels), int(bool(rgb)), float(scale), 0)
+        N.check(self._h, self._lib.hs_preprocess_device(self._h, d_src, w, h, row_stride, image_stride, batch, C.byref(pp), d_grey, grey_row_stride, grey_image_stride, stream or None))
+
     def find_frame(self, keypoints):
         """token of the cached frame whose keypoint array equals `keypoints` bit for bit (0: none) — hs_frame_find, what the matcher adaptors do with a FeatureViews"""
         k = np.ascontiguousarray(keypoints, KP_DTYPE)

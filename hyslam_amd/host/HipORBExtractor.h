@@ -225,6 +225,31 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         int st = hs_orb_extract(h, image.ptr(0), image.cols, image.rows, (int)image.step, kps.data(), desc.data(), cap, &n);
         if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        deliver(n, t0, _keypoints, descriptors);
+    }
+    // ImageProcessing::PreProcessImg + the extractor call in ONE call (src/main/ImageProcessing.cpp:44,55 / :76-77,82-83): `raw` is the frame as the camera
+    // delivers it (CV_8UC1 / CV_8UC3 / CV_8UC4), `rgb` and `scale` are the camera's RGB and scale keys (Camera::RGB, Camera::scale).  The frame crosses PCIe
+    // as it is, cv::resize by the scale and cvtColor to grey run on the device in front of the pyramid (hs_orb_extract_camera_batch) — no CPU resize of a
+    // 2704 x 2028 x 3 frame in front of a 0.1 ms extraction.  `grey` (may be nullptr) receives what the reference keeps as mImGray / track_data.image.
+    // Optional edit in hySLAM: replace `mImGray = PreProcessImg(mImGray, RGB, scale); (*extractor)(mImGray, cv::Mat(), keys, descs);` by this.
+    void extractFromCamera(const cv::Mat& raw, bool rgb, float scale, cv::Mat* grey, std::vector<cv::KeyPoint>& _keypoints, std::vector<FeatureDescriptor>& descriptors) {
+        if (raw.empty()) return;
+        const int cn = raw.channels();
+        if ((raw.type() & 7) != CV_8U || !(cn == 1 || cn == 3 || cn == 4)) throw std::runtime_error("HipORBExtractor: camera frames must be CV_8UC1, CV_8UC3 or CV_8UC4");
+        hs_preprocess_params pp; pp.channels = cn; pp.rgb = rgb ? 1 : 0; pp.scale = scale; pp._pad = 0;
+        int32_t ow = 0, oh = 0, n = 0;
+        hs_preprocess_size(raw.cols, raw.rows, scale, &ow, &oh);
+        if (ow < 1 || oh < 1) throw std::runtime_error("HipORBExtractor: the camera scale reduces the frame to nothing");
+        if (grey) *grey = cv::Mat(oh, ow, CV_8UC1);
+        const uint8_t* one[1] = { raw.ptr(0) };
+        const auto t0 = std::chrono::steady_clock::now();
+        const int st = hs_orb_extract_camera_batch(h, one, 1, raw.cols, raw.rows, (size_t)raw.step, &pp, kps.data(), desc.data(), cap, &n, grey ? grey->ptr(0) : nullptr);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipORBExtractor: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        deliver(n, t0, _keypoints, descriptors);
+    }
+private:
+    // the flat results of the call that started at t0 -> hySLAM's objects (keypoints cleared, descriptors appended: ORBExtractor.cpp:523,558-561)
+    void deliver(int32_t n, std::chrono::steady_clock::time_point t0, std::vector<cv::KeyPoint>& _keypoints, std::vector<FeatureDescriptor>& descriptors) {
         // keep what was just extracted on the device for the matchers (device-to-device; a full cache or a failed publish only means the host path later)
         last_token = 0;
         if (publish_frames && n > 0 && hs_frame_publish(h, 0, kps.data(), n, &last_token) != HS_OK) last_token = 0;
@@ -257,6 +282,7 @@ public:
         } else fill(0, n);
         timing.scatter_ms = hip_detail::ms_since(t1);
     }
+public:
     int GetLevels() override { return hs_orb_get_levels(h); }
     float GetScaleFactor() override { return hs_orb_get_scale_factor(h); }
     std::vector<float> GetScaleFactors() override { return table(0); }

@@ -15,6 +15,8 @@
 #define CV_8U 0
 #define CV_32F 5
 #define CV_8UC1 0
+#define CV_8UC3 16                     // CV_MAKETYPE(CV_8U, 3): the camera frames HipORBExtractor::extractFromCamera takes
+#define CV_8UC4 24
 #define CV_32FC1 5
 
 namespace cv {
@@ -22,7 +24,7 @@ struct Point2f { float x = 0, y = 0; Point2f() {} Point2f(float x_, float y_) : 
 struct KeyPoint {                      // field names of cv::KeyPoint (opencv2/core/types.hpp)
     Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1;
 };
-class Mat {                            // CV_8UC1 and CV_32FC1, 2-D, continuous or external rows
+class Mat {                            // CV_8UC1 / CV_8UC3 / CV_8UC4 and CV_32FC1, 2-D, continuous or external rows
 public:
     int rows = 0, cols = 0; size_t step = 0; uint8_t* data = nullptr;
     Mat() {}
@@ -31,6 +33,7 @@ public:
     Mat(int r, int c, int type, const void* ext, size_t st = 0) : rows(r), cols(c), step(st ? st : (size_t)c * esz(type)), data((uint8_t*)ext), type_(type) {}
     bool empty() const { return !data || rows == 0 || cols == 0; }
     int type() const { return type_; }
+    int channels() const { return (type_ >> 3) + 1; }
     Mat clone() const { Mat m(rows, cols, type_); for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t)y * m.step, data + (size_t)y * step, (size_t)cols * esz(type_)); return m; }
     uint8_t* ptr(int y = 0) { return data + (size_t)y * step; }
     const uint8_t* ptr(int y = 0) const { return data + (size_t)y * step; }
@@ -40,7 +43,7 @@ public:
     template <class T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : at<T>(i, 0); }
     Mat getMat() const { return *this; }
 private:
-    static size_t esz(int t) { return t == CV_32F ? 4 : 1; }
+    static size_t esz(int t) { return (size_t)((t & 7) == CV_32F ? 4 : 1) * (size_t)((t >> 3) + 1); }
     int type_ = CV_8UC1;
     std::shared_ptr<std::vector<uint8_t>> buf_;
 };

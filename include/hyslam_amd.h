@@ -100,6 +100,24 @@ int  hs_orb_extract(hs_orb* h, const uint8_t* img, int w, int h_px, int stride,
 /* `batch` same-sized host images; outputs are [batch][cap] / [batch][cap][32] / [batch]. */
 int  hs_orb_extract_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride,
                           hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n);
+/* ---- the camera frame as it arrives: ImageProcessing::PreProcessImg on the device (src/main/ImageProcessing.cpp:118-138; it sits inside the
+ * reference's timing bracket, :70 / :112, in front of both extractor calls, :76-77).  cv::resize(img, img, Size(), scale, scale) on the 1-, 3- or
+ * 4-channel 8-bit frame — a copy at scale 1, the rounded 2x2 mean INTER_LINEAR silently becomes at exactly 0.5 (the reference's "Imaging" camera:
+ * 2704 x 2028 x 3 -> 1352 x 1014), OpenCV's 11-bit fixed-point bilinear otherwise — then cvtColor to grey with its 14-bit weights (R 4899, G 9617,
+ * B 1868); `rgb` = the camera's `RGB:` key (1: channel 0 is red: CV_RGB(A)2GRAY, 0: CV_BGR(A)2GRAY).  The scaled size is cvRound(w * scale). */
+typedef struct hs_preprocess_params { int32_t channels; int32_t rgb; float scale; int32_t _pad; } hs_preprocess_params;
+void hs_preprocess_size(int w, int h_px, float scale, int32_t* ow, int32_t* oh);
+/* device frames (image i at d_src + i * image_stride, rows `row_stride` bytes apart, channels interleaved) -> device grey frames of the scaled size;
+ * asynchronous on `stream` (the handle's own when 0).  Only the ow x oh pixels of every grey frame are written. */
+int  hs_preprocess_device(hs_orb* h, const uint8_t* d_src, int w, int h_px, size_t row_stride, size_t image_stride, int batch, const hs_preprocess_params* pp,
+                          uint8_t* d_grey, size_t grey_row_stride, size_t grey_image_stride, void* stream);
+/* ProcessMonoImage / ProcessStereoImage's `PreProcessImg(...)` + `(*extractor)(mImGray, ...)` in one call (ImageProcessing.cpp:44,55 / :76-77,82-83): `batch`
+ * host frames of w x h_px x pp->channels cross PCIe as they are, are reduced to grey level-0 frames on the device and extracted; outputs as
+ * hs_orb_extract_batch ([batch][cap] ...; cap >= hs_orb_max_keypoints after hs_orb_reserve(h, ow, oh, batch) with (ow, oh) = hs_preprocess_size).
+ * grey_out (may be NULL): the grey frames, batch x oh x ow tight — what the reference keeps as track_data.image (:60,108). */
+int  hs_orb_extract_camera_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t row_stride, const hs_preprocess_params* pp,
+                                 hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n, uint8_t* grey_out);
+
 /* Device-resident batch: image i starts at d_imgs + i*image_stride, rows `row_stride` bytes apart.
  * d_kps [batch][cap], d_desc [batch][cap][32] (16-byte aligned), d_n [batch]; all device memory.  Asynchronous.
  * ONE STREAM AT A TIME PER HANDLE: the *_device entry points take a caller stream, but a handle's workspace, the FAST kernel's work-queue counter

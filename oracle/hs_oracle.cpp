@@ -114,6 +114,112 @@ void resizeLinearU8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* ds
     }
 }
 
+/* ------------------------------------------------------------------ ImageProcessing::PreProcessImg (src/main/ImageProcessing.cpp:118-138)
+ * cv::resize(img, img, cv::Size(), fscale, fscale) on the frame AS IT COMES (1, 3 or 4 interleaved channels), then cvtColor to grey.  OpenCV 3.4
+ * (modules/imgproc/src/resize.cpp, color_rgb.cpp), restated from its published algorithms — same status as every other primitive here:
+ *   dsize    = (saturate_cast<int>(w * inv_scale_x), ...) = cvRound of the DOUBLE product, inv_scale = (double)fscale; the scale the tables use is
+ *              1. / inv_scale (it is NOT re-derived from dsize when dsize was given empty)
+ *   dsize == ssize                      -> a copy
+ *   INTER_LINEAR with scale_x == scale_y == 2 exactly (the reference's "Imaging" camera: scale 0.5, config/sample_primary_config_file.yaml:66)
+ *                                       -> silently INTER_AREA's fast path: D = (S00 + S01 + S10 + S11 + 2) >> 2 per channel for the w / 2 full blocks,
+ *                                          saturate_cast<uchar>((float)sum / count) over the samples that exist for a trailing partial block
+ *   anything else                       -> the 11-bit fixed-point bilinear of A.2 per channel (xofs[dx * cn + k] = sx * cn + k)
+ *   RGB2GRAY / BGR2GRAY / RGBA / BGRA   -> (R * 4899 + G * 9617 + B * 1868 + (1 << 13)) >> 14   (R2Y, G2Y, B2Y at yuv_shift = 14); alpha ignored */
+void preprocessSize(int w, int h, float fscale, int* ow, int* oh)
+{
+    const double inv = (double)fscale;
+    *ow = cvRoundD((double)w * inv); *oh = cvRoundD((double)h * inv);
+}
+static void resizeColor(const uint8_t* src, int sw, int sh, int sstride, int cn, float fscale, std::vector<uint8_t>& out, int dw, int dh)
+{
+    out.assign((size_t)dw * dh * cn, 0);
+    const double inv_scale = (double)fscale, scale = 1. / inv_scale;
+    if (dw == sw && dh == sh) {
+        for (int y = 0; y < sh; y++) memcpy(&out[(size_t)y * dw * cn], src + (size_t)y * sstride, (size_t)sw * cn);
+        return;
+    }
+    const int iscale = cvRoundD(scale);                                     // saturate_cast<int>(scale_x)
+    const bool is_area_fast = std::fabs(scale - iscale) < DBL_EPSILON;
+    if (is_area_fast && iscale == 2) {
+        const int wfull = sw / 2;                                           // blocks with all four samples
+        for (int dy = 0; dy < dh; dy++) {
+            const int sy0 = dy * 2;
+            uint8_t* D = &out[(size_t)dy * dw * cn];
+            if (sy0 >= sh) continue;                                        // (row of zeros)
+            const uint8_t* S = src + (size_t)sy0 * sstride;
+            const uint8_t* nS = sy0 + 1 < sh ? S + sstride : nullptr;
+            for (int dx = 0; dx < dw; dx++)
+                for (int k = 0; k < cn; k++) {
+                    const int sx0 = dx * 2;
+                    if (dx < wfull && nS) { D[dx * cn + k] = (uint8_t)((S[sx0 * cn + k] + S[(sx0 + 1) * cn + k] + nS[sx0 * cn + k] + nS[(sx0 + 1) * cn + k] + 2) >> 2); continue; }
+                    if (sx0 >= sw) { D[dx * cn + k] = 0; continue; }
+                    int sum = 0, count = 0;
+                    for (int yy = 0; yy < 2 && sy0 + yy < sh; yy++)
+                        for (int xx = 0; xx < 2 && sx0 + xx < sw; xx++) { sum += src[(size_t)(sy0 + yy) * sstride + (sx0 + xx) * cn + k]; count++; }
+                    D[dx * cn + k] = (uint8_t)std::min(std::max(cvRoundF((float)sum / count), 0), 255);
+                }
+        }
+        return;
+    }
+    const int COEF_BITS = 11, COEF_SCALE = 1 << COEF_BITS;
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<short> ialpha(dw * 2), ibeta(dh * 2);
+    int xmax = dw;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale - 0.5);
+        int sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) { xmax = std::min(xmax, dx); if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+        xofs[dx] = sx;
+        ialpha[dx * 2] = saturate_short((1.f - fx) * COEF_SCALE);
+        ialpha[dx * 2 + 1] = saturate_short(fx * COEF_SCALE);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale - 0.5);
+        int sy = cvFloorF(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[dy * 2] = saturate_short((1.f - fy) * COEF_SCALE);
+        ibeta[dy * 2 + 1] = saturate_short(fy * COEF_SCALE);
+    }
+    auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+    for (int dy = 0; dy < dh; dy++) {
+        const uint8_t* S0 = src + (size_t)clip(yofs[dy], 0, sh) * sstride;
+        const uint8_t* S1 = src + (size_t)clip(yofs[dy] + 1, 0, sh) * sstride;
+        const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+        uint8_t* D = &out[(size_t)dy * dw * cn];
+        for (int dx = 0; dx < dw; dx++)
+            for (int k = 0; k < cn; k++) {
+                const int sx = xofs[dx] * cn + k;
+                int h0, h1;
+                if (dx < xmax) { h0 = S0[sx] * ialpha[dx * 2] + S0[sx + cn] * ialpha[dx * 2 + 1]; h1 = S1[sx] * ialpha[dx * 2] + S1[sx + cn] * ialpha[dx * 2 + 1]; }
+                else { h0 = S0[sx] * COEF_SCALE; h1 = S1[sx] * COEF_SCALE; }
+                D[dx * cn + k] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+    }
+}
+int preprocessImg(const uint8_t* src, int w, int h, int sstride, int cn, int rgb, float fscale, uint8_t* dst, int dstride)
+{
+    if (!(cn == 1 || cn == 3 || cn == 4) || w < 1 || h < 1) return -1;
+    int dw, dh;
+    preprocessSize(w, h, fscale, &dw, &dh);
+    if (dw < 1 || dh < 1) return -1;                                       // (OpenCV asserts !dsize.empty())
+    std::vector<uint8_t> col;
+    resizeColor(src, w, h, sstride, cn, fscale, col, dw, dh);
+    for (int y = 0; y < dh; y++) {
+        const uint8_t* S = &col[(size_t)y * dw * cn];
+        uint8_t* D = dst + (size_t)y * dstride;
+        if (cn == 1) { memcpy(D, S, (size_t)dw); continue; }
+        for (int x = 0; x < dw; x++) {
+            const int c0 = S[x * cn], c1 = S[x * cn + 1], c2 = S[x * cn + 2];
+            const int r = rgb ? c0 : c2, b = rgb ? c2 : c0;
+            D[x] = (uint8_t)((r * 4899 + c1 * 9617 + b * 1868 + (1 << 13)) >> 14);
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ A.1 cv::FAST 9_16 */
 static const int kRing[16][2] = { {0,3},{1,3},{2,2},{3,1},{3,0},{3,-1},{2,-2},{1,-3},
                                   {0,-3},{-1,-3},{-2,-2},{-3,-1},{-3,0},{-3,1},{-2,2},{-1,3} };
@@ -796,6 +902,9 @@ const int32_t* hso_pattern(void) { static ORBFinder f(20); return f.pattern; }
 
 void hso_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride)
 { resizeLinearU8(src, sw, sh, sstride, dst, dw, dh, dstride); }
+void hso_preprocess_size(int w, int h, float scale, int32_t* ow, int32_t* oh) { int a, b; preprocessSize(w, h, scale, &a, &b); *ow = a; *oh = b; }
+int hso_preprocess(const uint8_t* src, int w, int h, int sstride, int channels, int rgb, float scale, uint8_t* dst, int dstride)
+{ return preprocessImg(src, w, h, sstride, channels, rgb, scale, dst, dstride); }
 
 int hso_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, int32_t* out_xys, int cap)
 {

@@ -80,6 +80,10 @@ const int32_t* hso_pattern(void);
 
 /* ---- OpenCV primitives (Appendix A) ---- */
 void hso_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+/* ImageProcessing::PreProcessImg (src/main/ImageProcessing.cpp:118-138): cv::resize by the camera's scale on the 1 / 3 / 4-channel frame, then
+ * cvtColor to grey (rgb: 1 = RGB(A) order, 0 = BGR(A)).  Output size = hso_preprocess_size.  Returns 0, or -1 for an empty result / bad channels. */
+void hso_preprocess_size(int w, int h, float scale, int32_t* ow, int32_t* oh);
+int  hso_preprocess(const uint8_t* src, int w, int h, int sstride, int channels, int rgb, float scale, uint8_t* dst, int dstride);
 /* out: triplets (x, y, score) int32; returns number found (may exceed cap; only cap written) */
 int  hso_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, int nonmax, int32_t* out_xys, int cap);
 void hso_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, const uint16_t* taps7);

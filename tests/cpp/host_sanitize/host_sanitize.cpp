@@ -48,6 +48,24 @@ static int geometry_case(int w, int h, int nfeat, float scale, int levels, int c
             std::vector<const uint8_t*> ptrs(batch, img.data());
             st = hs_orb_extract_batch(ex, ptrs.data(), batch, w, h, w, k.data(), d.data(), cap, n.data());
             if (st != HS_OK) { printf("extract_batch %dx%d: %s\n", w, h, hs_orb_last_error(ex)); return -1; }
+            {   // the camera-frame entry point (PreProcessImg on the device): a 3-channel frame of TWICE the size at scale 0.5 lands on the same level-0 geometry,
+                // a 4-channel frame at scale 1 too; the staging of the raw frames (row padding to 4 bytes, odd strides) and the grey read-back run under the sanitizers
+                hs_preprocess_params pp{ 3, 1, 0.5f, 0 };
+                int32_t ow = 0, oh = 0; hs_preprocess_size(2 * w, 2 * h, pp.scale, &ow, &oh);
+                if (ow != w || oh != h) { printf("hs_preprocess_size(%d, %d, 0.5) = %d x %d\n", 2 * w, 2 * h, ow, oh); return -1; }
+                std::vector<uint8_t> col((size_t)2 * w * 3 * 2 * h + 16), grey((size_t)batch * w * h);
+                for (auto& v : col) v = (uint8_t)rng();
+                std::vector<const uint8_t*> cptrs(batch, col.data());
+                st = hs_orb_extract_camera_batch(ex, cptrs.data(), batch, 2 * w, 2 * h, (size_t)2 * w * 3, &pp, k.data(), d.data(), cap, n.data(), grey.data());
+                if (st != HS_OK) { printf("extract_camera_batch %dx%d: %s\n", w, h, hs_orb_last_error(ex)); return -1; }
+                hs_preprocess_params p4{ 4, 0, 1.0f, 0 };
+                std::vector<uint8_t> c4((size_t)(w * 4 + 3) * h);
+                std::vector<const uint8_t*> c4p(batch, c4.data());
+                st = hs_orb_extract_camera_batch(ex, c4p.data(), batch, w, h, (size_t)w * 4 + 3, &p4, k.data(), d.data(), cap, n.data(), nullptr);
+                if (st != HS_OK) { printf("extract_camera_batch (4 channels) %dx%d: %s\n", w, h, hs_orb_last_error(ex)); return -1; }
+                hs_preprocess_params bad{ 2, 0, 1.0f, 0 };
+                if (hs_orb_extract_camera_batch(ex, c4p.data(), batch, w, h, (size_t)w * 4 + 3, &bad, k.data(), d.data(), cap, n.data(), nullptr) == HS_OK) { printf("two channels were accepted\n"); return -1; }
+            }
             // the ingest tickets: two in flight, a third is refused, waits in both orders, a wait with too small a capacity keeps the ticket
             hs_stereo_params sp{ 500.f, 60.f, h, 100.f, 50.f, 31.f };
             if (batch % 2 == 0) {

@@ -149,6 +149,33 @@ int main(int argc, char** argv)
         for (int i = 0; i < nL; i++) if (uR3[i] != ouR[i] || depth3[i] != odepth[i]) { printf("stereo host fallback: %d differs\n", i); return 26; }
         printf("device frames: stereo on cached frames ok, projection search %d matches (device == host), slot reuse ok\n", n1);
     }
+    // ---- extractFromCamera (ImageProcessing::PreProcessImg on the device): the left frame as a BGR frame of twice the size (every pixel a 2x2 block of
+    //      equal channels) at the camera scale 0.5 is the grey frame again — the rounded 2x2 mean of four equal bytes and 4899 + 9617 + 1868 = 2^14 —, so
+    //      features and the grey frame handed back must equal the oracle's for L; then against the oracle's PreProcessImg on a frame with three different channels
+    {
+        cv::Mat big(2 * H, 2 * W, CV_8UC3);
+        for (int y = 0; y < 2 * H; y++) for (int x = 0; x < 2 * W; x++) for (int k = 0; k < 3; k++) big.ptr(y)[3 * x + k] = L.ptr(y / 2)[x / 2];
+        std::vector<cv::KeyPoint> kc; std::vector<FeatureDescriptor> dc; cv::Mat grey;
+        exL.extractFromCamera(big, false, 0.5f, &grey, kc, dc);
+        if (grey.rows != H || grey.cols != W || memcmp(grey.ptr(0), L.ptr(0), (size_t)W * H)) { printf("extractFromCamera: the grey frame differs\n"); return 27; }
+        if ((int)kc.size() != nL) { printf("extractFromCamera: %zu keypoints, expected %d\n", kc.size(), nL); return 28; }
+        for (int i = 0; i < nL; i++) {
+            cv::Mat row = dc[i].rawDescriptor();
+            if (kc[i].pt.x != okL[i].x || kc[i].pt.y != okL[i].y || kc[i].angle != okL[i].angle || memcmp(row.ptr(0), &odL[i * 32], 32)) { printf("extractFromCamera: feature %d differs\n", i); return 29; }
+        }
+        cv::Mat col(H, W, CV_8UC3);
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { col.ptr(y)[3 * x] = L.ptr(y)[x]; col.ptr(y)[3 * x + 1] = R.ptr(y)[x]; col.ptr(y)[3 * x + 2] = (uint8_t)(255 - L.ptr(y)[x]); }
+        std::vector<uint8_t> og((size_t)W * H);
+        if (hso_preprocess(col.ptr(0), W, H, (int)col.step, 3, 1, 1.0f, og.data(), W) != 0) return 30;
+        dc.clear();                                              // (descriptors are APPENDED, like the reference: ORBExtractor.cpp:558-561)
+        exL.extractFromCamera(col, true, 1.0f, &grey, kc, dc);
+        if (memcmp(grey.ptr(0), og.data(), (size_t)W * H)) { printf("extractFromCamera: RGB -> grey differs from the oracle\n"); return 31; }
+        std::vector<hso_keypoint> okc(cap); std::vector<uint8_t> odc(cap * 32);
+        const int nc = hso_orb_extract(&p, og.data(), W, H, W, okc.data(), odc.data(), cap, nullptr);
+        if (nc != (int)kc.size()) { printf("extractFromCamera: %zu keypoints on the RGB frame, oracle %d\n", kc.size(), nc); return 32; }
+        for (int i = 0; i < nc; i++) if (kc[i].pt.x != okc[i].x || kc[i].pt.y != okc[i].y || memcmp(dc[i].rawDescriptor().ptr(0), &odc[i * 32], 32)) { printf("extractFromCamera: RGB feature %d differs\n", i); return 33; }
+        printf("extractFromCamera: BGR 2x at scale 0.5 == the grey frame (%d keypoints), RGB at scale 1.0 == oracle (%d keypoints)\n", nL, nc);
+    }
     printf("ADAPTOR OK %d %d keypoints, %d stereo matches\n", nL, nR, matches);
     return 0;
 }

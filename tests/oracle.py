@@ -109,6 +109,25 @@ def resize_linear(src, dw, dh):
     return dst
 
 
+def preprocess_size(w, h, scale):
+    ow, oh = C.c_int32(), C.c_int32()
+    lib().hso_preprocess_size(int(w), int(h), C.c_float(scale), C.byref(ow), C.byref(oh))
+    return ow.value, oh.value
+
+
+def preprocess(src, rgb, scale):
+    """ImageProcessing::PreProcessImg (ImageProcessing.cpp:118-138): src = (h, w) or (h, w, 3 | 4) uint8; returns the grey frame of the scaled size"""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    ow, oh = preprocess_size(w, h, scale)
+    dst = np.zeros((max(oh, 1), max(ow, 1)), np.uint8)
+    rc = lib().hso_preprocess(src.ctypes.data_as(C.c_void_p), w, h, src.strides[0], cn, int(bool(rgb)), C.c_float(scale), dst.ctypes.data_as(C.c_void_p), dst.strides[0])
+    if rc != 0:
+        raise ValueError("preprocess: empty result or unsupported channel count")
+    return dst
+
+
 def fast(img, threshold=20, nonmax=True, cap=1 << 20):
     img, pi = _u8(img)
     out = np.zeros((cap, 3), np.int32)

@@ -48,6 +48,58 @@ def resize_linear(src, dw, dh):
     return out.astype(np.uint8)
 
 
+def preprocess(src, rgb, fscale):
+    """ImageProcessing::PreProcessImg (src/main/ImageProcessing.cpp:118-138) from the text of OpenCV 3.4's resize / cvtColor: vectorised over the frame
+    (the oracle walks pixels).  src (h, w) or (h, w, cn) uint8."""
+    if src.ndim == 2:
+        src = src[:, :, None]
+    sh, sw, cn = src.shape
+    inv = np.float64(np.float32(fscale))
+    dw, dh = int(np.rint(sw * inv)), int(np.rint(sh * inv))
+    scale = 1.0 / inv
+    S = src.astype(np.int64)
+    if (dw, dh) == (sw, sh):
+        col = S
+    elif abs(scale - np.rint(scale)) < np.finfo(np.float64).eps and int(np.rint(scale)) == 2:
+        # INTER_LINEAR at exactly 1/2 is INTER_AREA's fast path: rounded 2x2 means for the full blocks, float means of what exists for trailing partial ones
+        pad = np.zeros((2 * dh + 2, 2 * dw + 2, cn), np.int64)
+        msk = np.zeros((2 * dh + 2, 2 * dw + 2, 1), np.int64)
+        hh, ww = min(sh, 2 * dh), min(sw, 2 * dw)
+        pad[:hh, :ww] = S[:hh, :ww]
+        msk[:hh, :ww] = 1
+        blk = lambda a: a[0:2 * dh:2, 0:2 * dw:2] + a[0:2 * dh:2, 1:2 * dw:2] + a[1:2 * dh:2, 0:2 * dw:2] + a[1:2 * dh:2, 1:2 * dw:2]
+        ssum, cnt = blk(pad), blk(msk)
+        full = (np.arange(dw)[None, :, None] < sw // 2) & (2 * np.arange(dh)[:, None, None] + 1 < sh)
+        fast = (ssum + 2) >> 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            slow = np.where(cnt > 0, np.rint(ssum.astype(np.float32) / np.maximum(cnt, 1).astype(np.float32)), 0).astype(np.int64)
+        col = np.where(full, fast, np.clip(slow, 0, 255))
+    else:
+        def table(dn, sn, clamp_weights):
+            d = np.arange(dn, dtype=np.float64)
+            f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+            s_ = np.floor(f).astype(np.int64)
+            f = (f - s_.astype(np.float32)).astype(np.float32)
+            if clamp_weights:
+                low = s_ < 0
+                f[low] = 0; s_[low] = 0
+                high = s_ >= sn - 1
+                f[high] = 0; s_[high] = sn - 1
+            a0 = np.clip(cv_round((np.float32(1.0) - f) * np.float32(2048)), -32768, 32767)
+            a1 = np.clip(cv_round(f * np.float32(2048)), -32768, 32767)
+            return s_, a0, a1
+        sx, a0, a1 = table(dw, sw, True)
+        sy, b0, b1 = table(dh, sh, False)
+        sx1 = np.minimum(sx + 1, sw - 1)
+        H = S[:, sx] * a0[None, :, None] + S[:, sx1] * a1[None, :, None]
+        H0, H1 = H[np.clip(sy, 0, sh - 1)], H[np.clip(sy + 1, 0, sh - 1)]
+        col = (((b0[:, None, None] * (H0 >> 4)) >> 16) + ((b1[:, None, None] * (H1 >> 4)) >> 16) + 2) >> 2
+    if cn == 1:
+        return col[:, :, 0].astype(np.uint8)
+    r, g, b = (col[:, :, 0], col[:, :, 1], col[:, :, 2]) if rgb else (col[:, :, 2], col[:, :, 1], col[:, :, 0])
+    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+
 def fast_scores(img, t=20):
     """Score map (0 = not a corner) over the whole view; only [3,h-3) x [3,w-3) can be non-zero."""
     h, w = img.shape
