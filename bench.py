@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 CLOCK_GHZ = 2.4                # max shader clock (MI355X_MICROARCH.md); issue-rate fractions are quoted against it
 W, H, NFEAT = 1920, 1080, 2000
-PROFILE_TAG = "r05"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
+PROFILE_TAG = "r06"            # profiles/<tag>_hbm_traffic.json, profiles/<tag>_sq_counters.json hold the committed counter passes
 DEFAULT_PAIRS = 64             # stereo pairs per step; tools/pmc_traffic.py and tools/summarize_profiles.py read this constant (HS_PROFILE_PAIRS overrides)
 
 

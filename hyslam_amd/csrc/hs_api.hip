@@ -74,6 +74,7 @@ struct hs_orb {
                                        // sequence whose length goes with the rows per wave: more, flatter tiles shorten the launch although their halo rows cost more work)
     int deep_max_batch = 2;            // HS_PYRAMID_DEEP_MAX (read once): calls of at most this many frames use the small-batch plan (0 = never)
     std::vector<HsPyrChain> pyr_chain; // [level]: kernel argument of the chain launch that starts at this level (HsLevel::chain_n levels)
+    int pyr_tbx_max = 0;               // HS_PYRAMID_TBX_MAX (read once): cap on the level-B tile width of the two-level kernel (experiment: lane utilisation against time)
     int chain_mode = -1;               // HS_PYRAMID_CHAIN (read once): -1 = a three-level chain for the tail of an odd number of levels, 0 = never, 2 = chains for every fused pair too (parity tests)
     uint2* d_cand = nullptr; uint32_t *d_pts_xy = nullptr, *d_pts_sk = nullptr; uint16_t* d_pt_node = nullptr;
     int32_t *d_cand_count = nullptr, *d_sel_count = nullptr, *d_cell_count = nullptr;
@@ -340,7 +341,7 @@ int configure_impl(hs_orb* h, int w, int hh, int batch)
     {   // which level pairs the fused pyramid kernel can produce (decided on the host copies of the tables)
         std::vector<const int16_t*> xt(L, nullptr), yo(L, nullptr);
         for (int l = 1; l < L; l++) { xt[l] = tables.data() + tab_off[4 * l]; yo[l] = tables.data() + tab_off[4 * l + 2]; }
-        hs_pyramid_plan_fusion(h->lv.data(), L, xt.data(), yo.data());
+        hs_pyramid_plan_fusion(h->lv.data(), L, xt.data(), yo.data(), h->pyr_tbx_max);
         if (h->no_fuse) for (int l = 0; l < L; l++) h->lv[l].fuse_tbx = 0;
         std::vector<const int16_t*> ib(L, nullptr);
         for (int l = 1; l < L; l++) ib[l] = tables.data() + tab_off[4 * l + 3];
@@ -746,6 +747,7 @@ int hs_orb_create(const hs_orb_params* p, int device, hs_orb** out)
     { const char* e = getenv("HS_FAST_KEYS_MAX_BATCH"); if (e && atoi(e) >= 0) h->fast_keys_max_batch = atoi(e); }
     { const char* e = getenv("HS_FAST_ORDER"); h->fast_order = e ? atoi(e) : 1; }
     { const char* e = getenv("HS_PYRAMID_CHAIN"); h->chain_mode = e ? atoi(e) : -1; }
+    { const char* e = getenv("HS_PYRAMID_TBX_MAX"); if (e) h->pyr_tbx_max = atoi(e); }
     { const char* e = getenv("HS_PYRAMID_DEEP_MAX"); if (e) h->deep_max_batch = atoi(e); }
     { const char* e = getenv("HS_PYRAMID_DEEP_ROWS"); if (e && atoi(e) >= 2) h->deep_rows = atoi(e); }
     { const char* e = getenv("HS_QT_POINT_DOMAIN"); h->qt_point_domain = e && atoi(e) != 0; }

@@ -207,7 +207,7 @@ void hs_pyramid_plan_chain(const HsLevel* h_lv, int first, int n, const int16_t*
 void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, const int16_t* const* ibeta,
                              std::vector<uint64_t>& blob, std::vector<HsPyrFuse>& fuse);
 // decides, from the host copies of the resize tables, whether levels (l, l+1) can be produced by the fused kernel and with which tile geometry
-void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/);
+void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab /*[level] {sx,a0,a1,-} per column*/, const int16_t* const* yofs /*[level]*/, int tbx_max = 0 /*> 0: cap on the level-B tile width*/);
 int hs_pyramid_launch_count(const HsLevel* h_lv, int nlevels);          // kernel launches of one hs_launch_pyramid call
 int hs_fast_group_cells(int wcell, int ncols, int lc);   // cells per FAST work item for a level (0 when the level has no cells); lc = 6 / 5: wide / narrow tiles
 int hs_fast_max_cell_w(int lc);                          // widest FAST cell the kernel's tile holds at any offset (247 px wide tiles, 119 px narrow ones)

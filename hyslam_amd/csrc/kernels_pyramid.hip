@@ -711,14 +711,15 @@ void hs_pyramid_build_tables(const HsLevel* h_lv, int nlevels, const int16_t* co
 
 // Can levels (l, l+1) be fused?  Walks every tile with the host copies of the tables and checks what the kernel assumes: the level-A region of
 // a tile (owned part + halo) fits 256 columns / fuse_ar rows, its source rectangle fits the LDS rectangle, all LDS fits.
-void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs)
+void hs_pyramid_plan_fusion(HsLevel* h_lv, int nlevels, const int16_t* const* xtab, const int16_t* const* yofs, int tbx_max)
 {
     for (int l = 1; l < nlevels; l++) h_lv[l].fuse_tbx = h_lv[l].fuse_ar = h_lv[l].fuse_sr = h_lv[l].fuse_pitch = 0;
     for (int l = 1; l + 1 < nlevels; l += 2) {
         HsLevel& A = h_lv[l]; const HsLevel& B = h_lv[l + 1]; const HsLevel& S = h_lv[l - 1];
         const double scxA = (double)S.w / A.w, scyA = (double)S.h / A.h, scxB = (double)A.w / B.w, scyB = (double)A.h / B.h;
         if (scxA > 2.0 || scxB > 2.0 || scyA > 2.0 || scyB > 2.0 || B.w < 8 || B.h < 1) continue;
-        const int tbx = std::min(256, ((int)(250.0 / scxB)) & ~3);
+        int tbx = std::min(256, ((int)(250.0 / scxB)) & ~3);
+        if (tbx_max >= 64) tbx = std::min(tbx, tbx_max & ~3);      // tuning / experiment knob (HS_PYRAMID_TBX_MAX): narrower level-B tiles
         if (tbx < 64) continue;
         const int16_t* xA = xtab[l]; const int16_t* xB = xtab[l + 1]; const int16_t* yA = yofs[l]; const int16_t* yB = yofs[l + 1];
         auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };

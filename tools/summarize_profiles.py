@@ -94,7 +94,7 @@ json.dump({"source": "rocprofv3 --pmc SQ_* (one pass, no trace domains) of `pyth
            "pairs_per_step": PAIRS, "kernels": sq}, open("profiles/%s_sq_counters.json" % rnd, "w"), indent=1)
 summary = {}
 for name in ("bench", "matchers", "pcie", "c3", "c4", "c5", "c5_bow", "bench_pairs1", "bench_pairs2", "bench_pairs4", "bench_pairs8", "bench_pairs16", "bench_pairs32", "bench_pairs64", "bench_pairs128", "bench_handles2", "bench_handles3", "bench_under_rocprof", "bench16_under_rocprof",
-             "bench_density3", "adaptor"):
+             "bench_density3", "adaptor", "preprocess"):
     p = os.path.join(src, name + ".json")
     try:
         text = open(p).read()
@@ -178,5 +178,9 @@ if s16:
         o.write("kernel,launches," + ",".join(names16) + "\n")
         for k, d in agg16.items():
             o.write(k.replace(",", ";") + "," + str(len(next(iter(d.values())))) + "," + ",".join(str(round(sum(d[c]) / len(d[c]))) for c in names16) + "\n")
+try:
+    open("profiles/%s_lds_gather.txt" % rnd, "w").write("# tools/micro/lds_gather: a FAST ring gather (16 ring pixels + centre of a pseudo-random pixel per lane) as byte reads and as wider LDS reads\n" + open(os.path.join(src, "lds_gather.txt")).read())
+except OSError:
+    pass
 b = summary["bench"]
 print("value", b["value"], b["stage_ms_per_step"], b["roofline"])
