@@ -462,6 +462,9 @@ def run_c2(args, rank, world, local_rank, dev, torch, dist, HS, N):
         for rl in rls.values():
             rl["peak_measured_copy"] = copy_peak.get("GBps")
             rl["frac_of_measured"] = round(rl["achieved"] / copy_peak["GBps"], 5) if copy_peak.get("GBps") else None
+            if "achieved_on_moved_bytes" in rl and copy_peak.get("GBps"):      # describe: its algorithmic bytes include the reference's full-level blur, which it never moves
+                rl["frac_on_moved_bytes"] = round(rl["achieved_on_moved_bytes"] / HBM_PEAK_GBS, 5)
+                rl["frac_of_measured_on_moved_bytes"] = round(rl["achieved_on_moved_bytes"] / copy_peak["GBps"], 5)
     out["roofline"] = rls[dom]
     out["roofline_other_kernels"] = {s: rls[s] for s in rls if s != dom}
     if lat1 is not None:

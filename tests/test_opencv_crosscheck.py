@@ -51,3 +51,13 @@ def test_fast_atan2_matches_cv2():
     ref = np.array([cv2.fastAtan2(float(a), float(b)) for a, b in zip(y, x)], np.float32)
     got = np.array([oracle.lib().hso_fast_atan2(float(a), float(b)) for a, b in zip(y, x)], np.float32)
     assert np.array_equal(ref, got)
+
+
+def test_preprocess_matches_cv2():
+    """ImageProcessing::PreProcessImg (src/main/ImageProcessing.cpp:118-138): cv::resize(img, img, Size(), s, s) on the colour frame, then cvtColor to grey"""
+    col = np.ascontiguousarray(np.stack([synth_image(21 + 7 * k, 322, 241) for k in range(3)], axis=2))
+    for rgb in (True, False):
+        for s in (1.0, 0.5, 0.75, 0.4):
+            f = cv2.resize(col, None, fx=s, fy=s)
+            ref = cv2.cvtColor(f, cv2.COLOR_RGB2GRAY if rgb else cv2.COLOR_BGR2GRAY)
+            assert np.array_equal(ref, oracle.preprocess(col, rgb, s)), (rgb, s)

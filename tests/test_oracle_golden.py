@@ -58,5 +58,8 @@ def test_committed_boundary_dump_is_what_the_oracle_computes():
     assert np.array_equal(oracle.resize_linear(img, 533, 400), d["resize_533x400"]) and np.array_equal(oracle.resize_linear(img, 457, 343), d["resize_457x343"])
     assert np.array_equal(oracle.gaussian_blur7(img), d["blur_default_taps"])
     assert np.array_equal(oracle.gaussian_blur7(img, [16, 34, 50, 56, 50, 34, 16]), d["blur_256sum_taps"])
+    col = d["colour"]          # round 6: ImageProcessing::PreProcessImg
+    assert np.array_equal(oracle.preprocess(col, True, 1.0), d["pre_rgb_1_0"]) and np.array_equal(oracle.preprocess(col, False, 0.5), d["pre_bgr_0_5"])
+    assert np.array_equal(oracle.preprocess(col, True, 0.75), d["pre_rgb_0_75"]) and np.array_equal(oracle.preprocess(img, True, 0.5), d["pre_grey_0_5"])
     at = np.array([oracle.lib().hso_fast_atan2(float(a), float(b)) for a, b in zip(d["atan_y"][:2000], d["atan_x"][:2000])], np.float32)
     assert np.array_equal(at, d["atan_deg"][:2000])

@@ -19,8 +19,12 @@ cell = np.ascontiguousarray(img[100:137, 200:237])
 rng = np.random.default_rng(6)
 ay = rng.integers(-200000, 200000, 20000).astype(np.float32)
 ax = rng.integers(-200000, 200000, 20000).astype(np.float32)
+# round 6: ImageProcessing::PreProcessImg (src/main/ImageProcessing.cpp:118-138): cv::resize by a scale factor on a colour frame + cvtColor to grey
+col = np.ascontiguousarray(np.stack([synth_image(21 + 7 * k, 322, 241) for k in range(3)], axis=2))          # odd size: the 0.5 path has trailing partial blocks
 np.savez_compressed(
-    out, image=img, cell=cell,
+    out, image=img, cell=cell, colour=col,
+    pre_rgb_1_0=oracle.preprocess(col, True, 1.0), pre_bgr_0_5=oracle.preprocess(col, False, 0.5), pre_rgb_0_75=oracle.preprocess(col, True, 0.75),
+    pre_grey_0_5=oracle.preprocess(img, True, 0.5),
     fast_image=oracle.fast(img, 20, True), fast_cell=oracle.fast(cell, 20, True),
     resize_533x400=oracle.resize_linear(img, 533, 400), resize_457x343=oracle.resize_linear(img, 457, 343),
     blur_default_taps=oracle.gaussian_blur7(img), blur_256sum_taps=oracle.gaussian_blur7(img, [16, 34, 50, 56, 50, 34, 16]),
