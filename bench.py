@@ -513,6 +513,7 @@ def rccl_probe_guarded(out, ex, rank, world, dev, timeout_s=60.0):
             state["printed"] = True
             if out is not None:
                 out["rccl"] = info
+                out["rccl_probe_ok"] = "error" not in info      # a hung or failed probe is visible at the top level of the line (the exit code stays 0: the measurement is complete)
                 print(json.dumps(out), flush=True)
 
     def watchdog():
