@@ -278,6 +278,27 @@ def test_fast_kernel_variants_in_subprocess(gpu, env):
     assert r.returncode == 0 and "FAST_VARIANT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("env", [{"HS_QT_POINT_DOMAIN": "1"}, {"HS_FAST_KEYS": "0"}, {"HS_FAST_KEYS": "0", "HS_QT_POINT_DOMAIN": "1"}])
+def test_large_list_quadtree_variants(gpu, monkeypatch, env):
+    """k_quadtree<3328, 0, rectangles in global scratch> (round 6) on its other paths: the point-domain passes from the start (HS_QT_POINT_DOMAIN=1: every node rectangle
+    is read and written through the workgroup's piece of global scratch between barriers) and without the FAST kernel's keys (the gather); a scene dense enough to
+    fill a level-0 quota of 2 758 (the reference's 9000-feature init extractor @1.4), one frame and two frames per call."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, h, nfeat, scale = 1352, 1014, 9000, 1.4
+    p = oracle.default_params(nfeat, scale)
+    imgs = [synth_image(90 + i, w, h, 4 * max(40, (w * h) // 800)) for i in range(2)]
+    ref = [oracle.extract(p, im) for im in imgs]
+    ex = HS.ORBExtractor(settings(nfeat, scale))
+    assert max(ex.GetFeaturesPerLevel()) > 2040
+    gk, gd = ex(imgs[0])
+    assert_same_features(gk, gd, *ref[0])
+    assert int((gk["octave"] == 0).sum()) > 2040                       # the list really grew past the general instance's capacity
+    ks, ds = ex.extract_batch(imgs)
+    for i in range(2):
+        assert_same_features(ks[i], ds[i], *ref[i])
+
+
 @pytest.mark.parametrize("env", [{"HS_QT_SMALL": "1"}, {"HS_QT_SMALL": "1", "HS_QT_POINT_DOMAIN": "1"}, {"HS_QT_SMALL": "1", "HS_FAST_KEYS_MAX_BATCH": "100000"}])
 def test_quadtree_two_per_cu_instance(gpu, monkeypatch, env):
     """k_quadtree<1024, 0> — the instance without points in LDS, two workgroups per CU, for launches of more than 256 workgroups (HS_QT_SMALL=1; off by default:

@@ -152,8 +152,12 @@ def one_case(rng, i):
         kind = ["scene", "scene", "noise", "checker", "flat", "texture", "cluster"][int(rng.integers(0, 7))]
         w = int(rng.integers(64, 1500)) if rng.random() < 0.85 else int(rng.integers(1500, 2600))
         h = int(rng.integers(64, 1100)) if rng.random() < 0.85 else int(rng.integers(1100, 1700))
-    if rng.random() < 0.95:
-        h = min(h, 2 * w - 1)                   # w/h < 0.5 gives zero root nodes in the reference (division by zero, :183): refused by the library
+    r_shape = rng.random()
+    if r_shape < 0.80:
+        h = min(h, w)                           # landscape / square: (w_l - 32) / (h_l - 32) >= 1 on every level, never refused for its aspect ratio
+    elif r_shape < 0.95:
+        h = min(h, 2 * w - 1)                   # portrait up to 1 : 2 — w/h < 0.5 on a level with cells gives zero root nodes in the reference (division by zero, :183): refused by the
+                                                # library; the deeper levels of a portrait frame cross that line sooner than level 0 (round 5-6 campaigns: 20-25 % of ALL draws were such refusals)
     nfeat = int(rng.integers(20, 4000))
     if STRESS:
         r = rng.random()
@@ -265,6 +269,37 @@ def one_case(rng, i):
         good = good and fgood
         if fgood:
             msg += "; front end, %d pairs ok" % npairs
+    if good and w * h <= 900 * 700 and rng.random() < (0.25 if STRESS else 0.12):
+        # the camera-frame entry point (round 6: ImageProcessing::PreProcessImg on the device): a 1 / 3 / 4-channel frame of another size whose scaled grey version
+        # has THIS case's size class, a random camera scale (the copy, the exact-0.5 area path, bilinear both ways) and colour order, odd row strides
+        cn = int(rng.choice([1, 3, 3, 4]))
+        cscale = float(np.float32(rng.choice([1.0, 0.5, 0.5, 0.75, 0.6, 0.3, 1.25, 2.0])))
+        cw, ch = max(8, int(round(w / cscale))), max(8, int(round(h / cscale)))
+        if cw * ch * cn <= 8_000_000:
+            base = make_image(rng, kind, cw, ch, seed + 500)
+            if cn == 1:
+                cam = base
+            else:
+                chans = [base, np.roll(base, 3, axis=1), np.clip(base.astype(np.int32) + rng.integers(-20, 21, base.shape), 0, 255).astype(np.uint8)]
+                if cn == 4:
+                    chans.append(rng.integers(0, 256, base.shape, dtype=np.uint8))
+                cam = np.ascontiguousarray(np.stack(chans, axis=2))
+            crgb = bool(rng.integers(0, 2))
+            try:
+                og = oracle.preprocess(cam, crgb, cscale)
+            except ValueError:
+                og = None
+            if og is not None:
+                try:
+                    (ck, cd, cg) = ex.extract_camera_batch([cam], crgb, cscale, want_grey=True)
+                    okc, odc = oracle.extract(p, og, cap=big)
+                    cgood = np.array_equal(cg[0], og) and len(ck[0]) == len(okc) and ck[0].tobytes() == okc.tobytes() and np.array_equal(cd[0], odc)
+                    msg += "; camera %dx%dx%d scale %.2f %s -> %dx%d %s" % (cw, ch, cn, cscale, "RGB" if crgb else "BGR", og.shape[1], og.shape[0], "ok" if cgood else "MISMATCH")
+                    good = good and cgood
+                except Exception as e:
+                    reason, expected = refusal_reason("extract", str(e)[:80], og.shape[1], og.shape[0], nfeat, scale, levels, cell)
+                    msg += "; camera frame refused [%s]" % reason
+                    good = good and expected
     if good and len(ok) > 20 and rng.random() < (0.5 if STRESS else 0.3):      # stereo: shifted copy with noise as the right frame
         sh = int(rng.integers(1, 40))
         right = np.roll(img, -sh, axis=1).copy()
