@@ -74,7 +74,7 @@ EXPORTS = [
     "hs_version", "hs_status_string", "hs_device_count", "hs_orb_default_params", "hs_orb_create", "hs_orb_destroy",
     "hs_orb_last_error", "hs_orb_get_levels", "hs_orb_get_device", "hs_orb_get_scale_factor", "hs_orb_get_scale_tables",
     "hs_orb_max_keypoints", "hs_orb_reserve", "hs_orb_extract", "hs_orb_extract_batch", "hs_orb_extract_batch_device",
-    "hs_preprocess_size", "hs_preprocess_device", "hs_orb_extract_camera_batch",
+    "hs_preprocess_size", "hs_preprocess_device", "hs_orb_extract_camera_batch", "hs_orb_submit_camera_batch",
     "hs_host_alloc", "hs_host_free", "hs_orb_submit_batch", "hs_orb_wait", "hs_orb_cancel", "hs_ticket_frames_copied",
     "hs_stereo_match", "hs_stereo_match_batch_device", "hs_stereo_frontend_batch_device", "hs_orb_set_lanes", "hs_orb_set_split", "hs_orb_synchronize",
     "hs_frame_grid", "hs_search_by_projection", "hs_search_by_projection_device", "hs_frame_publish", "hs_frame_find", "hs_frame_release", "hs_frame_info", "hs_frame_cache_clear", "hs_search_by_projection_frame", "hs_stereo_match_frames", "hs_search_by_projection_sim3", "hs_search_by_sim3", "hs_search_by_bow", "hs_search_by_bow_ex", "hs_search_by_bow_legacy", "hs_search_for_initialization",
@@ -153,6 +153,7 @@ def lib():
     L.hs_preprocess_size.restype = None
     L.hs_preprocess_device.argtypes = [vp, vp, C.c_int, C.c_int, sz, sz, C.c_int, C.POINTER(PreprocessParams), vp, sz, sz, vp]
     L.hs_orb_extract_camera_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, sz, C.POINTER(PreprocessParams), vp, vp, C.c_int, vp, vp]
+    L.hs_orb_submit_camera_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, sz, C.POINTER(PreprocessParams), vp, C.POINTER(i32)]
     L.hs_stereo_match.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(StereoParams), vp, vp]
     L.hs_stereo_match_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(StereoParams), vp, vp, vp]
     L.hs_stereo_frontend_batch_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, sz, sz,

@@ -102,6 +102,7 @@ struct hs_orb {
     // pipelined host ingest (hs_orb_submit_batch / hs_orb_wait): two staging slots, a copy-in and a copy-out stream next to the compute stream
     struct IngestSlot {
         uint8_t* d_in = nullptr; size_t in_bytes = 0;          // frames of the batch in HBM
+        uint8_t* d_raw = nullptr; size_t raw_bytes = 0;        // hs_orb_submit_camera_batch: the camera's frames as uploaded (before PreProcessImg)
         uint8_t* d_out = nullptr; size_t out_bytes = 0;        // [counts | keypoints | descriptors | uRight | depth] in HBM
         uint8_t* h_out = nullptr; size_t h_out_bytes = 0;      // the same block in page-locked host memory
         hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
@@ -826,7 +827,7 @@ static void orb_destroy_now(hs_orb* h)
     if (h->s_in) hipStreamSynchronize(h->s_in);
     if (h->s_out) hipStreamSynchronize(h->s_out);
     for (auto& sl : h->slot) {
-        hipFree(sl.d_in); hipFree(sl.d_out);
+        hipFree(sl.d_in); hipFree(sl.d_raw); hipFree(sl.d_out);
         if (sl.h_out) hipHostFree(sl.h_out);
         if (sl.ev_in) hipEventDestroy(sl.ev_in);
         if (sl.ev_done) hipEventDestroy(sl.ev_done);
@@ -1193,11 +1194,14 @@ int hs_host_alloc(size_t bytes, void** out)
 }
 void hs_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride, const hs_stereo_params* sp, int32_t* ticket)
+// shared by hs_orb_submit_batch (grey frames: pp == nullptr, src_w x src_h IS the level-0 size) and hs_orb_submit_camera_batch (pp: the camera's own frames;
+// ImageProcessing::PreProcessImg runs on the compute stream between the copy-in and the pyramid)
+static int submit_frames(hs_orb* h, const uint8_t* const* imgs, int batch, int src_w, int src_h, size_t stride, const hs_preprocess_params* pp, const hs_stereo_params* sp, int32_t* ticket)
 {
-    if (!h) return HS_ERR_INVALID;
-    if (!imgs || !ticket || batch < 1 || batch > 65535 || w < 1 || h_px < 1 || stride < w || (sp && (batch & 1))) return fail(h, HS_ERR_INVALID, "bad argument");
     for (int i = 0; i < batch; i++) if (!imgs[i]) return fail(h, HS_ERR_INVALID, "null image in batch");
+    int w = src_w, h_px = src_h;
+    if (pp) hs_preprocess_out_size(src_w, src_h, pp->scale, &w, &h_px);
+    if (w < 1 || h_px < 1) return fail(h, HS_ERR_INVALID, "the camera scale reduces the frame to nothing (cv::resize asserts on an empty size)");
     *ticket = 0;
     h->pub_kps = nullptr; h->pub_desc = nullptr; h->pub_batch = 0;      // a slot's device block may be rewritten from here on
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1226,6 +1230,12 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
         HIP_TRY(h, hipMalloc(&sl->d_in, per_img * batch));
         sl->in_bytes = per_img * batch;
     }
+    const size_t raw_row = pp ? (size_t)src_w * pp->channels : 0, rpitch = (raw_row + 3) & ~(size_t)3, raw_img = rpitch * src_h;      // the camera's frames as uploaded
+    if (pp && raw_img * batch > sl->raw_bytes) {
+        hipFree(sl->d_raw); sl->d_raw = nullptr; sl->raw_bytes = 0;
+        HIP_TRY(h, hipMalloc(&sl->d_raw, raw_img * batch));
+        sl->raw_bytes = raw_img * batch;
+    }
     sl->off_k = pad256((size_t)batch * 4);
     sl->off_d = sl->off_k + pad256((size_t)batch * cap * sizeof(hs_keypoint));
     sl->off_u = sl->off_d + pad256((size_t)batch * cap * HS_DESC_BYTES);
@@ -1252,11 +1262,17 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
     auto enqueue = [&]() -> int {
     // copy-in stream: page-locked frames (hs_host_alloc) go by DMA at link speed and the call returns at once; pageable frames go through the
     // runtime's staging path (the call returns when they are staged) — either way the compute stream keeps running the previous batch
-    for (int i = 0; i < batch; i++)
-        HIP_TRY(h, hipMemcpy2DAsync(sl->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, h->s_in));
+    for (int i = 0; i < batch; i++) {
+        if (pp) HIP_TRY(h, hipMemcpy2DAsync(sl->d_raw + raw_img * i, rpitch, imgs[i], stride, raw_row, src_h, hipMemcpyHostToDevice, h->s_in));
+        else HIP_TRY(h, hipMemcpy2DAsync(sl->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, h->s_in));
+    }
     HIP_TRY(h, hipEventRecord(sl->ev_in, h->s_in));
     hipStream_t s = h->stream;
     HIP_TRY(h, hipStreamWaitEvent(s, sl->ev_in, 0));
+    if (pp) {      // camera scale + grey on the compute stream, into the slot's level-0 frames
+        hs_launch_preprocess(sl->d_raw, src_w, src_h, rpitch, raw_img, pp->channels, pp->rgb, pp->scale, sl->d_in, w, h_px, pitch, per_img, 1, batch, s);
+        HIP_TRY(h, hipGetLastError());
+    }
     int32_t* d_n = reinterpret_cast<int32_t*>(sl->d_out);
     hs_keypoint* d_k = reinterpret_cast<hs_keypoint*>(sl->d_out + sl->off_k);
     uint8_t* d_d = sl->d_out + sl->off_d;
@@ -1300,6 +1316,23 @@ int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
     if (h->next_ticket <= 0) h->next_ticket = 1;
     *ticket = sl->ticket;
     return HS_OK;
+}
+
+int hs_orb_submit_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, int stride, const hs_stereo_params* sp, int32_t* ticket)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!imgs || !ticket || batch < 1 || batch > 65535 || w < 1 || h_px < 1 || stride < w || (sp && (batch & 1))) return fail(h, HS_ERR_INVALID, "bad argument");
+    return submit_frames(h, imgs, batch, w, h_px, (size_t)stride, nullptr, sp, ticket);
+}
+
+int hs_orb_submit_camera_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t row_stride, const hs_preprocess_params* pp,
+                               const hs_stereo_params* sp, int32_t* ticket)
+{
+    if (!h) return HS_ERR_INVALID;
+    if (!preprocess_params_ok(pp) || !imgs || !ticket || batch < 1 || batch > 65535 || w < 1 || h_px < 1 || w > 32768 || h_px > 32768 ||
+        row_stride < (size_t)w * pp->channels || (sp && (batch & 1)))
+        return fail(h, HS_ERR_INVALID, "bad argument");
+    return submit_frames(h, imgs, batch, w, h_px, row_stride, pp, sp, ticket);
 }
 
 int hs_orb_wait(hs_orb* h, int32_t ticket, hs_keypoint* kps, uint8_t* desc, int32_t* n, int cap, float* uRight, float* depth)

@@ -218,6 +218,23 @@ class ORBExtractor:
         self._tickets[t.value] = (b, sp is not None, images, self.max_keypoints())
         return t.value
 
+    def submit_camera_batch(self, frames, rgb, scale, sp=None):
+        """the same with the camera's own frames (hs_orb_submit_camera_batch): equal-sized (h, w) or (h, w, 3 | 4) uint8 arrays, C-contiguous; PreProcessImg (camera
+        scale + grey) runs on the device in front of the pyramid; with `sp` the first half are the left frames, the second half the right ones."""
+        b = len(frames)
+        for im in frames:
+            if im.dtype != np.uint8 or im.ndim not in (2, 3) or im.shape != frames[0].shape or not im.flags["C_CONTIGUOUS"] or (im.ndim == 3 and im.shape[2] not in (3, 4)):
+                raise TypeError("camera frames must be equal-sized C-contiguous (h, w) or (h, w, 3 | 4) uint8 arrays")
+        h, w = frames[0].shape[:2]
+        cn = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        pp = N.PreprocessParams(cn, int(bool(rgb)), float(scale), 0)
+        ptrs = (C.c_void_p * b)(*[im.ctypes.data for im in frames])
+        t = C.c_int32()
+        N.check(self._h, self._lib.hs_orb_submit_camera_batch(self._h, ptrs, b, w, h, frames[0].strides[0], C.byref(pp), C.byref(sp) if sp is not None else None, C.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = (b, sp is not None, frames, self.max_keypoints())
+        return t.value
+
     def wait(self, ticket, out=None):
         """-> (n[b], kps[b, cap], desc[b, cap, 32], uRight[b/2, cap] | None, depth[b/2, cap] | None); entries beyond n[i] are undefined.
         `out` = a tuple of arrays from a previous call to reuse."""

@@ -423,6 +423,22 @@ public:
         timing.gather_ms = hip_detail::ms_since(t0);
         return t;
     }
+    // the same with the frames as the camera delivers them (CV_8UC1 / CV_8UC3 / CV_8UC4; Camera::RGB, Camera::scale): ImageProcessing::PreProcessImg for both
+    // eyes (ImageProcessing.cpp:76-77) runs on the device inside the ticket (hs_orb_submit_camera_batch)
+    int32_t submitCamera(const cv::Mat& rawLeft, const cv::Mat& rawRight, bool rgb, float scale) {
+        const int cn = rawLeft.empty() ? 0 : rawLeft.channels();
+        if (rawLeft.empty() || rawRight.empty() || rawLeft.type() != rawRight.type() || (rawLeft.type() & 7) != CV_8U || !(cn == 1 || cn == 3 || cn == 4) ||
+            rawLeft.cols != rawRight.cols || rawLeft.rows != rawRight.rows || rawLeft.step != rawRight.step)
+            throw std::runtime_error("HipStereoFrontend: two 8-bit frames of 1, 3 or 4 channels, one size and one row step");
+        hs_preprocess_params pp; pp.channels = cn; pp.rgb = rgb ? 1 : 0; pp.scale = scale; pp._pad = 0;
+        const uint8_t* imgs[2] = { rawLeft.ptr(0), rawRight.ptr(0) };
+        int32_t t = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = hs_orb_submit_camera_batch(h, imgs, 2, rawLeft.cols, rawLeft.rows, (size_t)rawLeft.step, &pp, &sp, &t);
+        if (st != HS_OK) throw std::runtime_error(std::string("HipStereoFrontend: ") + hs_status_string(st) + ": " + hs_orb_last_error(h));
+        timing.gather_ms = hip_detail::ms_since(t0);
+        return t;
+    }
     // wait for a ticket and build the stereo FeatureViews (keys, keysR, uRight, depth, descriptors, descriptorsR — FeatureViews.h:20-81)
     FeatureViews collect(int32_t ticket) {
         const int cap = hs_orb_max_keypoints(h);
@@ -460,6 +476,7 @@ public:
         return views;
     }
     FeatureViews process(const cv::Mat& imLeft, const cv::Mat& imRight) { return collect(submit(imLeft, imRight)); }
+    FeatureViews processCamera(const cv::Mat& rawLeft, const cv::Mat& rawRight, bool rgb, float scale) { return collect(submitCamera(rawLeft, rawRight, rgb, scale)); }
     hs_orb* handle() { return h; }
     HipCallTiming timing;             // gather = submit (H2D enqueue), abi = wait, scatter = FeatureViews construction
 

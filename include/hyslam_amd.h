@@ -117,6 +117,12 @@ int  hs_preprocess_device(hs_orb* h, const uint8_t* d_src, int w, int h_px, size
  * grey_out (may be NULL): the grey frames, batch x oh x ow tight — what the reference keeps as track_data.image (:60,108). */
 int  hs_orb_extract_camera_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t row_stride, const hs_preprocess_params* pp,
                                  hs_keypoint* kps, uint8_t* desc, int cap, int32_t* n, uint8_t* grey_out);
+/* the same through the pipelined ingest (hs_orb_submit_batch's ticket machinery, two tickets in flight): the camera's frames are copied in on the copy-in
+ * stream, PreProcessImg runs on the compute stream in front of the pyramid; with `sp` the batch is [left frames | right frames] of batch / 2 stereo pairs and the
+ * ticket also carries uRight / depth — ProcessStereoImage's PreProcessImg x 2 + extractors + Stereomatcher (ImageProcessing.cpp:76-103) as ONE ticket.
+ * Results by hs_orb_wait as for any ticket (cap >= hs_orb_max_keypoints for the SCALED size). */
+int  hs_orb_submit_camera_batch(hs_orb* h, const uint8_t* const* imgs, int batch, int w, int h_px, size_t row_stride, const hs_preprocess_params* pp,
+                                const hs_stereo_params* sp, int32_t* ticket);
 
 /* Device-resident batch: image i starts at d_imgs + i*image_stride, rows `row_stride` bytes apart.
  * d_kps [batch][cap], d_desc [batch][cap][32] (16-byte aligned), d_n [batch]; all device memory.  Asynchronous.

@@ -149,6 +149,23 @@ int main(int argc, char** argv)
         for (int i = 0; i < nL; i++) if (uR3[i] != ouR[i] || depth3[i] != odepth[i]) { printf("stereo host fallback: %d differs\n", i); return 26; }
         printf("device frames: stereo on cached frames ok, projection search %d matches (device == host), slot reuse ok\n", n1);
     }
+    // ---- HipStereoFrontend::processCamera: the pair as BGR frames of twice the size at the camera scale 0.5 is the grey pair again (see below): the views must
+    //      equal the oracle's for (L, R)
+    {
+        Camera cam2; cam2.sensor = 1;
+        for (int i = 0; i < 9; i++) cam2.K.at<float>(i / 3, i % 3) = 0.f;
+        cam2.K.at<float>(0, 0) = 500.f; cam2.K.at<float>(1, 1) = 500.f; cam2.K.at<float>(2, 2) = 1.f;
+        cam2.mbf = 60.f; cam2.mnMinX = 0; cam2.mnMaxX = (float)W; cam2.mnMinY = 0; cam2.mnMaxY = (float)H;
+        HipStereoFrontend fe(dist, s, cam2, ms);
+        cv::Mat bigL(2 * H, 2 * W, CV_8UC3), bigR(2 * H, 2 * W, CV_8UC3);
+        for (int y = 0; y < 2 * H; y++) for (int x = 0; x < 2 * W; x++) for (int k = 0; k < 3; k++) { bigL.ptr(y)[3 * x + k] = L.ptr(y / 2)[x / 2]; bigR.ptr(y)[3 * x + k] = R.ptr(y / 2)[x / 2]; }
+        FeatureViews v = fe.processCamera(bigL, bigR, false, 0.5f);
+        if (v.numViews() != nL) { printf("processCamera: %d views, expected %d\n", v.numViews(), nL); return 34; }
+        for (int i = 0; i < nL; i++)
+            if (v.keypt(i).pt.x != okL[i].x || v.keypt(i).pt.y != okL[i].y || v.uR(i) != ouR[i] || v.depth(i) != odepth[i] || memcmp(v.descriptor(i).rawDescriptor().ptr(0), &odL[i * 32], 32)) {
+                printf("processCamera: view %d differs\n", i); return 35; }
+        printf("processCamera: BGR pair 2x at scale 0.5 == the oracle's stereo views (%d)\n", nL);
+    }
     // ---- extractFromCamera (ImageProcessing::PreProcessImg on the device): the left frame as a BGR frame of twice the size (every pixel a 2x2 block of
     //      equal channels) at the camera scale 0.5 is the grey frame again — the rounded 2x2 mean of four equal bytes and 4899 + 9617 + 1868 = 2^14 —, so
     //      features and the grey frame handed back must equal the oracle's for L; then against the oracle's PreProcessImg on a frame with three different channels

@@ -67,6 +67,49 @@ def test_camera_frame_in_features_out(gpu, w, h, cn, rgb, scale, nfeat, fscale):
     assert all(a.tobytes() == b.tobytes() for a, b in zip(k, k2)) and all(np.array_equal(a, b) for a, b in zip(d, d2))
 
 
+@pytest.mark.parametrize("cn,rgb,scale", [(3, True, 0.5), (4, False, 1.0), (3, False, 0.75), (1, True, 0.5)])
+def test_stereo_front_end_from_camera_frames(gpu, cn, rgb, scale):
+    """ProcessStereoImage with PreProcessImg inside (ImageProcessing.cpp:76-103) as ONE ticket of the pipelined ingest (hs_orb_submit_camera_batch): colour stereo
+    pairs at the camera's own size in, keypoints / descriptors / uRight / depth out — against oracle.stereo_frontend on the oracle's grey frames; two tickets in
+    flight, then a grey ticket on the same handle (the slots' raw buffers and the geometry switch)."""
+    from hyslam_amd.synth import synth_stereo_pair
+    from hyslam_amd import _native as N
+    W, H, P = 640, 480, 3
+    sw, sh = int(round(W / scale)), int(round(H / scale))
+    ow, oh = oracle.preprocess_size(sw, sh, scale)
+    ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=1000))
+    p = oracle.default_params(1000)
+
+    def colour(g, k):
+        if cn == 1:
+            return g
+        ch = [g, np.roll(g, 2 + k, axis=1), np.roll(g, 1 + k, axis=0)] + ([np.full_like(g, 9)] if cn == 4 else [])
+        return np.ascontiguousarray(np.stack(ch, axis=2))
+    pairs = [synth_stereo_pair(700 + i, sw, sh) for i in range(P)]
+    lefts, rights = [colour(a, 0) for a, _ in pairs], [colour(b, 0) for _, b in pairs]
+    gsp = N.StereoParams(500.0, 60.0, oh, 100.0, 50.0, 31.0)
+    osp = oracle.stereo_params(fx=500.0, mbf=60.0, n_rows=oh)
+    t1 = ex.submit_camera_batch(lefts + rights, rgb, scale, gsp)
+    t2 = ex.submit_camera_batch(lefts[:1] + rights[:1], rgb, scale, gsp)
+    for t, idx in ((t1, range(P)), (t2, range(1))):
+        n, k, d, u, z = ex.wait(t)
+        npairs = len(idx)
+        for j in idx:
+            gl, gr = oracle.preprocess(lefts[j], rgb, scale), oracle.preprocess(rights[j], rgb, scale)
+            assert gl.shape == (oh, ow)
+            okL, odL, okR, odR, ou, oz = oracle.stereo_frontend(p, osp, gl, gr)
+            a, b = int(n[j]), int(n[npairs + j])
+            assert a == len(okL) and b == len(okR), (j, a, len(okL))
+            assert k[j, :a].tobytes() == okL.tobytes() and np.array_equal(d[j, :a], odL) and k[npairs + j, :b].tobytes() == okR.tobytes() and np.array_equal(d[npairs + j, :b], odR), j
+            assert np.array_equal(u[j, :a], ou) and np.array_equal(z[j, :a], oz), j
+            assert (oz > 0).sum() > 30
+    g = oracle.preprocess(lefts[0], rgb, scale)
+    t3 = ex.submit_batch([g])
+    n, k, d, _, _ = ex.wait(t3)
+    ok, od = oracle.extract(p, g)
+    assert k[0, :n[0]].tobytes() == ok.tobytes() and np.array_equal(d[0, :n[0]], od)
+
+
 def test_bad_camera_parameters_are_refused(gpu):
     ex = HS.ORBExtractor(HS.FeatureExtractorSettings(nFeatures=500))
     with pytest.raises(Exception):
