@@ -943,7 +943,7 @@ int extract_host_frames(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
         // one core copies 2 MB frames at ~10 GB/s, the runtime's staged copy moves them at more than twice that)
         for (int i = 0; i < batch; i++) {
             // a frame whose rows are as far apart as the staging copy's (width a multiple of 64, no padding: 1920 x 1080) is ONE linear copy
-            if (stride == pitch) HIP_TRY(h, hipMemcpyAsync(h->d_in + per_img * i, imgs[i], per_img, hipMemcpyHostToDevice, s));
+            if (stride == pitch && (size_t)w == pitch) HIP_TRY(h, hipMemcpyAsync(h->d_in + per_img * i, imgs[i], per_img, hipMemcpyHostToDevice, s));      // (rows with padding: the last row's padding need not exist in the caller's buffer)
             else HIP_TRY(h, hipMemcpy2DAsync(h->d_in + per_img * i, pitch, imgs[i], stride, w, h_px, hipMemcpyHostToDevice, s));
         }
     } else {
@@ -956,7 +956,7 @@ int extract_host_frames(hs_orb* h, const uint8_t* const* imgs, int batch, int w,
             h->raw_bytes = raw_img * batch;
         }
         for (int i = 0; i < batch; i++) {
-            if (stride == rpitch) HIP_TRY(h, hipMemcpyAsync(h->d_raw + raw_img * i, imgs[i], raw_img, hipMemcpyHostToDevice, s));
+            if (stride == rpitch && row_bytes == rpitch) HIP_TRY(h, hipMemcpyAsync(h->d_raw + raw_img * i, imgs[i], raw_img, hipMemcpyHostToDevice, s));
             else HIP_TRY(h, hipMemcpy2DAsync(h->d_raw + raw_img * i, rpitch, imgs[i], stride, row_bytes, h_px, hipMemcpyHostToDevice, s));
         }
         hs_launch_preprocess(h->d_raw, w, h_px, rpitch, raw_img, pp->channels, pp->rgb, pp->scale, h->d_in, gw, gh, pitch, per_img, 1, batch, s);
