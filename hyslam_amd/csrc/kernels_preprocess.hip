@@ -4,7 +4,7 @@
 // of both extractor calls (:76-77):   cv::resize(img, img, cv::Size(), fscale, fscale);   cvtColor(img, img, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY)
 // on a 1-, 3- or 4-channel 8-bit frame.  For the reference's own cameras (config/sample_primary_config_file.yaml:35-42,63-70) that is a copy for the
 // 1280x720 stereo pair (scale 1.0) and a 2704x2028x3 -> 1352x1014 reduction for the "Imaging" camera (scale 0.5) — milliseconds of CPU in front of a
-// 0.1 ms extraction, and 16 MB over PCIe instead of ... still 16 MB, but only once and with nothing waiting on a host core.
+// 0.1 ms extraction.  Here the frame crosses PCIe as the camera delivered it and no host core touches its pixels.
 //
 // OpenCV 3.4 semantics (the same status as every other primitive here: restated from its published algorithm, "parity unpinned" — DESIGN.md §1):
 //   size     (cvRound(w * (double)fscale), cvRound(h * (double)fscale)); the tables use scale = 1. / (double)fscale
